@@ -1,0 +1,168 @@
+// common.h -- context, workspace and launch helpers shared by every translation unit
+// of libtempest_hip.so.  gfx950 only; no CPU fallback anywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tempest_hip.h"
+
+namespace tsdr {
+
+// workspace slots: one growable device buffer each, owned by the context
+enum Slot {
+  WS_IN = 0,      // host-API staging of inputs
+  WS_OUT,         // host-API staging of outputs
+  WS_AUX,         // host-API staging (second output / state)
+  WS_ABS,         // |IQ| or power scratch
+  WS_RASTER,      // fallback raster when the fused path cannot tile
+  WS_IMG,         // per-frame 600x800 images of one buffer
+  WS_PROJ,        // raw + filtered projections, sums
+  WS_KEYS,        // packed argmax keys per frame
+  WS_FFT_A,       // FFT ping
+  WS_FFT_B,       // FFT pong
+  WS_FFT_C,       // Bluestein / correlation scratch
+  WS_FFT_D,
+  WS_MISC,
+  WS_COUNT
+};
+
+struct ProfRec {
+  const char *name;
+  hipEvent_t e0, e1;
+};
+
+struct TwTable {   // two-level table of W_N^e = exp(-2*pi*i*e/N), N = 2^logN
+  int logN = 0, h = 0;
+  float2 *lo = nullptr;  // W_N^j, j < 2^h
+  float2 *hi = nullptr;  // W_N^(j*2^h), j < 2^(logN-h)
+};
+
+struct BluesteinPlan {
+  size_t n = 0, L = 0;
+  float2 *chirp = nullptr;  // exp(-i*pi*k^2/n), k < n
+  float2 *bfft = nullptr;   // FFT_L of the wrapped conj chirp
+};
+
+}  // namespace tsdr
+
+struct tsdr_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  std::string err;
+  int cu_count = 0;
+  struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];
+  // profiling
+  bool prof_on = false;
+  std::vector<tsdr::ProfRec> prof;
+  std::vector<hipEvent_t> ev_pool;
+  struct ProfAgg { std::string name; double ms; long long n; };
+  std::vector<ProfAgg> prof_agg;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  // FFT state
+  float2 *tw_small = nullptr;  // W_4096^e, e < 4096
+  std::map<int, tsdr::TwTable> tw;
+  std::map<size_t, tsdr::BluesteinPlan> blu;
+
+  void *scratch(int slot, size_t bytes);  // nullptr on failure (err set)
+};
+
+namespace tsdr {
+
+int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...);
+int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what);
+void prof_begin(tsdr_ctx *ctx, const char *name);
+void prof_end(tsdr_ctx *ctx);
+
+#define TSDR_HIP(ctx, call)                                          \
+  do {                                                               \
+    hipError_t _e = (call);                                          \
+    if (_e != hipSuccess) return tsdr::hip_fail((ctx), _e, #call);   \
+  } while (0)
+
+// Launch a kernel on the context's stream; when profiling is on the launch is
+// bracketed by its own hipEvent pair so bench.py can read per-kernel durations live.
+#define TSDR_LAUNCH(ctx, kname, kernel, grid, block, shmem, ...)                              \
+  do {                                                                                        \
+    if ((ctx)->prof_on) tsdr::prof_begin((ctx), kname);                                       \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);               \
+    if ((ctx)->prof_on) tsdr::prof_end((ctx));                                                \
+    hipError_t _le = hipGetLastError();                                                       \
+    if (_le != hipSuccess) return tsdr::hip_fail((ctx), _le, kname);                          \
+  } while (0)
+
+static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// grid for a capped, grid-strided streaming kernel of 256-thread workgroups
+static inline int stream_grid(tsdr_ctx *ctx, size_t work_items) {
+  size_t blocks = ceil_div(work_items, 256);
+  size_t cap = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+// Host-pointer wrapper: stage `in` to the device, run the device-pointer core on the
+// context's stream, copy `out` back, synchronise.  run(din, dout) returns a tsdr_status.
+template <typename F>
+static inline int host_map(tsdr_ctx *ctx, const void *in, size_t in_bytes, void *out, size_t out_bytes, F run) {
+  if (!ctx) return TSDR_EINVAL;
+  if ((in_bytes && !in) || (out_bytes && !out)) return TSDR_EINVAL;
+  void *din = ctx->scratch(WS_IN, in_bytes);
+  void *dout = ctx->scratch(WS_OUT, out_bytes);
+  if (!din || !dout) return TSDR_ENOMEM;
+  if (in_bytes) TSDR_HIP(ctx, hipMemcpyAsync(din, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  int rc = run(din, dout);
+  if (rc) return rc;
+  if (out_bytes) TSDR_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TSDR_OK;
+}
+static inline int ilog2(size_t v) { int l = 0; while ((size_t(1) << l) < v) ++l; return l; }
+static inline bool is_pow2(size_t v) { return v && !(v & (v - 1)); }
+
+// ---- imresize coordinate helpers (shared host/device; mirrors oracle resize_axis /
+// resize_coord / lin_pos, i.e. ImageTransformations.imresize! + Interpolations Linear) ----
+struct RsAxis { double sf, off, n_in; };
+
+__host__ __device__ inline RsAxis rs_axis(size_t n_in, size_t n_out) {
+  RsAxis a;
+  a.sf = (double)n_in / (double)n_out;
+  a.off = (1.0 - 0.5) - a.sf * (1.0 - 0.5);
+  a.n_in = (double)n_in;
+  return a;
+}
+
+#ifdef __HIPCC__
+// x = sf*i + off with two roundings (no FMA), clamped to [1, n_in]; returns the 0-based
+// left sample index and the f64 weight of the right sample.
+__device__ inline unsigned rs_pos(const RsAxis &a, double i1, double &delta) {
+  double x = __dadd_rn(__dmul_rn(a.sf, i1), a.off);
+  x = fmax(x, 1.0);
+  x = fmin(x, a.n_in);
+  double xf = floor(x);
+  if (xf > a.n_in - 1.0) xf -= 1.0;
+  delta = x - xf;
+  return (unsigned)xf - 1u;
+}
+// (1-d)*a + d*b in f64 (two products, one sum, no FMA), rounded once to f32
+__device__ inline float rs_blend(float a, float b, double d) {
+  double v = __dadd_rn(__dmul_rn(1.0 - d, (double)a), __dmul_rn(d, (double)b));
+  return (float)v;
+}
+// |re + i*im| = f32( sqrt_f64( re^2 + im^2 ) ), the squares exact in f64
+__device__ inline float abs_c(float re, float im) {
+  double s = __dadd_rn(__dmul_rn((double)re, (double)re), __dmul_rn((double)im, (double)im));
+  float r = (float)sqrt(s);
+  if (isinf(re) || isinf(im)) r = INFINITY;
+  return r;
+}
+__device__ inline float abs2_c(float re, float im) { return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)); }
+#endif
+
+}  // namespace tsdr

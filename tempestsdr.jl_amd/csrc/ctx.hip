@@ -1,0 +1,251 @@
+// ctx.hip -- context lifetime, workspace, error reporting, HIP-event measurement.
+#include <cstdarg>
+#include <cstring>
+
+#include "common.h"
+
+namespace tsdr {
+
+int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return status;
+}
+
+int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what) {
+  return set_err(ctx, TSDR_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+static hipEvent_t take_event(tsdr_ctx *ctx) {
+  if (!ctx->ev_pool.empty()) {
+    hipEvent_t e = ctx->ev_pool.back();
+    ctx->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void prof_begin(tsdr_ctx *ctx, const char *name) {
+  ProfRec r;
+  r.name = name;
+  r.e0 = take_event(ctx);
+  r.e1 = take_event(ctx);
+  (void)hipEventRecord(r.e0, ctx->stream);
+  ctx->prof.push_back(r);
+}
+
+void prof_end(tsdr_ctx *ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->stream); }
+
+// fold finished event pairs into the per-kernel aggregate
+static int prof_collect(tsdr_ctx *ctx) {
+  if (ctx->prof.empty()) return TSDR_OK;
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &r : ctx->prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    bool found = false;
+    for (auto &a : ctx->prof_agg)
+      if (a.name == r.name) { a.ms += ms; a.n += 1; found = true; break; }
+    if (!found) ctx->prof_agg.push_back({r.name, (double)ms, 1});
+    ctx->ev_pool.push_back(r.e0);
+    ctx->ev_pool.push_back(r.e1);
+  }
+  ctx->prof.clear();
+  return TSDR_OK;
+}
+
+}  // namespace tsdr
+
+void *tsdr_ctx::scratch(int slot, size_t bytes) {
+  Buf &b = ws[slot];
+  if (bytes == 0) bytes = 16;
+  if (b.cap >= bytes) return b.p;
+  if (b.p) {
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 4096;  // slack so slowly growing inputs do not realloc
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    tsdr::set_err(this, TSDR_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    return nullptr;
+  }
+  b.cap = want;
+  return b.p;
+}
+
+extern "C" {
+
+const char *tsdr_version(void) { return "tempest-hip 0.1 (gfx950)"; }
+
+const char *tsdr_strerror(int s) {
+  switch (s) {
+    case TSDR_OK: return "ok";
+    case TSDR_EINVAL: return "invalid argument (AssertionError/ArgumentError in the reference)";
+    case TSDR_EBOUNDS: return "index out of bounds (BoundsError in the reference)";
+    case TSDR_ENOMEM: return "out of device memory";
+    case TSDR_EHIP: return "HIP runtime error";
+    case TSDR_ENODEV: return "no usable HIP device";
+    default: return "unknown status";
+  }
+}
+
+const char *tsdr_last_error(tsdr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+tsdr_ctx *tsdr_create(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    fprintf(stderr, "tempest_hip: no usable HIP device (requested %d, found %d); there is no CPU fallback\n",
+            device, ndev);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  tsdr_ctx *ctx = new tsdr_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  ctx->own_stream = true;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+  (void)hipEventCreate(&ctx->t0);
+  (void)hipEventCreate(&ctx->t1);
+  return ctx;
+}
+
+void tsdr_destroy(tsdr_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
+  for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->tw_small) (void)hipFree(ctx->tw_small);
+  for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
+  for (auto &kv : ctx->blu) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.bfft); }
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream) {
+  if (!ctx) return TSDR_EINVAL;
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hip_stream) {
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+  } else if (!ctx->own_stream) {
+    TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return TSDR_OK;
+}
+
+int tsdr_synchronize(tsdr_ctx *ctx) {
+  if (!ctx) return TSDR_EINVAL;
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TSDR_OK;
+}
+
+int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_t *hbm_bytes) {
+  if (!ctx) return TSDR_EINVAL;
+  hipDeviceProp_t prop;
+  TSDR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (name && cap) { snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName); }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return TSDR_OK;
+}
+
+void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) {
+    tsdr::set_err(ctx, TSDR_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+int tsdr_dev_free(tsdr_ctx *ctx, void *dev) {
+  if (!ctx) return TSDR_EINVAL;
+  if (dev) { TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream)); TSDR_HIP(ctx, hipFree(dev)); }
+  return TSDR_OK;
+}
+
+int tsdr_upload(tsdr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  if (!ctx || (bytes && (!dst_dev || !src_host))) return TSDR_EINVAL;
+  if (bytes) {
+    TSDR_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return TSDR_OK;
+}
+
+int tsdr_download(tsdr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+  if (!ctx || (bytes && (!dst_host || !src_dev))) return TSDR_EINVAL;
+  if (bytes) {
+    TSDR_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return TSDR_OK;
+}
+
+int tsdr_timer_start(tsdr_ctx *ctx) {
+  if (!ctx) return TSDR_EINVAL;
+  TSDR_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return TSDR_OK;
+}
+
+int tsdr_timer_stop(tsdr_ctx *ctx, double *ms) {
+  if (!ctx || !ms) return TSDR_EINVAL;
+  TSDR_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  TSDR_HIP(ctx, hipEventSynchronize(ctx->t1));
+  float f = 0.f;
+  TSDR_HIP(ctx, hipEventElapsedTime(&f, ctx->t0, ctx->t1));
+  *ms = f;
+  return TSDR_OK;
+}
+
+int tsdr_profile_enable(tsdr_ctx *ctx, int on) {
+  if (!ctx) return TSDR_EINVAL;
+  int rc = tsdr::prof_collect(ctx);
+  ctx->prof_on = on != 0;
+  return rc;
+}
+
+int tsdr_profile_reset(tsdr_ctx *ctx) {
+  if (!ctx) return TSDR_EINVAL;
+  int rc = tsdr::prof_collect(ctx);
+  ctx->prof_agg.clear();
+  return rc;
+}
+
+int tsdr_profile_count(tsdr_ctx *ctx) {
+  if (!ctx) return TSDR_EINVAL;
+  int rc = tsdr::prof_collect(ctx);
+  if (rc) return rc;
+  return (int)ctx->prof_agg.size();
+}
+
+int tsdr_profile_get(tsdr_ctx *ctx, int idx, char *name, size_t cap, double *total_ms, long long *launches) {
+  if (!ctx || idx < 0 || idx >= (int)ctx->prof_agg.size()) return TSDR_EINVAL;
+  const auto &a = ctx->prof_agg[idx];
+  if (name && cap) snprintf(name, cap, "%s", a.name.c_str());
+  if (total_ms) *total_ms = a.ms;
+  if (launches) *launches = a.n;
+  return TSDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+// sync.hip -- FrameSynchronisation.jl on gfx950, plus the per-frame post-ops of the GUI loop.
+//
+//   vsync(image,sync)            FrameSynchronisation.jl:56-79
+//   fill_beta!                   :94-112      averagePixel :84-90     modIndex :120-122
+//   init_gaussian_filter(5)      :124-129
+//   circshift + IIR              GUI.jl:172,175
+//
+// The arithmetic follows the oracle's evaluation ORDER, not only its formulas, so that for the
+// same image the projections, beta values and therefore the argmax indices are bit-identical:
+//   * column / row sums accumulate sequentially in f32 (one lane per column / row),
+//   * the 5-tap causal FIR uses the transposed-direct-form association
+//       y[i] = ((((h4 x[i-4]) + h3 x[i-3]) + h2 x[i-2]) + h1 x[i-1]) + h0 x[i],
+//   * Sigma = sum(c_v) is one sequential f32 chain,
+//   * each centre's running blank sum _Sigma is the reference's sequential recurrence over w.
+// Parallelism comes from frames x centres (one lane per centre, 64 centres per wavefront);
+// the argmax over (w,c) is a lane-local scan, a 64-wide shuffle reduction and one 64-bit
+// atomicMax per wavefront on a packed key (beta bits << 32 | ~c): beta >= +0 so its bit
+// pattern is order-preserving, NaN patterns sort above +Inf (Julia's findmax treats NaN as
+// maximal), and ~c makes the smallest column win ties = first maximum in column-major order.
+#include "common.h"
+
+struct tsdr_sync {
+  tsdr_ctx *ctx;
+  int y_t, x_t;
+  int wmin_y, wmax_y, wmin_x, wmax_x;
+  float h[5];
+  float *beta_x = nullptr;  // device, (1+wmax_x-wmin_x) x x_t
+  float *beta_y = nullptr;  // device, (1+wmax_y-wmin_y) x y_t
+  int *pending = nullptr;   // device: [0] = s_y the next vsync call will return (argmax of beta_y)
+};
+
+namespace tsdr {
+
+struct SyncGeom {
+  int y_t, x_t, wmin_y, wmax_y, wmin_x, wmax_x;
+  float h0, h1, h2, h3, h4;
+};
+
+// ---- projections: raw sums --------------------------------------------------------------
+// proj layout per frame: [ cv_raw (x_t) | ch_raw (y_t) | cv_f (x_t) | ch_f (y_t) | Sigma_x | Sigma_y | pad ]
+__host__ __device__ inline size_t proj_stride(int y_t, int x_t) { return (size_t)2 * (x_t + y_t) + 4; }
+
+// grid.x = ceil(x_t/64) + ceil(y_t/64) wavefront-sized blocks, grid.y = frames
+__global__ __launch_bounds__(64) void k_sums(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
+                                             float *__restrict__ proj) {
+  const int f = blockIdx.y;
+  const float *im = img + (size_t)f * img_stride;
+  float *pr = proj + (size_t)f * proj_stride(y_t, x_t);
+  const int nbx = (x_t + 63) >> 6;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < nbx) {
+    // sum(image;dims=1): one lane per column, rows in order
+    const int c = blockIdx.x * 64 + lane;
+    if (c >= x_t) return;
+    const float *col = im + (size_t)c * y_t;
+    float a = 0.0f;
+    int r = 0;
+    if ((((uintptr_t)col) & 15) == 0) {
+      for (; r + 4 <= y_t; r += 4) {
+        float4 v = *reinterpret_cast<const float4 *>(col + r);
+        a = __fadd_rn(a, v.x); a = __fadd_rn(a, v.y); a = __fadd_rn(a, v.z); a = __fadd_rn(a, v.w);
+      }
+    }
+    for (; r < y_t; ++r) a = __fadd_rn(a, col[r]);
+    pr[c] = a;
+  } else {
+    // sum(image;dims=2): one lane per row, columns in order (coalesced across lanes)
+    const int r = (blockIdx.x - nbx) * 64 + lane;
+    if (r >= y_t) return;
+    float a = 0.0f;
+    const float *p = im + r;
+#pragma unroll 8
+    for (int c = 0; c < x_t; ++c) a = __fadd_rn(a, p[(size_t)c * y_t]);
+    pr[x_t + r] = a;
+  }
+}
+
+// ---- FIR + Sigma; also zeroes the argmax keys.  grid = (2, frames), 256 threads ----------
+__global__ __launch_bounds__(256) void k_fir(float *__restrict__ proj, SyncGeom g,
+                                             unsigned long long *__restrict__ keys) {
+  extern __shared__ float s[];
+  const int f = blockIdx.y, axis = blockIdx.x;  // 0: x (columns, c_v), 1: y (rows, c_h)
+  const int n = axis == 0 ? g.x_t : g.y_t;
+  float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
+  const float *raw = pr + (axis == 0 ? 0 : g.x_t);
+  float *flt = pr + (g.x_t + g.y_t) + (axis == 0 ? 0 : g.x_t);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float acc = __fmul_rn(g.h4, i >= 4 ? raw[i - 4] : 0.0f);
+    acc = __fadd_rn(acc, __fmul_rn(g.h3, i >= 3 ? raw[i - 3] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h2, i >= 2 ? raw[i - 2] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h1, i >= 1 ? raw[i - 1] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h0, raw[i]));
+    s[i] = acc;
+    flt[i] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float S = 0.0f;
+    for (int i = 0; i < n; ++i) S = __fadd_rn(S, s[i]);
+    pr[2 * (g.x_t + g.y_t) + axis] = S;
+    keys[(size_t)f * 2 + axis] = 0ull;
+  }
+}
+
+__device__ inline unsigned long long pack_key(float v, int c) {
+  unsigned bits = (v != v) ? 0x7FC00000u : __float_as_uint(v);
+  return ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c);
+}
+
+// ---- beta search: one lane per centre.  grid.x = ceil(x_t/64)+ceil(y_t/64), grid.y = frames --
+// write_frame: frame whose beta matrices are materialised into bx/by (-1: none)
+__global__ __launch_bounds__(64) void k_beta(const float *__restrict__ proj, SyncGeom g,
+                                             unsigned long long *__restrict__ keys, int write_frame,
+                                             float *__restrict__ bx, float *__restrict__ by) {
+  extern __shared__ float cv[];
+  const int f = blockIdx.y;
+  const int nbx = (g.x_t + 63) >> 6;
+  const int axis = (int)blockIdx.x < nbx ? 0 : 1;
+  const int n = axis == 0 ? g.x_t : g.y_t;
+  const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
+  const float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
+  const float *flt = pr + (g.x_t + g.y_t) + (axis == 0 ? 0 : g.x_t);
+  const float S = pr[2 * (g.x_t + g.y_t) + axis];
+  for (int i = threadIdx.x; i < n; i += 64) cv[i] = flt[i];
+  __syncthreads();
+  const int c0 = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64 + threadIdx.x;  // 0-based centre
+  unsigned long long key = 0ull;
+  if (c0 < n) {
+    const int W = w_max - w_min + 1;
+    float *bout = (f == write_frame) ? (axis == 0 ? bx : by) + (size_t)c0 * W : nullptr;
+    // averagePixel(c_v,c,w_min-1,n): sequential, circular
+    float acc = 0.0f;
+    int k = c0 - (w_min - 1);
+    k %= n; if (k < 0) k += n;
+    for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) {
+      acc = __fadd_rn(acc, cv[k]);
+      if (++k == n) k = 0;
+    }
+    float s = __fmul_rn(2.0f, acc);
+    int lo = c0 - w_min, hi = c0 + w_min;
+    lo %= n; if (lo < 0) lo += n;
+    hi %= n;
+    float bv = -1.0f;  // below any beta (>= +0); first comparison always takes the first value
+    bool have = false;
+    for (int w = w_min; w <= w_max; ++w) {
+      s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
+      s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
+      float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
+      v = __fmul_rn(v, v);
+      if (bout) bout[w - w_min] = v;
+      if (!have) { bv = v; have = true; }
+      else if (!(bv != bv) && (v != v || v > bv)) bv = v;
+      if (--lo < 0) lo = n - 1;
+      if (++hi == n) hi = 0;
+    }
+    key = pack_key(bv, c0);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_xor(key, off, 64);
+    key = o > key ? o : key;
+  }
+  if (threadIdx.x == 0) atomicMax(&keys[(size_t)f * 2 + axis], key);
+}
+
+__device__ inline int key_col1(unsigned long long key) {  // 1-based column of the packed argmax
+  return (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) + 1;
+}
+
+// ---- shift + IIR over the frames of one buffer (GUI.jl:172,175) ----------------------------
+// For frame f: s_x = argmax beta_x(f); s_y = argmax beta_y(f-1) (pending[0] for f = 0).
+// out = alpha*out + (1-alpha)*img_shifted, f32, two products and one sum (no FMA).
+__global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img, size_t img_stride, int h, int w,
+                                                   int frames, const unsigned long long *__restrict__ keys,
+                                                   const int *__restrict__ pending, int do_align, float alpha,
+                                                   float *__restrict__ state, float *__restrict__ frames_out) {
+  const size_t npx = (size_t)h * w;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npx) return;
+  const int i = (int)(idx % (size_t)h), j = (int)(idx / (size_t)h);
+  float acc = state[idx];
+  const float oma = __fsub_rn(1.0f, alpha);
+  for (int f = 0; f < frames; ++f) {
+    size_t src = idx;
+    if (do_align) {
+      const int sy = f == 0 ? pending[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
+      const int sx = key_col1(keys[(size_t)f * 2 + 0]);
+      int si = i + sy; si %= h;
+      int sj = j + sx; sj %= w;
+      src = (size_t)sj * h + si;
+    }
+    const float v = img[(size_t)f * img_stride + src];
+    acc = __fadd_rn(__fmul_rn(alpha, acc), __fmul_rn(oma, v));
+    if (frames_out) frames_out[(size_t)f * npx + idx] = acc;
+  }
+  state[idx] = acc;
+}
+
+// after k_shift_iir: publish (s_y,s_x) per frame and roll the pending s_y forward
+__global__ void k_publish(const unsigned long long *__restrict__ keys, int frames, int *__restrict__ pending,
+                          int *__restrict__ sync_idx) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int sy = pending[0];
+  for (int f = 0; f < frames; ++f) {
+    if (sync_idx) { sync_idx[2 * f] = sy; sync_idx[2 * f + 1] = key_col1(keys[(size_t)f * 2 + 0]); }
+    sy = key_col1(keys[(size_t)f * 2 + 1]);
+  }
+  pending[0] = sy;
+}
+
+__global__ __launch_bounds__(256) void k_circshift(const float *__restrict__ in, int h, int w, int s_y, int s_x,
+                                                   float *__restrict__ out) {
+  const size_t npx = (size_t)h * w;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npx) return;
+  const int i = (int)(idx % (size_t)h), j = (int)(idx / (size_t)h);
+  int si = (i + s_y) % h; if (si < 0) si += h;
+  int sj = (j + s_x) % w; if (sj < 0) sj += w;
+  out[idx] = in[(size_t)sj * h + si];
+}
+
+// standalone fill_beta!: beta (W x n) from an already filtered projection
+__global__ __launch_bounds__(64) void k_fill_beta(const float *__restrict__ cvin, int n, int w_min, int w_max,
+                                                  float *__restrict__ beta) {
+  extern __shared__ float cv[];
+  for (int i = threadIdx.x; i < n; i += 64) cv[i] = cvin[i];
+  __syncthreads();
+  __shared__ float Ssh;
+  if (threadIdx.x == 0) {
+    float S = 0.0f;
+    for (int i = 0; i < n; ++i) S = __fadd_rn(S, cv[i]);
+    Ssh = S;
+  }
+  __syncthreads();
+  const float S = Ssh;
+  const int c0 = blockIdx.x * 64 + threadIdx.x;
+  if (c0 >= n) return;
+  const int W = w_max - w_min + 1;
+  float acc = 0.0f;
+  int k = (c0 - (w_min - 1)) % n; if (k < 0) k += n;
+  for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) { acc = __fadd_rn(acc, cv[k]); if (++k == n) k = 0; }
+  float s = __fmul_rn(2.0f, acc);
+  int lo = (c0 - w_min) % n; if (lo < 0) lo += n;
+  int hi = (c0 + w_min) % n;
+  for (int w = w_min; w <= w_max; ++w) {
+    s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
+    s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
+    float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
+    beta[(size_t)c0 * W + (w - w_min)] = __fmul_rn(v, v);
+    if (--lo < 0) lo = n - 1;
+    if (++hi == n) hi = 0;
+  }
+}
+
+static SyncGeom geom_of(const tsdr_sync *s) {
+  SyncGeom g;
+  g.y_t = s->y_t; g.x_t = s->x_t;
+  g.wmin_y = s->wmin_y; g.wmax_y = s->wmax_y; g.wmin_x = s->wmin_x; g.wmax_x = s->wmax_x;
+  g.h0 = s->h[0]; g.h1 = s->h[1]; g.h2 = s->h[2]; g.h3 = s->h[3]; g.h4 = s->h[4];
+  return g;
+}
+
+// vsync statistics for `frames` images already on the device: fills keys[2*frames]
+// (x then y per frame); beta matrices of the LAST frame are materialised into the sync state.
+int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long **keys_out) {
+  tsdr_ctx *ctx = s->ctx;
+  const int y = s->y_t, x = s->x_t;
+  float *proj = (float *)ctx->scratch(WS_PROJ, (size_t)frames * proj_stride(y, x) * 4);
+  unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
+  if (!proj || !keys) return TSDR_ENOMEM;
+  const SyncGeom g = geom_of(s);
+  const unsigned nb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
+  TSDR_LAUNCH(ctx, "sync_sums", k_sums, dim3(nb, (unsigned)frames), dim3(64), 0, img, img_stride, y, x, proj);
+  const size_t nmax = (size_t)(x > y ? x : y);
+  TSDR_LAUNCH(ctx, "sync_fir", k_fir, dim3(2, (unsigned)frames), dim3(256), nmax * 4, proj, g, keys);
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nb, (unsigned)frames), dim3(64), nmax * 4, (const float *)proj, g, keys,
+              frames - 1, s->beta_x, s->beta_y);
+  *keys_out = keys;
+  return TSDR_OK;
+}
+
+int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
+                const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
+                int *sync_idx) {
+  const size_t npx = (size_t)h * w;
+  TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, img, img_stride, h, w,
+              frames, keys, do_align ? (const int *)s->pending : (const int *)nullptr, do_align, alpha, state, frames_out);
+  if (do_align) TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, keys, frames, s->pending, sync_idx);
+  return TSDR_OK;
+}
+
+}  // namespace tsdr
+
+using namespace tsdr;
+
+extern "C" {
+
+int tsdr_sync_create(tsdr_ctx *ctx, int y_t, int x_t, tsdr_sync **out) {
+  if (!ctx || !out) return TSDR_EINVAL;
+  *out = nullptr;
+  if (y_t < 8 || x_t < 20) return set_err(ctx, TSDR_EINVAL, "SyncXY needs an image of at least 8x20");
+  tsdr_sync *s = new tsdr_sync();
+  s->ctx = ctx; s->y_t = y_t; s->x_t = x_t;
+  // init_gaussian_filter(5): exp(-2k^2/25), k=-2..2, normalised in f64, stored as Float32
+  double t[5], sum = 0.0;
+  for (int k = -2; k <= 2; ++k) { t[k + 2] = exp(-2.0 * (double)(k * k) / 25.0); sum += t[k + 2]; }
+  for (int i = 0; i < 5; ++i) s->h[i] = (float)(t[i] / sum);
+  s->wmin_y = (int)ceil(1.0 / 100.0 * (double)y_t);
+  s->wmax_y = (int)floor((double)y_t / 4.0);
+  s->wmin_x = (int)ceil(5.0 / 100.0 * (double)x_t);
+  s->wmax_x = (int)floor((double)x_t / 4.0);
+  const size_t nbx = (size_t)(1 + s->wmax_x - s->wmin_x) * x_t, nby = (size_t)(1 + s->wmax_y - s->wmin_y) * y_t;
+  if (hipMalloc((void **)&s->beta_x, nbx * 4) != hipSuccess || hipMalloc((void **)&s->beta_y, nby * 4) != hipSuccess ||
+      hipMalloc((void **)&s->pending, 16) != hipSuccess) {
+    tsdr_sync_free(s);
+    return set_err(ctx, TSDR_ENOMEM, "sync state allocation failed");
+  }
+  int rc = tsdr_sync_reset(s);
+  if (rc) { tsdr_sync_free(s); return rc; }
+  *out = s;
+  return TSDR_OK;
+}
+
+int tsdr_sync_reset(tsdr_sync *s) {
+  if (!s) return TSDR_EINVAL;
+  tsdr_ctx *ctx = s->ctx;
+  const size_t nbx = (size_t)(1 + s->wmax_x - s->wmin_x) * s->x_t, nby = (size_t)(1 + s->wmax_y - s->wmin_y) * s->y_t;
+  TSDR_HIP(ctx, hipMemsetAsync(s->beta_x, 0, nbx * 4, ctx->stream));
+  TSDR_HIP(ctx, hipMemsetAsync(s->beta_y, 0, nby * 4, ctx->stream));
+  const int one[4] = {1, 0, 0, 0};  // findmax of an all-zero beta_y is index (1,1)
+  TSDR_HIP(ctx, hipMemcpyAsync(s->pending, one, 16, hipMemcpyHostToDevice, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TSDR_OK;
+}
+
+void tsdr_sync_free(tsdr_sync *s) {
+  if (!s) return;
+  if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
+  if (s->beta_x) (void)hipFree(s->beta_x);
+  if (s->beta_y) (void)hipFree(s->beta_y);
+  if (s->pending) (void)hipFree(s->pending);
+  delete s;
+}
+
+int tsdr_sync_bounds(const tsdr_sync *s, int b[4]) {
+  if (!s || !b) return TSDR_EINVAL;
+  b[0] = s->wmin_y; b[1] = s->wmax_y; b[2] = s->wmin_x; b[3] = s->wmax_x;
+  return TSDR_OK;
+}
+
+int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
+  if (!s || !img) return TSDR_EINVAL;
+  tsdr_ctx *ctx = s->ctx;
+  unsigned long long *keys = nullptr;
+  int rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, &keys);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys, 1, s->pending,
+              s_yx_dev);
+  return TSDR_OK;
+}
+
+int tsdr_vsync(tsdr_sync *s, const float *img, int *s_y, int *s_x) {
+  if (!s || !img || !s_y || !s_x) return TSDR_EINVAL;
+  tsdr_ctx *ctx = s->ctx;
+  const size_t bytes = (size_t)s->y_t * s->x_t * 4;
+  float *d = (float *)ctx->scratch(WS_IN, bytes);
+  int *didx = (int *)ctx->scratch(WS_OUT, 16);
+  if (!d || !didx) return TSDR_ENOMEM;
+  TSDR_HIP(ctx, hipMemcpyAsync(d, img, bytes, hipMemcpyHostToDevice, ctx->stream));
+  int rc = tsdr_vsync_d(s, d, didx);
+  if (rc) return rc;
+  int hidx[2];
+  TSDR_HIP(ctx, hipMemcpyAsync(hidx, didx, 8, hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *s_y = hidx[0]; *s_x = hidx[1];
+  return TSDR_OK;
+}
+
+int tsdr_sync_beta(tsdr_sync *s, int which, float *beta_host) {
+  if (!s || !beta_host || (which != 0 && which != 1)) return TSDR_EINVAL;
+  tsdr_ctx *ctx = s->ctx;
+  const size_t n = which == 0 ? (size_t)(1 + s->wmax_x - s->wmin_x) * s->x_t : (size_t)(1 + s->wmax_y - s->wmin_y) * s->y_t;
+  TSDR_HIP(ctx, hipMemcpyAsync(beta_host, which == 0 ? s->beta_x : s->beta_y, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TSDR_OK;
+}
+
+int tsdr_fill_beta(tsdr_ctx *ctx, const float *cv, int n, int w_min, int w_max, float *beta) {
+  if (!ctx || !cv || !beta || n < 2 || w_min < 1 || w_max < w_min || w_max >= n) return TSDR_EINVAL;
+  const size_t W = (size_t)(w_max - w_min + 1);
+  return host_map(ctx, cv, (size_t)n * 4, beta, W * n * 4, [&](void *i, void *o) {
+    TSDR_LAUNCH(ctx, "fill_beta", k_fill_beta, dim3((unsigned)ceil_div((size_t)n, 64)), dim3(64), (size_t)n * 4,
+                (const float *)i, n, w_min, w_max, (float *)o);
+    return (int)TSDR_OK;
+  });
+}
+
+int tsdr_circshift_neg(tsdr_ctx *ctx, const float *img, int h, int w, int s_y, int s_x, float *out) {
+  if (!ctx || !img || !out || h <= 0 || w <= 0) return TSDR_EINVAL;
+  const size_t npx = (size_t)h * w;
+  return host_map(ctx, img, npx * 4, out, npx * 4, [&](void *i, void *o) {
+    TSDR_LAUNCH(ctx, "circshift", k_circshift, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, (const float *)i, h, w,
+                s_y, s_x, (float *)o);
+    return (int)TSDR_OK;
+  });
+}
+
+}  // extern "C"
