@@ -1,0 +1,387 @@
+"""Host-side mirror of TempestSDR.jl's processing API over the HIP C ABI.
+
+Same function names, argument meaning and error behaviour as the reference's
+Demodulation.jl / Resampler.jl / Autocorrelations.jl / GetSpectrum.jl /
+FrameSynchronisation.jl, so tests read like the reference's own call sites
+(GUI.jl:73-74,136,164,168,171; production/investigate_data.jl).  Matrices are Fortran-order
+numpy arrays (Julia is column-major); complex vectors are complex64 (ComplexF32).
+
+Every function runs on the GPU through libtempest_hip.so; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RENDER_H, RENDER_W, TempestHIPError, check
+
+
+def _ptr(a):
+    """host numpy array, torch tensor (device or host) or raw integer address -> c_void_p"""
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(f"cannot take the address of {type(a)}")
+
+
+def _c64(sig):
+    a = np.ascontiguousarray(sig)
+    if not np.iscomplexobj(a):
+        # amDemod(sig::Array{Complex{T}}): a real array is a MethodError in the reference
+        raise AssertionError("expected a complex vector (MethodError in the reference)")
+    return a.astype(np.complex64, copy=False)
+
+
+def _f32(sig):
+    return np.ascontiguousarray(sig, dtype=np.float32)
+
+
+class Context:
+    """One tsdr_ctx (HIP stream + workspaces).  One per caller thread, as in the reference's
+    two-task layout."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self.h = self.lib.tsdr_create(int(device))
+        if not self.h:
+            raise TempestHIPError(f"tsdr_create({device}) failed: no usable HIP device (no CPU fallback exists)")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsdr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing -------------------------------------------------------------------
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.h, *args)
+        check(self.h, rc, name)
+
+    def synchronize(self):
+        self.call("tsdr_synchronize")
+
+    def set_stream(self, stream_ptr):
+        self.call("tsdr_set_stream", C.c_void_p(stream_ptr or 0))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        mem = C.c_size_t(0)
+        self.call("tsdr_device_info", name, 256, C.byref(cu), C.byref(mem))
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    def timer_start(self):
+        self.call("tsdr_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double(0)
+        self.call("tsdr_timer_stop", C.byref(ms))
+        return ms.value
+
+    def profile(self, on):
+        self.call("tsdr_profile_enable", int(bool(on)))
+
+    def profile_reset(self):
+        self.call("tsdr_profile_reset")
+
+    def profile_results(self):
+        n = self.lib.tsdr_profile_count(self.h)
+        if n < 0:
+            check(self.h, n, "tsdr_profile_count")
+        out = {}
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            ms = C.c_double(0)
+            cnt = C.c_longlong(0)
+            self.call("tsdr_profile_get", i, name, 128, C.byref(ms), C.byref(cnt))
+            out[name.value.decode()] = {"total_ms": ms.value, "launches": cnt.value}
+        return out
+
+    # -- Demodulation.jl ----------------------------------------------------------------
+    def amDemod(self, sig):
+        z = _c64(sig)
+        out = np.empty(z.shape, np.float32)
+        self.call("tsdr_am_demod", _ptr(z), z.size, _ptr(out))
+        return out
+
+    def invert_amDemod(self, sig):
+        z = _c64(sig)
+        out = np.empty(z.shape, np.float32)
+        self.call("tsdr_invert_am", _ptr(z), z.size, _ptr(out))
+        return out
+
+    def fmDemod(self, sig):
+        z = _c64(sig)
+        out = np.empty(z.shape, np.float32)
+        self.call("tsdr_fm_demod", _ptr(z), z.size, _ptr(out))
+        return out
+
+    def abs2(self, sig):
+        z = _c64(sig)
+        out = np.empty(z.shape, np.float32)
+        self.call("tsdr_abs2", _ptr(z), z.size, _ptr(out))
+        return out
+
+    # -- Resampler.jl -------------------------------------------------------------------
+    def imresize1d(self, sig, n_out):
+        x = _f32(sig)
+        out = np.empty(int(n_out), np.float32)
+        self.call("tsdr_resize1d", _ptr(x), x.size, int(n_out), _ptr(out))
+        return out
+
+    def sig_to_image(self, sig, y_t, x_t):
+        x = _f32(sig)
+        img = np.empty((int(y_t), int(x_t)), np.float32, order="F")
+        self.call("tsdr_sig_to_image", _ptr(x), x.size, int(y_t), int(x_t), _ptr(img))
+        return img
+
+    def imresize2d(self, image, size):
+        a = np.asfortranarray(image, dtype=np.float32)
+        h, w = int(size[0]), int(size[1])
+        out = np.empty((h, w), np.float32, order="F")
+        self.call("tsdr_resize2d", _ptr(a), a.shape[0], a.shape[1], h, w, _ptr(out))
+        return out
+
+    def downgradeImage(self, image):
+        return self.imresize2d(image, (RENDER_H, RENDER_W))
+
+    def naiveResampler(self, sigOut, sigId, upCoeff):
+        x = _f32(sigId)
+        if not (isinstance(sigOut, np.ndarray) and sigOut.dtype == np.float32 and sigOut.flags.c_contiguous):
+            raise AssertionError("sigOut must be a contiguous float32 array")
+        if sigOut.size < x.size * int(upCoeff):
+            raise IndexError("sigOut too short (BoundsError in the reference)")
+        self.call("tsdr_naive_resample", _ptr(x), x.size, int(upCoeff), _ptr(sigOut))
+
+    def init_resampler(self, T, bufferSize, upCoeff):
+        """init_resampler(T,bufferSize,upCoeff) -> resampler!(out,in)  (Resampler.jl:26-62)"""
+        if np.dtype(T) != np.float32:
+            raise AssertionError("only Float32 resamplers are implemented on the GPU path")
+        return Resampler(self, int(bufferSize), int(upCoeff))
+
+    # -- Autocorrelations.jl --------------------------------------------------------------
+    def calculate_autocorrelation(self, x, Fs, minDelay, maxDelay, scale="log"):
+        xv = _f32(x)
+        index_min = 1 + int(np.round(minDelay * Fs))
+        index_max = int(np.round(maxDelay * Fs))
+        cnt = max(index_max - index_min + 1, 0)
+        out = np.empty(max(cnt, 1), np.float32)
+        n_out = C.c_size_t(0)
+        self.call("tsdr_autocorr", _ptr(xv), xv.size, float(Fs), float(minDelay), float(maxDelay),
+                  1 if scale == "log" else 0, _ptr(out), C.byref(n_out))
+        lags = np.arange(0, index_max - index_min + 1, dtype=np.float64) * (1.0 / Fs)
+        return out[: n_out.value], lags
+
+    def zoom_autocorr(self, G, Fs, rate_min=20, rate_max=100):
+        pmin, pmax = C.c_size_t(0), C.c_size_t(0)
+        rc = self.lib.tsdr_zoom_bounds(len(G), float(Fs), float(rate_min), float(rate_max), C.byref(pmin), C.byref(pmax))
+        check(self.h, rc, "tsdr_zoom_bounds")
+        idx = np.arange(pmin.value, pmax.value + 1, dtype=np.float64)
+        rates = 1.0 / (idx / Fs)
+        return rates, np.asarray(G)[pmin.value - 1: pmax.value]
+
+    # -- GetSpectrum.jl -----------------------------------------------------------------
+    def _sig(self, sig):
+        a = np.ascontiguousarray(sig)
+        if np.iscomplexobj(a):
+            return a.astype(np.complex64, copy=False), 1
+        return a.astype(np.float32, copy=False), 0
+
+    def getSpectrum(self, fs, sig, N=None, lin=False):
+        a, cplx = self._sig(sig)
+        N = a.size if N is None else int(N)
+        if N > a.size:
+            raise IndexError("N exceeds the signal length (BoundsError in the reference)")
+        y = np.empty(N, np.float32)
+        self.call("tsdr_spectrum", _ptr(a), cplx, N, int(lin), _ptr(y))
+        freq = (np.arange(N) / N - 0.5) * fs
+        return freq, y
+
+    def getWelch(self, fe, sig, sizeFFT=1024, lin=False):
+        a, cplx = self._sig(sig)
+        y = np.empty(int(sizeFFT), np.float32)
+        self.call("tsdr_welch", _ptr(a), cplx, a.size, int(sizeFFT), int(lin), _ptr(y))
+        freq = (np.arange(sizeFFT) / sizeFFT - 0.5) * fe
+        return freq, y
+
+    def getWaterfall(self, fe, sig, sizeFFT=1024):
+        a, cplx = self._sig(sig)
+        nb = a.size // int(sizeFFT)
+        m = np.empty((int(sizeFFT), nb), np.float64, order="F")
+        self.call("tsdr_waterfall", _ptr(a), cplx, a.size, int(sizeFFT), _ptr(m))
+        f_ax = (np.arange(sizeFFT) / sizeFFT - 0.5) * fe
+        t_ax = np.arange(nb) * (sizeFFT / fe)
+        return t_ax, f_ax, m
+
+    def fft(self, x, inverse=False):
+        a = np.ascontiguousarray(x).astype(np.complex64)
+        batch = 1 if a.ndim == 1 else a.shape[0]
+        n = a.shape[-1]
+        out = np.empty_like(a)
+        self.call("tsdr_fft_c2c", _ptr(a), _ptr(out), n, batch, 1 if inverse else -1)
+        return out
+
+    # -- FrameSynchronisation.jl ------------------------------------------------------------
+    def SyncXY(self, image):
+        a = np.asarray(image)
+        return SyncXY(self, a.shape[0], a.shape[1])
+
+    def vsync(self, image, sync):
+        return sync.vsync(image)
+
+    def fill_beta(self, cv, n, w_min, w_max):
+        x = _f32(cv)
+        beta = np.empty((w_max - w_min + 1, n), np.float32, order="F")
+        self.call("tsdr_fill_beta", _ptr(x), int(n), int(w_min), int(w_max), _ptr(beta))
+        return beta
+
+    def circshift_neg(self, image, s_y, s_x):
+        a = np.asfortranarray(image, dtype=np.float32)
+        out = np.empty_like(a, order="F")
+        self.call("tsdr_circshift_neg", _ptr(a), a.shape[0], a.shape[1], int(s_y), int(s_x), _ptr(out))
+        return out
+
+    # -- frame loop (GUI.jl:163-178) ---------------------------------------------------------
+    def frames(self, sync, iq, S, y_t, x_t, alpha, imageOut, do_align=True, want_frames=True, want_raster=False):
+        """One SDR buffer through the steady-state loop.  imageOut (600x800 F-order float32) is
+        updated in place.  Returns dict(n_frames, frames, raster, sync_idx)."""
+        z = _c64(iq)
+        nb = z.size // int(S)
+        if not (isinstance(imageOut, np.ndarray) and imageOut.dtype == np.float32 and imageOut.flags.f_contiguous
+                and imageOut.shape == (RENDER_H, RENDER_W)):
+            raise AssertionError("imageOut must be a Fortran-order float32 (600,800) array")
+        frames = np.empty((nb, RENDER_H, RENDER_W), np.float32) if want_frames else None
+        raster = np.empty((nb, int(y_t) * int(x_t)), np.float32) if want_raster else None
+        idx = np.zeros((nb, 2), np.int32)
+        n = C.c_int(0)
+        self.call("tsdr_frames", C.c_void_p(sync.h if sync is not None else 0), _ptr(z), z.size, int(S), int(y_t),
+                  int(x_t), C.c_float(alpha), int(bool(do_align)), _ptr(imageOut), _ptr(frames), _ptr(raster), _ptr(idx),
+                  C.byref(n))
+        out = {"n_frames": n.value, "sync_idx": idx}
+        if frames is not None:  # each frame is stored column-major (600,800)
+            out["frames"] = [frames[f].reshape(-1).reshape((RENDER_H, RENDER_W), order="F") for f in range(nb)]
+        if raster is not None:
+            out["raster"] = [raster[f].reshape((int(y_t), int(x_t)), order="F") for f in range(nb)]
+        return out
+
+
+class SyncXY:
+    """SyncXY{Float32} state (FrameSynchronisation.jl:25-48) living on the device."""
+
+    def __init__(self, ctx, y_t, x_t):
+        self.ctx = ctx
+        self.y_t, self.x_t = int(y_t), int(x_t)
+        h = C.c_void_p(0)
+        ctx.call("tsdr_sync_create", self.y_t, self.x_t, C.byref(h))
+        self.h = h.value
+        b = (C.c_int * 4)()
+        check(ctx.h, ctx.lib.tsdr_sync_bounds(self.h, b), "tsdr_sync_bounds")
+        self.wmin_y, self.wmax_y, self.wmin_x, self.wmax_x = list(b)
+
+    def reset(self):
+        check(self.ctx.h, self.ctx.lib.tsdr_sync_reset(self.h), "tsdr_sync_reset")
+
+    def vsync(self, image):
+        a = np.asfortranarray(image, dtype=np.float32)
+        if a.shape != (self.y_t, self.x_t):
+            raise AssertionError("image size does not match the SyncXY state")
+        sy, sx = C.c_int(0), C.c_int(0)
+        check(self.ctx.h, self.ctx.lib.tsdr_vsync(self.h, _ptr(a), C.byref(sy), C.byref(sx)), "tsdr_vsync")
+        return sy.value, sx.value
+
+    def beta(self, which):
+        """which='x' -> beta_x (W_x, x_t); 'y' -> beta_y (W_y, y_t); Fortran order like the Julia field."""
+        if which == "x":
+            shape, w = (1 + self.wmax_x - self.wmin_x, self.x_t), 0
+        else:
+            shape, w = (1 + self.wmax_y - self.wmin_y, self.y_t), 1
+        out = np.empty(shape, np.float32, order="F")
+        check(self.ctx.h, self.ctx.lib.tsdr_sync_beta(self.h, w, _ptr(out)), "tsdr_sync_beta")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.tsdr_sync_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Resampler:
+    """The closure init_resampler returns (Resampler.jl:26-62): call it as r(out, inp)."""
+
+    def __init__(self, ctx, bufferSize, upCoeff):
+        self.ctx, self.bufferSize, self.upCoeff = ctx, bufferSize, upCoeff
+        h = C.c_void_p(0)
+        ctx.call("tsdr_resampler_init", bufferSize, upCoeff, C.byref(h))
+        self.h = h.value
+
+    def __call__(self, out, inp):
+        if not (isinstance(out, np.ndarray) and isinstance(inp, np.ndarray)):
+            raise AssertionError("numpy arrays expected")
+        if out.dtype != np.float32 or inp.dtype != np.float32:
+            raise AssertionError("Type of input should match type used during init (Float32)")  # Resampler.jl:44
+        if inp.size != self.bufferSize:
+            raise AssertionError(f"Size of input {inp.size} should match size used during init {self.bufferSize}")  # :47
+        if out.size < self.bufferSize * self.upCoeff:
+            raise IndexError("out too short")
+        x = np.ascontiguousarray(inp)
+        check(self.ctx.h, self.ctx.lib.tsdr_resampler_run(self.h, _ptr(x), x.size, _ptr(out)), "tsdr_resampler_run")
+
+    def lpf(self):
+        H = np.empty(self.bufferSize * self.upCoeff, np.complex64)
+        check(self.ctx.h, self.ctx.lib.tsdr_resampler_lpf(self.h, _ptr(H)), "tsdr_resampler_lpf")
+        return H
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.ctx, "h", None):
+            self.ctx.lib.tsdr_resampler_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def default_context():
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+# module-level functions with the reference's names, bound to the default context
+def amDemod(sig): return default_context().amDemod(sig)
+def invert_amDemod(sig): return default_context().invert_amDemod(sig)
+def fmDemod(sig): return default_context().fmDemod(sig)
+def sig_to_image(sig, y_t, x_t): return default_context().sig_to_image(sig, y_t, x_t)
+def downgradeImage(image): return default_context().downgradeImage(image)
+def naiveResampler(sigOut, sigId, upCoeff): return default_context().naiveResampler(sigOut, sigId, upCoeff)
+def init_resampler(T, bufferSize, upCoeff): return default_context().init_resampler(T, bufferSize, upCoeff)
+def calculate_autocorrelation(x, Fs, minDelay, maxDelay, scale="log"):
+    return default_context().calculate_autocorrelation(x, Fs, minDelay, maxDelay, scale)
+def zoom_autocorr(G, Fs, rate_min=20, rate_max=100): return default_context().zoom_autocorr(G, Fs, rate_min, rate_max)
+def getSpectrum(fs, sig, N=None): return default_context().getSpectrum(fs, sig, N)
+def getWelch(fe, sig, sizeFFT=1024): return default_context().getWelch(fe, sig, sizeFFT)
+def getWaterfall(fe, sig, sizeFFT=1024): return default_context().getWaterfall(fe, sig, sizeFFT)
+def vsync(image, sync): return sync.vsync(image)
