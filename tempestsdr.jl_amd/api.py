@@ -81,6 +81,27 @@ class Context:
         self.call("tsdr_device_info", name, 256, C.byref(cu), C.byref(mem))
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
 
+    # -- resident device buffers (for the *_d entry points) ----------------------------
+    def dev_alloc(self, nbytes):
+        p = self.lib.tsdr_dev_alloc(self.h, int(nbytes))
+        if not p:
+            raise MemoryError(self.lib.tsdr_last_error(self.h).decode())
+        return p
+
+    def dev_free(self, p):
+        self.call("tsdr_dev_free", C.c_void_p(p))
+
+    def upload(self, arr):
+        a = np.ascontiguousarray(arr)
+        p = self.dev_alloc(a.nbytes)
+        self.call("tsdr_upload", C.c_void_p(p), _ptr(a), a.nbytes)
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        self.call("tsdr_download", _ptr(out), C.c_void_p(p), out.nbytes)
+        return out
+
     def timer_start(self):
         self.call("tsdr_timer_start")
 

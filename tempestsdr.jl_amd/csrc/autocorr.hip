@@ -1,0 +1,282 @@
+// autocorr.hip -- Autocorrelations.jl on gfx950.
+//
+// calculate_autocorrelation (Autocorrelations.jl:23-37) is the CIRCULAR autocorrelation of the
+// first n samples, r[k] = sum_m x[m] x[(m+k) mod n] = ifft(fft(x) .* conj(fft(x)))[k].  n is
+// arbitrary (4e6 = 2^8*5^6 at 20 MS/s), so instead of a length-n transform the kernels compute the
+// LINEAR autocorrelation a[k] = sum_m x[m] x[m+k] with zero padding to M = 2^ceil(log2(2n)) and fold
+//     r[0] = a[0],   r[k] = a[k] + a[n-k]   (0 < k < n)
+// which is the same sum regrouped.  x is real, so the length-M real transforms run as length-M/2
+// complex ones: pack z[j] = x[2j] + i x[2j+1], one pointwise pass turns Z = FFT(z) into the packed
+// spectrum Y of the (real, even) power |X|^2, and IFFT(Y)/2 is a[2j] + i a[2j+1].
+//
+// Multi-GPU: tsdr_autocorr_partial_d computes the partial sum over a range of m on one
+// GPU as a zero-padded cross-correlation of the segment with segment+halo; ranks all-reduce the
+// partial vectors (linear domain) and only then apply 10log10(abs2) via tsdr_autocorr_finish_d.
+#include <cmath>
+
+#include "common.h"
+
+namespace tsdr {
+
+int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale);
+int get_tw(tsdr_ctx *ctx, int logN, TwTable **out);
+
+__device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__device__ inline float ld_power(const float *x, int is_iq, size_t i) {
+  if (is_iq) {
+    float2 z = reinterpret_cast<const float2 *>(x)[i];
+    return abs2_c(z.x, z.y);
+  }
+  return x[i];
+}
+
+// z[j] = x[2j] + i x[2j+1], zero beyond n; Mc complex outputs
+__global__ __launch_bounds__(256) void k_ac_pack(const float *__restrict__ x, int is_iq, size_t n, size_t Mc,
+                                                 float2 *__restrict__ z) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < Mc; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t i0 = 2 * j;
+    float a = i0 < n ? ld_power(x, is_iq, i0) : 0.f;
+    float b = i0 + 1 < n ? ld_power(x, is_iq, i0 + 1) : 0.f;
+    z[j] = make_float2(a, b);
+  }
+}
+
+// In place: Z (FFT of the packed real sequence, length Mc) -> Y, the packed spectrum whose
+// inverse transform (times 1/2) is the real sequence with spectrum P[k] = |X[k]|^2.
+//   X[k]    = E + W O,  X[Mc-k] = conj(E - W O),  E = (Z[k]+conj Z[Mc-k])/2, O = -i (Z[k]-conj Z[Mc-k])/2
+//   Y[k]    = (P + P') + i conj(W) (P - P'),   Y[Mc-k] = (P + P') + i W (P - P'),   W = W_M^k
+__global__ __launch_bounds__(256) void k_ac_power(float2 *__restrict__ Z, size_t Mc, const float2 *__restrict__ tw_lo,
+                                                  const float2 *__restrict__ tw_hi, int tw_h) {
+  const size_t half = Mc >> 1;
+  const unsigned lomask = (1u << tw_h) - 1u;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= half; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t kk = k == 0 ? 0 : Mc - k;
+    const float2 a = Z[k], b = Z[kk];
+    const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (Z[k]-conj Z[kk])/2
+    const float2 O = make_float2(D.y, -D.x);                                // -i*D
+    const float2 W = cmulf(tw_hi[k >> tw_h], tw_lo[k & lomask]);
+    const float2 WO = cmulf(W, O);
+    const float2 X0 = make_float2(E.x + WO.x, E.y + WO.y), X1 = make_float2(E.x - WO.x, E.y - WO.y);
+    const float P0 = X0.x * X0.x + X0.y * X0.y, P1 = X1.x * X1.x + X1.y * X1.y;
+    const float s = P0 + P1, d = P0 - P1;
+    // i*conj(W)*d = d*(W.y, W.x)... i*(Wx - iWy) = Wy + i Wx
+    Z[k] = make_float2(s + d * W.y, d * W.x);
+    if (k != 0 && k != half) Z[kk] = make_float2(s - d * W.y, d * W.x);  // i*W*d = d*(-Wy + i Wx)
+  }
+}
+
+// out[i] = f(r[k0+i]), r[k] = a[k] + a[n-k] (k>0), a = linear autocorrelation (float view of y)
+__global__ __launch_bounds__(256) void k_ac_fold(const float *__restrict__ a, size_t n, size_t k0, size_t cnt,
+                                                 int log_scale, float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = k0 + i;
+    float r = a[k];
+    if (k > 0) r += a[n - k];
+    const float p = r * r;
+    out[i] = log_scale ? 10.0f * log10f(p) : p;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ac_finish(const float *__restrict__ corr, size_t k0, size_t cnt, int log_scale,
+                                                   float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+    const float r = corr[k0 + i];
+    const float p = r * r;
+    out[i] = log_scale ? 10.0f * log10f(p) : p;
+  }
+}
+
+// ---- partial (sharded) correlation --------------------------------------------------------
+// z[j] = u[j] + i v[j]; u = x[m0 .. m0+cnt), v = x[(m0+j) mod n], j < cnt+n_lags-1; zero padded to M
+__global__ __launch_bounds__(256) void k_pc_pack(const float *__restrict__ x, int is_iq, size_t n, size_t m0,
+                                                 size_t cnt, size_t vlen, size_t M, float2 *__restrict__ z) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < M; j += (size_t)gridDim.x * blockDim.x) {
+    float u = 0.f, v = 0.f;
+    if (j < vlen) {
+      size_t idx = m0 + j;
+      if (idx >= n) idx %= n;
+      v = ld_power(x, is_iq, idx);
+      if (j < cnt) u = v;
+    }
+    z[j] = make_float2(u, v);
+  }
+}
+
+// in place: Z = FFT(u + i v) -> C = conj(U) * V with U=(Z[k]+conj Z[M-k])/2, V=-i(Z[k]-conj Z[M-k])/2
+__global__ __launch_bounds__(256) void k_pc_cross(float2 *__restrict__ Z, size_t M) {
+  const size_t half = M >> 1;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= half; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t kk = k == 0 ? 0 : M - k;
+    const float2 a = Z[k], b = Z[kk];
+    const float2 U = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+    const float2 V = make_float2(D.y, -D.x);
+    // conj(U)*V
+    const float2 C = make_float2(U.x * V.x + U.y * V.y, U.x * V.y - U.y * V.x);
+    Z[k] = C;
+    // U[M-k] = conj U[k], V[M-k] = conj V[k]  ->  C[M-k] = conj(C[k])
+    if (k != 0 && k != half) Z[kk] = make_float2(C.x, -C.y);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_real_part(const float2 *__restrict__ c, size_t cnt, float *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = c[i].x;
+}
+
+// ---- argmax (findmax: first maximum, NaN maximal) -------------------------------------------
+__device__ inline unsigned long long argmax_key(float v, unsigned idx) {
+  unsigned u = (v != v) ? 0x7FC00000u : __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, size_t n, unsigned long long *__restrict__ key) {
+  unsigned long long best = 0ull;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = argmax_key(v[i], (unsigned)i);
+    best = k > best ? k : best;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off, 64);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(key, best);
+}
+
+static inline double jl_round(double v) { return nearbyint(v); }  // Julia round(): ties to even
+
+// shared core: x (real f32, or IQ whose abs2 is taken on the fly), first n samples
+static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, size_t k0, size_t cnt, int log_scale,
+                         float *out) {
+  const int logM = ilog2(2 * n);
+  const size_t M = size_t(1) << logM, Mc = M >> 1;
+  if (logM > 31) return set_err(ctx, TSDR_EINVAL, "autocorr: window too long");
+  float2 *z = (float2 *)ctx->scratch(WS_FFT_A, Mc * sizeof(float2));
+  float2 *Z = (float2 *)ctx->scratch(WS_FFT_C, Mc * sizeof(float2));
+  if (!z || !Z) return TSDR_ENOMEM;
+  TwTable *tw = nullptr;
+  int rc = get_tw(ctx, logM, &tw);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "ac_pack", k_ac_pack, dim3(stream_grid(ctx, Mc)), dim3(256), 0, x, is_iq, n, Mc, z);
+  rc = fft_pow2(ctx, z, Z, logM - 1, 1, -1, 1.0f);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)tw->lo,
+              (const float2 *)tw->hi, tw->h);
+  rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc));
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "ac_fold", k_ac_fold, dim3(stream_grid(ctx, cnt)), dim3(256), 0, reinterpret_cast<const float *>(z), n, k0,
+              cnt, log_scale, out);
+  return TSDR_OK;
+}
+
+static int autocorr_args(tsdr_ctx *ctx, size_t len, double Fs, double minDelay, double maxDelay, size_t *n, size_t *k0,
+                         size_t *cnt) {
+  const double dmin = jl_round(minDelay * Fs), dmax = jl_round(maxDelay * Fs);
+  if (!(dmin >= 0) || !(dmax >= 1) || dmax > 1e15) return set_err(ctx, TSDR_EBOUNDS, "autocorr: delay window out of range");
+  const size_t indexMin = 1 + (size_t)dmin, indexMax = (size_t)dmax;
+  *n = 2 * indexMax < len ? 2 * indexMax : len;                     // :27
+  if (indexMax > *n) return set_err(ctx, TSDR_EBOUNDS, "autocorr: signal shorter than maxDelay*Fs (BoundsError at :33)");
+  *k0 = indexMin - 1;
+  *cnt = indexMin <= indexMax ? indexMax - indexMin + 1 : 0;
+  return TSDR_OK;
+}
+
+}  // namespace tsdr
+
+using namespace tsdr;
+
+extern "C" {
+
+static int autocorr_any_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t len, double Fs, double minDelay, double maxDelay,
+                          int log_scale, float *out, size_t *n_out) {
+  if (!ctx || !x || !out) return TSDR_EINVAL;
+  size_t n, k0, cnt;
+  int rc = autocorr_args(ctx, len, Fs, minDelay, maxDelay, &n, &k0, &cnt);
+  if (rc) return rc;
+  if (n_out) *n_out = cnt;
+  if (cnt == 0) return TSDR_OK;
+  return autocorr_core(ctx, x, is_iq, n, k0, cnt, log_scale, out);
+}
+
+int tsdr_autocorr_d(tsdr_ctx *ctx, const float *x, size_t len, double Fs, double minDelay, double maxDelay, int log_scale,
+                    float *out, size_t *n_out) {
+  return autocorr_any_d(ctx, x, 0, len, Fs, minDelay, maxDelay, log_scale, out, n_out);
+}
+
+int tsdr_autocorr_iq_d(tsdr_ctx *ctx, const float *iq, size_t len, double Fs, double minDelay, double maxDelay,
+                       int log_scale, float *out, size_t *n_out) {
+  return autocorr_any_d(ctx, iq, 1, len, Fs, minDelay, maxDelay, log_scale, out, n_out);
+}
+
+int tsdr_autocorr(tsdr_ctx *ctx, const float *x, size_t len, double Fs, double minDelay, double maxDelay, int log_scale,
+                  float *out, size_t *n_out) {
+  if (!ctx || !x || !out) return TSDR_EINVAL;
+  size_t n, k0, cnt;
+  int rc = autocorr_args(ctx, len, Fs, minDelay, maxDelay, &n, &k0, &cnt);
+  if (rc) return rc;
+  if (n_out) *n_out = cnt;
+  if (cnt == 0) return TSDR_OK;
+  return host_map(ctx, x, n * 4, out, cnt * 4,
+                  [&](void *i, void *o) { return autocorr_core(ctx, (const float *)i, 0, n, k0, cnt, log_scale, (float *)o); });
+}
+
+int tsdr_autocorr_partial_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, size_t m0, size_t cnt, size_t n_lags,
+                            float *part) {
+  if (!ctx || !x || !part) return TSDR_EINVAL;
+  if (n == 0 || cnt == 0 || n_lags == 0 || m0 >= n || cnt > n || n_lags > n) return set_err(ctx, TSDR_EINVAL, "autocorr_partial: bad range");
+  const size_t vlen = cnt + n_lags - 1;
+  const int logM = ilog2(vlen);
+  if (logM > 31) return set_err(ctx, TSDR_EINVAL, "autocorr_partial: window too long");
+  const size_t M = size_t(1) << logM;
+  float2 *z = (float2 *)ctx->scratch(WS_FFT_A, M * sizeof(float2));
+  float2 *Z = (float2 *)ctx->scratch(WS_FFT_C, M * sizeof(float2));
+  if (!z || !Z) return TSDR_ENOMEM;
+  TSDR_LAUNCH(ctx, "pc_pack", k_pc_pack, dim3(stream_grid(ctx, M)), dim3(256), 0, x, is_iq, n, m0, cnt, vlen, M, z);
+  int rc = fft_pow2(ctx, z, Z, logM, 1, -1, 1.0f);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "pc_cross", k_pc_cross, dim3(stream_grid(ctx, M / 2 + 1)), dim3(256), 0, Z, M);
+  rc = fft_pow2(ctx, Z, z, logM, 1, +1, (float)(1.0 / (double)M));
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "pc_real", k_real_part, dim3(stream_grid(ctx, n_lags)), dim3(256), 0, (const float2 *)z, n_lags, part);
+  return TSDR_OK;
+}
+
+int tsdr_autocorr_finish_d(tsdr_ctx *ctx, const float *corr, size_t k0, size_t cnt, int log_scale, float *out) {
+  if (!ctx || (cnt && (!corr || !out))) return TSDR_EINVAL;
+  if (cnt == 0) return TSDR_OK;
+  TSDR_LAUNCH(ctx, "ac_finish", k_ac_finish, dim3(stream_grid(ctx, cnt)), dim3(256), 0, corr, k0, cnt, log_scale, out);
+  return TSDR_OK;
+}
+
+int tsdr_zoom_bounds(size_t N, double Fs, double rate_min, double rate_max, size_t *pmin, size_t *pmax) {
+  if (!pmin || !pmax) return TSDR_EINVAL;
+  const double a = jl_round(1.0 / rate_max * Fs), b = jl_round(1.0 / rate_min * Fs);  // :46-47
+  if (!(a >= 0) || !(b >= 0)) return TSDR_EBOUNDS;
+  *pmin = a < (double)N ? (size_t)a : N;
+  *pmax = b < (double)N ? (size_t)b : N;
+  if (*pmin < 1) return TSDR_EBOUNDS;  // G[0:...] is a BoundsError
+  return TSDR_OK;
+}
+
+int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *val) {
+  if (!ctx || !v || !idx || n == 0) return TSDR_EINVAL;  // findmax of an empty collection throws
+  if (n >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "argmax: vector too long");
+  unsigned long long *key = (unsigned long long *)ctx->scratch(WS_MISC, 16);
+  if (!key) return TSDR_ENOMEM;
+  TSDR_HIP(ctx, hipMemsetAsync(key, 0, 8, ctx->stream));
+  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(stream_grid(ctx, n)), dim3(256), 0, v, n, key);
+  unsigned long long h = 0;
+  TSDR_HIP(ctx, hipMemcpyAsync(&h, key, 8, hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *idx = (size_t)(0xFFFFFFFFu - (unsigned)(h & 0xFFFFFFFFull));
+  if (val) {
+    TSDR_HIP(ctx, hipMemcpyAsync(val, v + *idx, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return TSDR_OK;
+}
+
+}  // extern "C"

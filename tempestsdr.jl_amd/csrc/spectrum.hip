@@ -1,0 +1,258 @@
+// spectrum.hip -- GetSpectrum.jl on gfx950 (getSpectrum :21-30, getWelch :36-52,
+// getWaterfall :54-66) and the init_resampler closure of Resampler.jl:26-99.
+// All transforms go through the hand-written FFT engine (fft.hip).
+#include <cmath>
+
+#include "common.h"
+
+struct tsdr_resampler {
+  tsdr_ctx *ctx;
+  size_t bufferSize, sizeFFT;
+  int up;
+  float2 *H = nullptr;     // initLPF's H (ComplexF32 here), device
+  float2 *work = nullptr;  // containerFFT / inFFT / outFFT, device
+};
+
+namespace tsdr {
+
+int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n, size_t batch, int dir);
+
+// fftshift: output j takes input (j + ceil(N/2)) mod N
+__device__ inline size_t shift_src(size_t j, size_t N) {
+  size_t s = j + (N - N / 2);
+  return s >= N ? s - N : s;
+}
+
+__global__ __launch_bounds__(256) void k_spec_out(const float2 *__restrict__ X, size_t N, int lin, float *__restrict__ y) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += (size_t)gridDim.x * blockDim.x) {
+    const float2 c = X[shift_src(j, N)];
+    const float p = c.x * c.x + c.y * c.y;
+    y[j] = lin ? p : 10.0f * log10f(p);
+  }
+}
+
+// S[k] = sum over segments (in order) of |X_seg[k]|^2, then fftshift and optional dB
+__global__ __launch_bounds__(256) void k_welch(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg, int lin,
+                                               float *__restrict__ y) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < sizeFFT; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t k = shift_src(j, sizeFFT);
+    float S = 0.f;
+    for (size_t s = 0; s < nbSeg; ++s) {
+      const float2 c = X[s * sizeFFT + k];
+      S += c.x * c.x + c.y * c.y;
+    }
+    y[j] = lin ? S : 10.0f * log10f(S);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg,
+                                                   double *__restrict__ m) {
+  const size_t total = sizeFFT * nbSeg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t s = i / sizeFFT, j = i - s * sizeFFT;
+    const float2 c = X[s * sizeFFT + shift_src(j, sizeFFT)];
+    m[i] = (double)(c.x * c.x + c.y * c.y);
+  }
+}
+
+// ---- init_resampler kernels ------------------------------------------------------------------
+// h[n] = ifft(H0)[n] * blackman(n)  (window in f64, DSP.blackman: 0.42 - 0.5cos(2pi n/(N-1)) + 0.08cos(4pi n/(N-1)))
+__global__ __launch_bounds__(256) void k_window(float2 *__restrict__ h, size_t N) {
+  for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (size_t)gridDim.x * blockDim.x) {
+    double w = 1.0;
+    if (N > 1) {
+      const double t = (double)n / (double)(N - 1);
+      w = 0.42 - 0.5 * cos(2.0 * M_PI * t) + 0.08 * cos(4.0 * M_PI * t);
+    }
+    const float2 v = h[n];
+    h[n] = make_float2((float)((double)v.x * w), (float)((double)v.y * w));
+  }
+}
+
+// H[k] *= (-1)^k
+__global__ __launch_bounds__(256) void k_altsign(float2 *__restrict__ H, size_t N) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x)
+    if (k & 1) { float2 v = H[k]; H[k] = make_float2(-v.x, -v.y); }
+}
+
+// containerFFT[1:up:end] .= in  (zero elsewhere)
+__global__ __launch_bounds__(256) void k_stuff(const float *__restrict__ in, size_t N, unsigned up, float2 *__restrict__ c) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t q = k / up;
+    c[k] = (k - q * up == 0) ? make_float2(in[q], 0.f) : make_float2(0.f, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_cmul(float2 *__restrict__ a, const float2 *__restrict__ b, size_t N) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x) {
+    const float2 x = a[k], h = b[k];
+    a[k] = make_float2(x.x * h.x - x.y * h.y, x.x * h.y + x.y * h.x);
+  }
+}
+
+// out[n] = 2*upCoeff*real(outFFT[n])
+__global__ __launch_bounds__(256) void k_real_scale(const float2 *__restrict__ c, size_t N, float g, float *__restrict__ out) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x)
+    out[k] = g * c[k].x;
+}
+
+static int spectrum_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int lin, float *y) {
+  if (N == 0) return TSDR_OK;
+  float2 *X = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
+  if (!X) return TSDR_ENOMEM;
+  int rc = fft_any(ctx, sig, is_complex, X, N, 1, -1);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "spectrum_out", k_spec_out, dim3(stream_grid(ctx, N)), dim3(256), 0, (const float2 *)X, N, lin, y);
+  return TSDR_OK;
+}
+
+static int segments_fft(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, float2 **X,
+                        size_t *nbSeg) {
+  if (sizeFFT == 0) return set_err(ctx, TSDR_EINVAL, "sizeFFT must be positive");
+  *nbSeg = len / sizeFFT;
+  *X = (float2 *)ctx->scratch(WS_FFT_A, (*nbSeg ? *nbSeg : 1) * sizeFFT * sizeof(float2));
+  if (!*X) return TSDR_ENOMEM;
+  if (*nbSeg == 0) return TSDR_OK;
+  return fft_any(ctx, sig, is_complex, *X, sizeFFT, *nbSeg, -1);
+}
+
+}  // namespace tsdr
+
+using namespace tsdr;
+
+extern "C" {
+
+int tsdr_spectrum_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int lin, float *y) {
+  if (!ctx || (N && (!sig || !y))) return TSDR_EINVAL;
+  return spectrum_d(ctx, sig, is_complex, N, lin, y);
+}
+
+int tsdr_spectrum(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int lin, float *y) {
+  return host_map(ctx, sig, N * (is_complex ? 8 : 4), y, N * 4,
+                  [&](void *i, void *o) { return spectrum_d(ctx, (const float *)i, is_complex, N, lin, (float *)o); });
+}
+
+int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y) {
+  if (!ctx || !y || (len && !sig)) return TSDR_EINVAL;
+  float2 *X;
+  size_t nbSeg;
+  int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "welch_acc", k_welch, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, (const float2 *)X, sizeFFT,
+              nbSeg, lin, y);
+  return TSDR_OK;
+}
+
+int tsdr_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y) {
+  return host_map(ctx, sig, len * (is_complex ? 8 : 4), y, sizeFFT * 4, [&](void *i, void *o) {
+    return tsdr_welch_d(ctx, (const float *)i, is_complex, len, sizeFFT, lin, (float *)o);
+  });
+}
+
+int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, double *sMatrix) {
+  if (!ctx || (len && !sig)) return TSDR_EINVAL;
+  float2 *X;
+  size_t nbSeg;
+  int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);
+  if (rc) return rc;
+  if (nbSeg == 0) return TSDR_OK;
+  if (!sMatrix) return TSDR_EINVAL;
+  TSDR_LAUNCH(ctx, "waterfall_out", k_waterfall, dim3(stream_grid(ctx, sizeFFT * nbSeg)), dim3(256), 0, (const float2 *)X,
+              sizeFFT, nbSeg, sMatrix);
+  return TSDR_OK;
+}
+
+int tsdr_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, double *sMatrix) {
+  if (sizeFFT == 0) return TSDR_EINVAL;
+  const size_t nb = len / sizeFFT;
+  return host_map(ctx, sig, len * (is_complex ? 8 : 4), sMatrix, nb * sizeFFT * 8, [&](void *i, void *o) {
+    return tsdr_waterfall_d(ctx, (const float *)i, is_complex, len, sizeFFT, (double *)o);
+  });
+}
+
+// ---- init_resampler / initLPF (Resampler.jl:26-99) ------------------------------------------------
+int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resampler **out) {
+  if (!ctx || !out) return TSDR_EINVAL;
+  *out = nullptr;
+  if (bufferSize == 0 || upCoeff < 1) return set_err(ctx, TSDR_EINVAL, "init_resampler: bufferSize and upCoeff must be positive");
+  const size_t N = bufferSize * (size_t)upCoeff;
+  if (N >= (size_t(1) << 30)) return set_err(ctx, TSDR_EINVAL, "init_resampler: sizeFFT too large");
+  tsdr_resampler *r = new tsdr_resampler();
+  r->ctx = ctx; r->bufferSize = bufferSize; r->up = upCoeff; r->sizeFFT = N;
+  if (hipMalloc((void **)&r->H, N * sizeof(float2)) != hipSuccess || hipMalloc((void **)&r->work, N * sizeof(float2)) != hipSuccess) {
+    tsdr_resampler_free(r);
+    return set_err(ctx, TSDR_ENOMEM, "init_resampler: allocation failed");
+  }
+  // H0 = round.(H .* exp(im*groupDelay*pulsation)) with H[1:bound]=1  (:85-91): entries are
+  // integers in {-1,0,1}; evaluated on the host in f64 like the reference's broadcast.
+  std::vector<float2> H0(N, make_float2(0.f, 0.f));
+  const double bound_d = nearbyint((double)N / (double)upCoeff / 2.0);
+  const size_t bound = bound_d < (double)N ? (size_t)bound_d : N;
+  const double g = -((double)N - 1.0) / 2.0;
+  for (size_t k = 0; k < bound; ++k) {
+    const double om = (double)(2.0L * M_PIl * (long double)k / (long double)N);
+    const double th = g * om;
+    H0[k] = make_float2((float)nearbyint(cos(th)), (float)nearbyint(sin(th)));
+  }
+  hipError_t e = hipMemcpyAsync(r->work, H0.data(), N * sizeof(float2), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { tsdr_resampler_free(r); return hip_fail(ctx, e, "init_resampler upload"); }
+  // h = ifft(H0) .* blackman ; H = fft(h) .* (-1)^k
+  int rc = fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, r->H, N, 1, +1);
+  if (!rc) {
+    hipLaunchKernelGGL(k_window, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->H, N);
+    rc = fft_any(ctx, reinterpret_cast<const float *>(r->H), 1, r->work, N, 1, -1);
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(k_altsign, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->work, N);
+    e = hipMemcpyAsync(r->H, r->work, N * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = hip_fail(ctx, e, "init_resampler finalize");
+  }
+  if (rc) { tsdr_resampler_free(r); return rc; }
+  *out = r;
+  return TSDR_OK;
+}
+
+int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float *out) {
+  if (!r || !in || !out) return TSDR_EINVAL;
+  tsdr_ctx *ctx = r->ctx;
+  if (n_in != r->bufferSize) return set_err(ctx, TSDR_EINVAL, "Size of input %zu should match size used during init %zu", n_in, r->bufferSize);
+  const size_t N = r->sizeFFT;
+  float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
+  if (!tmp) return TSDR_ENOMEM;
+  TSDR_LAUNCH(ctx, "resampler_stuff", k_stuff, dim3(stream_grid(ctx, N)), dim3(256), 0, in, N, (unsigned)r->up, r->work);
+  int rc = fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, tmp, N, 1, -1);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "resampler_filter", k_cmul, dim3(stream_grid(ctx, N)), dim3(256), 0, tmp, (const float2 *)r->H, N);
+  rc = fft_any(ctx, reinterpret_cast<const float *>(tmp), 1, r->work, N, 1, +1);
+  if (rc) return rc;
+  TSDR_LAUNCH(ctx, "resampler_out", k_real_scale, dim3(stream_grid(ctx, N)), dim3(256), 0, (const float2 *)r->work, N,
+              (float)(2 * r->up), out);
+  return TSDR_OK;
+}
+
+int tsdr_resampler_run(tsdr_resampler *r, const float *in, size_t n_in, float *out) {
+  if (!r) return TSDR_EINVAL;
+  if (n_in != r->bufferSize) return set_err(r->ctx, TSDR_EINVAL, "Size of input %zu should match size used during init %zu", n_in, r->bufferSize);
+  return host_map(r->ctx, in, n_in * 4, out, r->sizeFFT * 4,
+                  [&](void *i, void *o) { return tsdr_resampler_run_d(r, (const float *)i, n_in, (float *)o); });
+}
+
+int tsdr_resampler_lpf(tsdr_resampler *r, float *H_host) {
+  if (!r || !H_host) return TSDR_EINVAL;
+  tsdr_ctx *ctx = r->ctx;
+  TSDR_HIP(ctx, hipMemcpyAsync(H_host, r->H, r->sizeFFT * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TSDR_OK;
+}
+
+void tsdr_resampler_free(tsdr_resampler *r) {
+  if (!r) return;
+  if (r->ctx) (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->H) (void)hipFree(r->H);
+  if (r->work) (void)hipFree(r->work);
+  delete r;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+"""GPU parity, FFT-based functions: HIP (f32 FFT) vs the CPU oracle (f64 FFT rounded to f32).
+
+These cannot be bit-exact (different FFT factorisation and precision), so the bar is a stated
+tolerance: errors are measured relative to the largest magnitude of the vector, the natural
+scale of FFT rounding noise; argmax-type results must be identical.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(7)
+
+FFT_TOL = 5e-6   # max |err| / max |ref| for a single f32 FFT up to 2^23 points
+CORR_TOL = 2e-5  # autocorrelation (two FFTs + squaring), relative to r[0]
+
+
+def relmax(got, want):
+    want = np.asarray(want)
+    return float(np.max(np.abs(np.asarray(got, dtype=want.dtype) - want)) / np.max(np.abs(want)))
+
+
+def crandn(n):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+# ------------------------------------------------------------------ raw FFT engine
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 1 << 16, 1 << 17, 1 << 20, 1 << 22])
+def test_fft_pow2(ctx, n):
+    x = crandn(n)
+    ref = np.fft.fft(x.astype(np.complex128))
+    e = relmax(ctx.fft(x), ref)
+    assert e < FFT_TOL, f"n={n}: {e:.3e}"
+    ref = np.fft.ifft(x.astype(np.complex128))
+    e = relmax(ctx.fft(x, inverse=True), ref)
+    assert e < FFT_TOL, f"inverse n={n}: {e:.3e}"
+
+
+@pytest.mark.parametrize("n,batch", [(8, 1000), (64, 33), (256, 17), (1024, 9), (4096, 3), (1 << 13, 2)])
+def test_fft_batched(ctx, n, batch):
+    x = crandn(n * batch).reshape(batch, n)
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    e = relmax(ctx.fft(x), ref)
+    assert e < FFT_TOL, f"{e:.3e}"
+
+
+@pytest.mark.parametrize("n", [3, 5, 7, 100, 997, 1000, 1536, 80_000, 4_000_000 // 64])
+def test_fft_any_length(ctx, n):
+    x = crandn(n)
+    ref = np.fft.fft(x.astype(np.complex128))
+    e = relmax(ctx.fft(x), ref)
+    assert e < 2 * FFT_TOL, f"n={n}: {e:.3e}"
+    e = relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128)))
+    assert e < 2 * FFT_TOL, f"inverse n={n}: {e:.3e}"
+    # oracle FFT agrees with numpy too (pins the oracle's own transform)
+    assert relmax(O.fft(x), ref) < 1e-12
+
+
+# ------------------------------------------------------------------ Autocorrelations.jl
+def test_autocorr_periodic_known_answer(ctx):
+    """Exact period-T sequence: circular autocorrelation peaks at lag T, i.e. output index T
+    (0-based) with minDelay=0; zoom labels that entry with rate Fs/(T+1) (reference off-by-one)."""
+    T, reps, Fs = 250, 16, 10_000.0
+    base = rng.random(T).astype(np.float32)
+    x = np.tile(base, reps)  # n = 4000
+    G, lags = ctx.calculate_autocorrelation(x, Fs, 0, 0.2)  # indexMax = 2000, n = 4000
+    assert G.size == 2000 and lags.size == 2000 and lags[1] == 1 / Fs
+    k = int(np.argmax(G[1:])) + 1
+    assert k % T == 0, k
+    assert abs(G[T] - G[0]) < 1e-3  # same energy at a full period (dB)
+    rates, Gz = ctx.zoom_autocorr(G, Fs, rate_min=30, rate_max=50)
+    # window is indices 200..333 (1-based); the peak sits at 1-based index T+1 = 251
+    assert rates[0] == Fs / 200 and int(np.argmax(Gz)) + 200 == T + 1
+
+
+@pytest.mark.parametrize("n,Fs,maxd,mind", [(3000, 30_000.0, 0.05, 0.0), (5000, 10_000.0, 0.1, 0.01), (4096, 4096.0, 0.5, 0.0),
+                                           (1500, 1000.0, 1.0, 0.0), (100_003, 1e6, 0.03, 0.0)])
+def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind):
+    x = (rng.random(n) ** 2).astype(np.float32) * 1e-5  # power-like, non-negative (GUI.jl:70)
+    for scale in ("lin", "log"):
+        g, _ = ctx.calculate_autocorrelation(x, Fs, mind, maxd, scale)
+        o, _ = O.calculate_autocorrelation(x, Fs, mind, maxd, scale)
+        assert g.shape == o.shape
+        if scale == "lin":
+            assert relmax(g, o) < 2 * CORR_TOL, relmax(g, o)   # abs2 doubles the relative error
+        else:
+            assert np.max(np.abs(g - o)) < 2e-4, np.max(np.abs(g - o))  # dB; 8.7*CORR_TOL
+
+
+def test_autocorr_bounds_error(ctx):
+    x = np.ones(100, np.float32)
+    with pytest.raises(IndexError):  # BoundsError at Autocorrelations.jl:33
+        ctx.calculate_autocorrelation(x, 1000.0, 0, 0.5)
+    with pytest.raises(IndexError):
+        O.calculate_autocorrelation(x, 1000.0, 0, 0.5)
+
+
+def test_autocorr_search_c2(ctx, synth):
+    """extract_configuration (GUI.jl:56-81) at the C2 size: n = 4e6, refresh-rate argmax."""
+    Fs, fv = 20e6, 60.0
+    iq = synth.synth_leak(Fs, 2576, 1125, fv, 4_000_000)
+    x = O.abs2(iq)
+    assert np.array_equal(ctx.abs2(iq).view(np.uint32), x.view(np.uint32))
+    g, _ = ctx.calculate_autocorrelation(x, Fs, 0, 0.1)
+    o, _ = O.calculate_autocorrelation(x, Fs, 0, 0.1)
+    assert g.size == o.size == 2_000_000
+    assert np.max(np.abs(g - o)) < 2e-4, np.max(np.abs(g - o))
+    rg, gz = ctx.zoom_autocorr(g, Fs, rate_min=50, rate_max=90)
+    ro, oz = O.zoom_autocorr(o, Fs, rate_min=50, rate_max=90)
+    assert gz.size == oz.size == 177_779 and np.array_equal(rg, ro)
+    pg, po = int(np.argmax(gz)), int(np.argmax(oz))
+    top2 = np.sort(oz)[-2:]
+    assert pg == po, f"argmax {pg} vs {po}; oracle top-2 margin {top2[1] - top2[0]:.3e} dB"
+    # the strongest lag may sit one video line (Fs/(y_t*fv) = 296 samples = 0.053 Hz) off the frame
+    # lag: the bar pattern is line-periodic and sub-sample alignment decides between the two
+    assert abs(rg[pg] - fv) < 0.1, rg[pg]
+
+
+def test_autocorr_partial_sums_to_whole(ctx):
+    """partial sums over ranges of m, added in the linear domain, equal the whole."""
+    n, n_lags, G = 40_000, 20_000, 4
+    x = (rng.random(n) ** 2).astype(np.float32)
+    dx = ctx.upload(x)
+    parts = []
+    for g in range(G):
+        m0, cnt = g * n // G, n // G
+        dp = ctx.dev_alloc(n_lags * 4)
+        ctx.call("tsdr_autocorr_partial_d", C.c_void_p(dx), 0, n, m0, cnt, n_lags, C.c_void_p(dp))
+        parts.append(ctx.download(dp, n_lags, np.float32))
+        ctx.dev_free(dp)
+    total = np.sum(np.stack(parts).astype(np.float64), axis=0)
+    X = np.fft.fft(x.astype(np.float64))
+    ref = np.fft.ifft(X * np.conj(X)).real[:n_lags]
+    assert relmax(total, ref) < CORR_TOL, relmax(total, ref)
+    # finish: 10log10(abs2) of the reduced vector
+    dt = ctx.upload(total.astype(np.float32))
+    do = ctx.dev_alloc(n_lags * 4)
+    ctx.call("tsdr_autocorr_finish_d", C.c_void_p(dt), 0, n_lags, 1, C.c_void_p(do))
+    db = ctx.download(do, n_lags, np.float32)
+    assert np.max(np.abs(db - 20 * np.log10(np.abs(ref)))) < 2e-4
+    idx, val = C.c_size_t(0), C.c_float(0)
+    ctx.call("tsdr_argmax_d", C.c_void_p(do), n_lags, C.byref(idx), C.byref(val))
+    assert idx.value == int(np.argmax(db)) and val.value == db[idx.value]
+    for p in (dx, dt, do):
+        ctx.dev_free(p)
+
+
+# ------------------------------------------------------------------ GetSpectrum.jl
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("N", [1024, 80_000, 4097])
+def test_spectrum_vs_oracle(ctx, N, cplx):
+    sig = crandn(N + 10) if cplx else rng.standard_normal(N + 10).astype(np.float32)
+    sig = sig + 3.0  # strong DC line, like an AM-demodulated capture
+    f, y = ctx.getSpectrum(2e6, sig, N=N, lin=True)
+    o = O.getSpectrum(sig, N=N, lin=True)
+    assert f[0] == -1e6 and f.size == N
+    assert relmax(np.sqrt(y), np.sqrt(o)) < 2 * FFT_TOL, relmax(np.sqrt(y), np.sqrt(o))
+    # Parseval: sum |X|^2 = N * sum |x|^2
+    assert abs(y.astype(np.float64).sum() / (N * np.sum(np.abs(sig[:N].astype(np.complex128)) ** 2)) - 1) < 1e-5
+    # dB output where the bins are not in the noise of the DC line
+    _, ydb = ctx.getSpectrum(2e6, sig, N=N)
+    odb = O.getSpectrum(sig, N=N)
+    strong = o > 1e-4 * o.max()
+    assert np.max(np.abs(ydb[strong] - odb[strong])) < 2e-2
+
+
+def test_spectrum_too_long_raises(ctx):
+    with pytest.raises(IndexError):
+        ctx.getSpectrum(1.0, np.ones(10, np.float32), N=11)
+
+
+@pytest.mark.parametrize("sizeFFT,cplx", [(1024, False), (1024, True), (256, True), (1000, False)])
+def test_welch_and_waterfall(ctx, sizeFFT, cplx):
+    L = sizeFFT * 37 + 123  # ragged tail is dropped
+    sig = crandn(L) if cplx else rng.standard_normal(L).astype(np.float32)
+    _, y = ctx.getWelch(1.0, sig, sizeFFT=sizeFFT, lin=True)
+    o = O.getWelch(sig, sizeFFT=sizeFFT, lin=True)
+    assert relmax(y, o) < 4 * FFT_TOL, relmax(y, o)
+    t, f, m = ctx.getWaterfall(1.0, sig, sizeFFT=sizeFFT)
+    om = O.getWaterfall(sig, sizeFFT=sizeFFT)
+    assert m.dtype == np.float64 and m.shape == (sizeFFT, 37) and m.flags.f_contiguous
+    assert relmax(np.sqrt(m), np.sqrt(om)) < 4 * FFT_TOL
+    assert t[1] == sizeFFT / 1.0
+
+
+# ------------------------------------------------------------------ init_resampler
+@pytest.mark.parametrize("bufferSize,up", [(1000, 4), (1024, 2), (999, 3)])
+def test_init_resampler(ctx, bufferSize, up):
+    r, o = ctx.init_resampler(np.float32, bufferSize, up), O.Resampler(bufferSize, up)
+    H, Ho = r.lpf(), o.lpf()
+    assert relmax(H, Ho) < 4 * FFT_TOL, relmax(H, Ho)
+    x = rng.standard_normal(bufferSize).astype(np.float32)
+    out, oo = np.empty(bufferSize * up, np.float32), np.empty(bufferSize * up, np.float32)
+    r(out, x)
+    o(oo, x)
+    assert relmax(out, oo) < 1e-5, relmax(out, oo)
+    with pytest.raises(AssertionError):  # Resampler.jl:47
+        r(out, x[:-1])
+    with pytest.raises(AssertionError):  # Resampler.jl:44
+        r(out.astype(np.float64), x.astype(np.float64))
