@@ -297,6 +297,16 @@ class Context:
         return out
 
 
+def frames_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, frames_out=None, raster_out=None, sync_idx=None):
+    """Device-pointer form of Context.frames: every array argument is a device buffer (torch tensor
+    or raw address); enqueues on the context's stream and returns without synchronising."""
+    n = C.c_int(0)
+    ctx.call("tsdr_frames_d", C.c_void_p(sync.h if sync is not None else 0), _ptr(iq), int(nEch), int(S), int(y_t),
+             int(x_t), C.c_float(alpha), int(bool(do_align)), _ptr(state), _ptr(frames_out), _ptr(raster_out),
+             _ptr(sync_idx), C.byref(n))
+    return n.value
+
+
 class SyncXY:
     """SyncXY{Float32} state (FrameSynchronisation.jl:25-48) living on the device."""
 
