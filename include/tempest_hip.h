@@ -193,6 +193,18 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
                   float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                   int *sync_idx, int *n_frames);
 
+/* ---- the same loop in two stages, for sharding ONE buffer's frames across GPUs ----
+ * Stage 1 is independent per frame (shard frames across ranks, no collective): IQ -> 600x800 image
+ * per frame (+ optional raster) and, if do_align, two opaque 64-bit vsync argmax keys per frame
+ * (keys[2f] for beta_x, keys[2f+1] for beta_y).  Stage 2 resolves the two sequential couplings of
+ * the reference loop on the gathered images/keys: s_y of frame f is the beta_y argmax of frame f-1
+ * (FrameSynchronisation.jl:66) and the IIR recurrence (GUI.jl:175).  scan + combine on one GPU is
+ * exactly tsdr_frames_d. */
+int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
+                       int do_align, float *img_out, float *raster_out, unsigned long long *keys_out, int *n_frames);
+int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, const unsigned long long *keys, int n_frames,
+                          float alpha, int do_align, float *imageOut_state, float *frames_out, int *sync_idx);
+
 #ifdef __cplusplus
 }
 #endif

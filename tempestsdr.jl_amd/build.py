@@ -1,4 +1,4 @@
-"""Build libtempest_hip.so (gfx950) and the CPU oracle, in-tree.
+"""Build libtempest_hip.so (gfx950), in-tree.
 
     python tempestsdr.jl_amd/build.py [--force]
 
@@ -66,17 +66,5 @@ def build_hip(force=False, verbose=True):
     return LIB
 
 
-def build_oracle(verbose=True):
-    odir = os.path.join(ROOT, "oracle")
-    r = subprocess.run(["make", "-C", odir], capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("oracle build failed")
-    if verbose:
-        print("[oracle] ok")
-    return os.path.join(odir, "libtempest_oracle.so")
-
-
 if __name__ == "__main__":
     build_hip(force="--force" in sys.argv)
-    build_oracle()

@@ -28,41 +28,69 @@ using namespace tsdr;
 
 extern "C" {
 
-int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,
-                  int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx,
-                  int *n_frames) {
-  if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
+static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
+  if (!do_align) return TSDR_OK;
+  if (!sync) return set_err(ctx, TSDR_EINVAL, "do_align needs a SyncXY state");
+  int b[4];
+  tsdr_sync_bounds(sync, b);
+  // SyncXY(image_mat) is built on the 600x800 rendering image (GUI.jl:134-136)
+  if (b[1] != TSDR_RENDER_H / 4 || b[3] != TSDR_RENDER_W / 4) return set_err(ctx, TSDR_EINVAL, "SyncXY state must be 600x800");
+  return TSDR_OK;
+}
+
+int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
+                       int do_align, float *img_out, float *raster_out, unsigned long long *keys_out, int *n_frames) {
+  if (!ctx || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
   if (nEch && !iq) return TSDR_EINVAL;
-  const int H = TSDR_RENDER_H, W = TSDR_RENDER_W;
-  if (do_align) {
-    if (!sync) return set_err(ctx, TSDR_EINVAL, "do_align needs a SyncXY state");
-    int b[4];
-    tsdr_sync_bounds(sync, b);
-    // SyncXY(image_mat) is built on the 600x800 rendering image (GUI.jl:134-136)
-    if (b[1] != H / 4 || b[3] != W / 4) return set_err(ctx, TSDR_EINVAL, "SyncXY state must be 600x800");
-  }
+  int rc = frames_check(ctx, sync, do_align);
+  if (rc) return rc;
   const size_t nb = nEch / S;
   if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
   if (n_frames) *n_frames = (int)nb;
   if (nb == 0) return TSDR_OK;
+  if (!img_out || (do_align && !keys_out)) return TSDR_EINVAL;
   const int F = (int)nb;
-  const size_t npx = (size_t)H * W;
-  float *img = (float *)ctx->scratch(WS_IMG, (size_t)F * npx * 4);
-  if (!img) return TSDR_ENOMEM;
-  int rc;
+  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   if (raster_out) {
     rc = raster_frames_d(ctx, iq, 1, S, S, y_t, x_t, F, raster_out, (size_t)y_t * x_t);
     if (rc) return rc;
   }
-  rc = down_frames_d(ctx, iq, 1, S, S, y_t, x_t, H, W, F, img, npx);
+  rc = down_frames_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, img_out, npx);
   if (rc) return rc;
-  unsigned long long *keys = nullptr;
   if (do_align) {
-    rc = sync_scan_d(sync, img, npx, F, &keys);
+    unsigned long long *keys = keys_out;
+    rc = sync_scan_d(sync, img_out, npx, F, &keys);
     if (rc) return rc;
   }
-  return shift_iir_d(ctx, sync, img, npx, H, W, F, keys, do_align, alpha, imageOut_state, frames_out,
-                     do_align ? sync_idx : nullptr);
+  return TSDR_OK;
+}
+
+int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, const unsigned long long *keys, int n_frames,
+                          float alpha, int do_align, float *imageOut_state, float *frames_out, int *sync_idx) {
+  if (!ctx || !imageOut_state || n_frames < 0) return TSDR_EINVAL;
+  int rc = frames_check(ctx, sync, do_align);
+  if (rc) return rc;
+  if (n_frames == 0) return TSDR_OK;
+  if (!img || (do_align && !keys)) return TSDR_EINVAL;
+  return shift_iir_d(ctx, sync, img, (size_t)TSDR_RENDER_H * TSDR_RENDER_W, TSDR_RENDER_H, TSDR_RENDER_W, n_frames, keys,
+                     do_align, alpha, imageOut_state, frames_out, do_align ? sync_idx : nullptr);
+}
+
+int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,
+                  int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx,
+                  int *n_frames) {
+  if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
+  const size_t nb = nEch / S;
+  if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
+  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
+  float *img = (float *)ctx->scratch(WS_IMG, (nb ? nb : 1) * npx * 4);
+  unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, (nb ? nb : 1) * 2 * 8);
+  if (!img || !keys) return TSDR_ENOMEM;
+  int nf = 0;
+  int rc = tsdr_frames_scan_d(ctx, sync, iq, nEch, S, y_t, x_t, do_align, img, raster_out, keys, &nf);
+  if (n_frames) *n_frames = nf;
+  if (rc || nf == 0) return rc;
+  return tsdr_frames_combine_d(ctx, sync, img, keys, nf, alpha, do_align, imageOut_state, frames_out, sync_idx);
 }
 
 int tsdr_frames(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,

@@ -265,7 +265,8 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
   float *proj = (float *)ctx->scratch(WS_PROJ, (size_t)frames * proj_stride(y, x) * 4);
-  unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
+  // *keys_out != nullptr: caller-provided key buffer (2 per frame); else workspace
+  unsigned long long *keys = *keys_out ? *keys_out : (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
   if (!proj || !keys) return TSDR_ENOMEM;
   const SyncGeom g = geom_of(s);
   const unsigned nb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));

@@ -1,0 +1,62 @@
+"""The C-ABI shared library loads and exports every symbol include/tempest_hip.h declares.
+CPU only: no compute entry point is called (there is no GPU here and no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "tempest_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsdr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_a_sane_surface():
+    syms = header_symbols()
+    for must in ("tsdr_am_demod", "tsdr_sig_to_image", "tsdr_downgrade", "tsdr_autocorr", "tsdr_zoom_bounds",
+                 "tsdr_spectrum", "tsdr_welch", "tsdr_waterfall", "tsdr_sync_create", "tsdr_vsync", "tsdr_frames",
+                 "tsdr_resampler_init", "tsdr_naive_resample", "tsdr_invert_am", "tsdr_fm_demod"):
+        assert must in syms
+    assert len(syms) >= 60
+
+
+def test_library_exports_every_declared_symbol(tsdr):
+    lib = tsdr._lib.load()  # raises if the .so is missing or a prototype cannot be bound
+    raw = C.CDLL(tsdr._lib.LIB_PATH)
+    for s in header_symbols():
+        assert hasattr(raw, s), f"{s} declared in include/tempest_hip.h but not exported"
+    assert sorted(tsdr._lib.exported_names()) == header_symbols(), "ctypes table and header drifted apart"
+    assert b"gfx950" in lib.tsdr_version()
+    assert lib.tsdr_strerror(-2).startswith(b"index out of bounds")
+
+
+def test_no_device_means_loud_failure_not_fallback(tsdr):
+    """In this container there is no GPU: creating a context must FAIL (never fall back)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(tsdr.TempestHIPError):
+        tsdr.Context(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "tempestsdr.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".jl")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "libtempest_oracle" not in txt, f"{f} references the oracle"
+                assert "orc_" not in txt, f"{f} references an oracle symbol"
+
+
+def test_zoom_bounds_is_pure_host_logic(tsdr):
+    lib = tsdr._lib.load()
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    assert lib.tsdr_zoom_bounds(2_000_000, 20e6, 50.0, 90.0, C.byref(a), C.byref(b)) == 0
+    assert (a.value, b.value) == (222_222, 400_000)  # 177 779 points at C2
+    assert lib.tsdr_zoom_bounds(1000, 20e6, 50.0, 90.0, C.byref(a), C.byref(b)) == 0
+    assert (a.value, b.value) == (1000, 1000)  # min(.,N) clamp, Autocorrelations.jl:46-47
