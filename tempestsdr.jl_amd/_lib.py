@@ -112,11 +112,26 @@ def exported_names():
     return sorted(_SIGS)
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+    process cannot both own the GPU (whichever initialises second sees no device), and the dynamic
+    loader de-duplicates by SONAME only in load order.  So when torch is installed, import it BEFORE
+    dlopen-ing libtempest_hip.so: its runtime then serves both.  Without torch (e.g. under the Julia
+    shim) the system ROCm runtime is used.  TSDR_NO_TORCH_PRELOAD=1 skips this."""
+    if os.environ.get("TSDR_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def load():
     """dlopen the library and attach prototypes.  Raises if it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise TempestHIPError(
             f"{LIB_PATH} not found: build it with `python tempestsdr.jl_amd/build.py` "

@@ -211,3 +211,69 @@ def test_frames_short_buffer(ctx, tsdr):
     st = np.zeros((600, 800), np.float32, order="F")
     out = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq_random(100), 333333, 1125, 2576, 0.1, st)
     assert out["n_frames"] == 0 and not st.any()
+
+
+# ---------------------------------------------------------------- multi-GPU decomposition
+def test_scan_combine_split_equals_frames(ctx, tsdr, synth):
+    """Frames [0,2) and [2,5) scanned separately (as two ranks would), keys/images gathered, then
+    one combine: bit-identical to the single tsdr_frames call, including sync indices."""
+    import ctypes as C
+    Fs, x_t, y_t, fv, nfr = 2.0e6, 1056, 628, 60.0, 5
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 5)
+    ref_state = np.zeros((600, 800), np.float32, order="F")
+    ref = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), ref_state)
+    npx = 480000
+    d_iq = ctx.upload(iq)
+    d_img = ctx.dev_alloc(nfr * npx * 4)
+    d_keys = ctx.dev_alloc(nfr * 16)
+    sync = tsdr.SyncXY(ctx, 600, 800)
+    n = C.c_int(0)
+    for f0, cnt in ((0, 2), (2, 3)):
+        ctx.call("tsdr_frames_scan_d", C.c_void_p(sync.h), C.c_void_p(d_iq + 8 * f0 * S), cnt * S, S, y_t, x_t, 1,
+                 C.c_void_p(d_img + 4 * f0 * npx), C.c_void_p(0), C.c_void_p(d_keys + 16 * f0), C.byref(n))
+        assert n.value == cnt
+    d_state = ctx.upload(np.zeros(npx, np.float32))
+    d_frames = ctx.dev_alloc(nfr * npx * 4)
+    d_idx = ctx.dev_alloc(nfr * 8)
+    ctx.call("tsdr_frames_combine_d", C.c_void_p(sync.h), C.c_void_p(d_img), C.c_void_p(d_keys), nfr, C.c_float(0.1), 1,
+             C.c_void_p(d_state), C.c_void_p(d_frames), C.c_void_p(d_idx))
+    ctx.synchronize()
+    idx = ctx.download(d_idx, (nfr, 2), np.int32)
+    state = ctx.download(d_state, npx, np.float32)
+    frames = ctx.download(d_frames, (nfr, npx), np.float32)
+    assert np.array_equal(idx, ref["sync_idx"]), (idx.tolist(), ref["sync_idx"].tolist())
+    assert_bitexact(state, ref_state.ravel(order="F"), "combined state")
+    for f in range(nfr):
+        assert_bitexact(frames[f], ref["frames"][f].ravel(order="F"), f"combined frame {f}")
+    for p in (d_iq, d_img, d_keys, d_state, d_frames, d_idx):
+        ctx.dev_free(p)
+
+
+def test_parallel_bindings_single_rank(ctx, tsdr, synth):
+    """HipFrames / HipSearch (the product bindings bench.py uses at N>1) at world_size 1."""
+    import importlib
+    torch = pytest.importorskip("torch")
+    par = importlib.import_module("tempestsdr_jl_amd.parallel")
+    dev = torch.device("cuda", 0)
+    Fs, x_t, y_t, fv, nfr = 2.0e6, 1056, 628, 60.0, 4
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr)
+    ref_state = np.zeros((600, 800), np.float32, order="F")
+    ref = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), ref_state)
+    t_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
+    state = torch.zeros(480000, dtype=torch.float32, device=dev)
+    idx = torch.zeros(2 * nfr, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    hf = par.HipFrames(ctx, tsdr.SyncXY(ctx, 600, 800), dev, 1, 0)
+    assert hf.run(t_iq, iq.size, S, y_t, x_t, np.float32(0.1), state, sync_idx=idx) == nfr
+    assert np.array_equal(idx.cpu().numpy().reshape(nfr, 2), ref["sync_idx"])
+    assert_bitexact(state.cpu().numpy(), ref_state.ravel(order="F"), "HipFrames state")
+    # sharded search at world 1 == calculate_autocorrelation on abs2
+    n, n_lags = 60000, 30000
+    hs = par.HipSearch(ctx, dev, 1, 0)
+    res, pos, val = hs.run(t_iq, n, n_lags)
+    o, _ = O.calculate_autocorrelation(O.abs2(iq[:n]), Fs, 0, n_lags / Fs)
+    got = res.cpu().numpy()
+    assert np.max(np.abs(got - o)) < 2e-4, np.max(np.abs(got - o))
+    assert pos == int(np.argmax(o))
