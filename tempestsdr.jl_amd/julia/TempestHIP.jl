@@ -1,0 +1,190 @@
+# TempestHIP.jl -- thin `ccall` shim over libtempest_hip.so (include/tempest_hip.h).
+#
+# Re-exports TempestSDR.jl's hot-path functions with the reference's own names and argument
+# lists, so that GUI.jl / production scripts run unmodified once TempestSDR.jl does
+#
+#     include("TempestHIP.jl"); using .TempestHIP          # instead of include("Demodulation.jl") etc.
+#
+# (see INTEGRATION.md).  Julia is not available in the build container, so this file has not
+# been executed there; its Python twin tempestsdr.jl_amd/api.py binds the same entry points with
+# the same conventions and IS exercised by the test-suite.  Keep the two in step.
+#
+# Conventions (tempest_hip.h): status 0 = ok; -1 -> AssertionError/ArgumentError, -2 -> BoundsError;
+# ComplexF32 vectors are passed as-is (interleaved f32); matrices are column-major, as here.
+module TempestHIP
+
+export amDemod, invert_amDemod, fmDemod
+export sig_to_image, downgradeImage, naiveResampler, init_resampler
+export calculate_autocorrelation, zoom_autocorr
+export getSpectrum, getWelch, getWaterfall
+export SyncXY, vsync
+export hip_frames!           # fused GUI.jl:163-178 loop body (optional fast path)
+
+const LIB = get(ENV, "TEMPEST_HIP_LIB", joinpath(@__DIR__, "..", "libtempest_hip.so"))
+const RENDERING_SIZE = (600, 800)   # GUI.jl:10
+
+# ---- context: one per task (frame loop and configuration search run on different threads) ----
+mutable struct Ctx
+    h::Ptr{Cvoid}
+end
+function Ctx(device::Integer = 0)
+    h = ccall((:tsdr_create, LIB), Ptr{Cvoid}, (Cint,), device)
+    h == C_NULL && error("tempest_hip: no usable HIP device (there is no CPU fallback)")
+    c = Ctx(h)
+    finalizer(x -> ccall((:tsdr_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+    return c
+end
+const _ctxs = Dict{Int,Ctx}()
+const _lock = ReentrantLock()
+ctx() = lock(_lock) do
+    get!(() -> Ctx(parse(Int, get(ENV, "TEMPEST_HIP_DEVICE", "0"))), _ctxs, Threads.threadid())
+end
+
+function check(c::Ctx, rc::Cint, what)
+    rc == 0 && return
+    detail = unsafe_string(ccall((:tsdr_last_error, LIB), Cstring, (Ptr{Cvoid},), c.h))
+    msg = "$what: " * unsafe_string(ccall((:tsdr_strerror, LIB), Cstring, (Cint,), rc)) * " [$detail]"
+    rc == -1 && throw(AssertionError(msg))
+    rc == -2 && throw(BoundsError(msg))
+    rc == -3 && throw(OutOfMemoryError())
+    error(msg)
+end
+
+# ---- Demodulation.jl --------------------------------------------------------------------
+function amDemod(sig::Array{ComplexF32})                      # Demodulation.jl:26-28
+    out = similar(sig, Float32); c = ctx()
+    check(c, ccall((:tsdr_am_demod, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF32}, Csize_t, Ptr{Float32}), c.h, sig, length(sig), out), "amDemod")
+    return out
+end
+function invert_amDemod(sig::Array{ComplexF32})               # Demodulation.jl:31-35
+    out = similar(sig, Float32); c = ctx()
+    check(c, ccall((:tsdr_invert_am, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF32}, Csize_t, Ptr{Float32}), c.h, sig, length(sig), out), "invert_amDemod")
+    return out
+end
+function fmDemod(sig::Array{ComplexF32})                      # Demodulation.jl:17-23
+    out = similar(sig, Float32); c = ctx()
+    check(c, ccall((:tsdr_fm_demod, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF32}, Csize_t, Ptr{Float32}), c.h, sig, length(sig), out), "fmDemod")
+    return out
+end
+
+# ---- Resampler.jl -----------------------------------------------------------------------
+function sig_to_image(sig::AbstractVector{Float32}, y_t, x_t)   # Resampler.jl:117-122
+    s = collect(sig)                                            # views (GUI.jl:166) -> dense
+    img = Matrix{Float32}(undef, Int(y_t), Int(x_t)); c = ctx()
+    check(c, ccall((:tsdr_sig_to_image, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t, Cint, Cint, Ptr{Float32}),
+                   c.h, s, length(s), y_t, x_t, img), "sig_to_image")
+    return img
+end
+function downgradeImage(image::AbstractMatrix{Float32})         # Resampler.jl:124-126
+    a = collect(image); out = Matrix{Float32}(undef, RENDERING_SIZE...); c = ctx()
+    check(c, ccall((:tsdr_downgrade, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Cint, Ptr{Float32}),
+                   c.h, a, size(a, 1), size(a, 2), out), "downgradeImage")
+    return out
+end
+function naiveResampler(sigOut::Vector{Float32}, sigId::Vector{Float32}, upCoeff)   # Resampler.jl:103-110
+    length(sigOut) >= upCoeff * length(sigId) || throw(BoundsError(sigOut, upCoeff * length(sigId)))
+    c = ctx()
+    check(c, ccall((:tsdr_naive_resample, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t, Cint, Ptr{Float32}),
+                   c.h, sigId, length(sigId), upCoeff, sigOut), "naiveResampler")
+    return nothing
+end
+function init_resampler(T::Type, bufferSize::Int, upCoeff::Int)  # Resampler.jl:26-62
+    T == Float32 || throw(AssertionError("the HIP path implements Float32 resamplers"))
+    c = ctx(); r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(c, ccall((:tsdr_resampler_init, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Ptr{Ptr{Cvoid}}), c.h, bufferSize, upCoeff, r), "init_resampler")
+    h = r[]
+    function resampler!(out::AbstractVector{T2}, in::AbstractVector{T2}) where T2
+        @assert T == T2 "Type of input ($T2) should match type used during init ($T)"             # :44
+        @assert length(in) == bufferSize "Size of input $(length(in)) should match size used during init $bufferSize"   # :47
+        check(c, ccall((:tsdr_resampler_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t, Ptr{Float32}), h, in, length(in), out), "resampler!")
+    end
+    return resampler!
+end
+init_resampler(x::Vector{T}, upCoeff) where T = init_resampler(T, length(x), upCoeff)   # :65-68
+
+# ---- Autocorrelations.jl ------------------------------------------------------------------
+function calculate_autocorrelation(x, Fs, minDelay, maxDelay, scale = :log)   # Autocorrelations.jl:23-37
+    xv = convert(Vector{Float32}, x)
+    indexMin = 1 + round(minDelay * Fs) |> Int
+    indexMax = round(maxDelay * Fs) |> Int
+    out = Vector{Float32}(undef, max(indexMax - indexMin + 1, 1)); n = Ref{Csize_t}(0); c = ctx()
+    check(c, ccall((:tsdr_autocorr, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Float32}, Csize_t, Cdouble, Cdouble, Cdouble, Cint, Ptr{Float32}, Ptr{Csize_t}),
+                   c.h, xv, length(xv), Fs, minDelay, maxDelay, scale == :log ? 1 : 0, out, n), "calculate_autocorrelation")
+    lags = (0:(indexMax - indexMin)) * 1 / Fs
+    return resize!(out, n[]), lags
+end
+function zoom_autocorr(Γ, Fs; rate_min = 20, rate_max = 100)                 # Autocorrelations.jl:42-53
+    pmin = Ref{Csize_t}(0); pmax = Ref{Csize_t}(0)
+    rc = ccall((:tsdr_zoom_bounds, LIB), Cint, (Csize_t, Cdouble, Cdouble, Cdouble, Ptr{Csize_t}, Ptr{Csize_t}),
+               length(Γ), Fs, rate_min, rate_max, pmin, pmax)
+    rc == 0 || throw(BoundsError(Γ, Int(pmin[])))
+    xAx = (Int(pmin[]):Int(pmax[])) ./ Fs
+    return (1 ./ xAx, Γ[Int(pmin[]):Int(pmax[])])
+end
+
+# ---- GetSpectrum.jl -------------------------------------------------------------------------
+_raw(sig::AbstractVector{<:Complex}) = (convert(Vector{ComplexF32}, sig), 1)
+_raw(sig::AbstractVector{<:Real}) = (convert(Vector{Float32}, sig), 0)
+function getSpectrum(fs, sig; N = nothing)                                   # GetSpectrum.jl:21-30
+    isnothing(N) && (N = length(sig))
+    N <= length(sig) || throw(BoundsError(sig, N))
+    a, cplx = _raw(sig); y = Vector{Float32}(undef, N); c = ctx()
+    check(c, ccall((:tsdr_spectrum, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t, Cint, Ptr{Float32}), c.h, a, cplx, N, 0, y), "getSpectrum")
+    return (collect(((0:N-1) ./ N .- 0.5) * fs), y)
+end
+getSpectrum(sig) = getSpectrum(1, sig)
+function getWelch(fe, sig; sizeFFT = 1024)                                   # GetSpectrum.jl:36-52
+    a, cplx = _raw(sig); y = Vector{Float32}(undef, sizeFFT); c = ctx()
+    check(c, ccall((:tsdr_welch, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t, Csize_t, Cint, Ptr{Float32}),
+                   c.h, a, cplx, length(a), sizeFFT, 0, y), "getWelch")
+    return (collect(((0:sizeFFT-1) ./ sizeFFT .- 0.5) * fe), y)
+end
+function getWaterfall(fe, sig; sizeFFT = 1024)                               # GetSpectrum.jl:54-66
+    a, cplx = _raw(sig); nbSeg = length(a) ÷ sizeFFT
+    m = Matrix{Float64}(undef, sizeFFT, nbSeg); c = ctx()
+    check(c, ccall((:tsdr_waterfall, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t, Csize_t, Ptr{Float64}),
+                   c.h, a, cplx, length(a), sizeFFT, m), "getWaterfall")
+    return ((0:nbSeg-1) * (sizeFFT / fe), collect(((0:sizeFFT-1) ./ sizeFFT .- 0.5) .* fe), m)
+end
+getWaterfall(sig; sizeFFT = 1024) = getWaterfall(1, sig; sizeFFT = sizeFFT)
+
+# ---- FrameSynchronisation.jl ------------------------------------------------------------------
+mutable struct SyncXY{T}                                                      # FrameSynchronisation.jl:25-48
+    h::Ptr{Cvoid}
+    c::Ctx
+    y_t::Int
+    x_t::Int
+    function SyncXY(image::Matrix{T}) where T
+        T == Float32 || throw(MethodError(SyncXY, (image,)))
+        c = ctx(); r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(c, ccall((:tsdr_sync_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}), c.h, size(image, 1), size(image, 2), r), "SyncXY")
+        s = new{T}(r[], c, size(image, 1), size(image, 2))
+        finalizer(x -> ccall((:tsdr_sync_free, LIB), Cvoid, (Ptr{Cvoid},), x.h), s)
+        return s
+    end
+end
+function vsync(image::AbstractMatrix{T}, sync::SyncXY{T}) where T               # FrameSynchronisation.jl:56-79
+    a = collect(image); sy = Ref{Cint}(0); sx = Ref{Cint}(0)
+    size(a) == (sync.y_t, sync.x_t) || throw(DimensionMismatch("image does not match the SyncXY state"))
+    check(sync.c, ccall((:tsdr_vsync, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cint}, Ptr{Cint}), sync.h, a, sy, sx), "vsync")
+    return (Int(sy[]), Int(sx[]))      # s_y lags one call, exactly as the reference (:66)
+end
+
+# ---- fused loop body of coreProcessing (GUI.jl:163-178): optional fast path ----------------------
+"""
+    hip_frames!(imageOut, sigId, sync, S, y_t, x_t, α; do_align=true) -> (frames, sync_idx)
+
+Replaces GUI.jl:164-178 for one received buffer: `frames[:,:,n]` is what the n-th
+`non_blocking_put!(imageOut)` would have carried; `imageOut` is updated in place.
+"""
+function hip_frames!(imageOut::Matrix{Float32}, sigId::Vector{ComplexF32}, sync::SyncXY{Float32}, S, y_t, x_t, α::Float32; do_align = true)
+    nb = length(sigId) ÷ S
+    frames = Array{Float32}(undef, RENDERING_SIZE..., nb); idx = Matrix{Cint}(undef, 2, nb); n = Ref{Cint}(0)
+    check(sync.c, ccall((:tsdr_frames, LIB), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{ComplexF32}, Csize_t, Csize_t, Cint, Cint, Cfloat, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cint}, Ptr{Cint}),
+                        sync.c.h, sync.h, sigId, length(sigId), S, y_t, x_t, α, do_align ? 1 : 0, imageOut, frames, C_NULL, idx, n), "hip_frames!")
+    return frames, idx
+end
+
+end # module
