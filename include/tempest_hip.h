@@ -62,6 +62,17 @@ int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream);
 int tsdr_synchronize(tsdr_ctx *ctx);
 int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_t *hbm_bytes);
 
+/* Arithmetic of the resize/raster kernels (sig_to_image, the frame loop):
+ *   TSDR_EXACT: the reference's evaluation order -- f64 source coordinate sf*i+off and f64 weights,
+ *               one rounding to f32 per value; bit-identical to the CPU oracle.
+ *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend, within
+ *               1 ulp (1.2e-7 relative) of TSDR_EXACT; ~2.5x fewer VALU cycles.  Default.
+ * Both are parity-tested; everything downstream of the 600x800 image (vsync, circshift, IIR) is
+ * evaluated identically in the two modes. */
+enum tsdr_precision { TSDR_EXACT = 0, TSDR_FAST = 1 };
+int tsdr_set_precision(tsdr_ctx *ctx, int mode);
+int tsdr_get_precision(tsdr_ctx *ctx);
+
 /* resident buffers for callers without their own device allocator */
 void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes);
 int tsdr_dev_free(tsdr_ctx *ctx, void *dev);

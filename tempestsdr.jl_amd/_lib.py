@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libtempest_hip.so")
 
 TSDR_OK, TSDR_EINVAL, TSDR_EBOUNDS, TSDR_ENOMEM, TSDR_EHIP, TSDR_ENODEV = 0, -1, -2, -3, -4, -5
 RENDER_H, RENDER_W = 600, 800
+EXACT, FAST = 0, 1  # tsdr_precision
 
 
 class TempestHIPError(RuntimeError):
@@ -36,6 +37,8 @@ _SIGS = {
     "tsdr_version": (C.c_char_p, []),
     "tsdr_set_stream": (C.c_int, [vp, vp]),
     "tsdr_synchronize": (C.c_int, [vp]),
+    "tsdr_set_precision": (C.c_int, [vp, C.c_int]),
+    "tsdr_get_precision": (C.c_int, [vp]),
     "tsdr_device_info": (C.c_int, [vp, C.c_char_p, c_sz, c_i, c_szp]),
     "tsdr_dev_alloc": (vp, [vp, c_sz]),
     "tsdr_dev_free": (C.c_int, [vp, vp]),

@@ -71,6 +71,14 @@ class Context:
     def synchronize(self):
         self.call("tsdr_synchronize")
 
+    def set_precision(self, mode):
+        """'exact' (bit-identical to the oracle) or 'fast' (within 1 ulp, default) -- tsdr_set_precision"""
+        self.call("tsdr_set_precision", {"exact": _lib.EXACT, "fast": _lib.FAST}[mode])
+
+    @property
+    def precision(self):
+        return "exact" if self.lib.tsdr_get_precision(self.h) == _lib.EXACT else "fast"
+
     def set_stream(self, stream_ptr):
         self.call("tsdr_set_stream", C.c_void_p(stream_ptr or 0))
 

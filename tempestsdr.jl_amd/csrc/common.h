@@ -56,6 +56,7 @@ struct tsdr_ctx {
   bool own_stream = true;
   std::string err;
   int cu_count = 0;
+  int precision = TSDR_FAST;  // tsdr_precision
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];
   // profiling
   bool prof_on = false;

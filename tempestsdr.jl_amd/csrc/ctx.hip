@@ -152,6 +152,14 @@ int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream) {
   return TSDR_OK;
 }
 
+int tsdr_set_precision(tsdr_ctx *ctx, int mode) {
+  if (!ctx || (mode != TSDR_EXACT && mode != TSDR_FAST)) return TSDR_EINVAL;
+  ctx->precision = mode;
+  return TSDR_OK;
+}
+
+int tsdr_get_precision(tsdr_ctx *ctx) { return ctx ? ctx->precision : TSDR_EINVAL; }
+
 int tsdr_synchronize(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,90 +1,257 @@
 // resample.hip -- Resampler.jl on gfx950.
 //
-//   sig_to_image (Resampler.jl:117-122)   k_raster      IQ/|IQ| -> column-major (y_t,x_t) raster
-//   downgradeImage (:124-126)             k_resize2d    raster -> (h_out,w_out)
-//   sig_to_image |> downgradeImage        k_down_fused  IQ/|IQ| -> (h_out,w_out) with no raster in HBM
-//   imresize(sig,n)                       k_resize1d
-//   naiveResampler (:103-110)             k_naive
+//   sig_to_image (Resampler.jl:117-122)     k_raster_tile   IQ/|IQ| -> column-major (y_t,x_t) raster
+//   ... |> downgradeImage (:124-126)        k_raster_tile<DOWN>: the same launch also emits the 600x800 image
+//   sig_to_image |> downgradeImage          k_down_fused    IQ/|IQ| -> (h_out,w_out), no raster in HBM
+//   downgradeImage / imresize(image,size)   k_resize2d
+//   imresize(sig,n)                         k_resize1d
+//   naiveResampler (:103-110)               k_naive
 //
-// Arithmetic mirrors ImageTransformations.imresize! / Interpolations BSpline(Linear()) as
-// restated in oracle/tempest_oracle.c: f64 source coordinate sf*i+off (two roundings),
-// f64 weights, f32 samples, one rounding to f32 per interpolated value.  The fused kernel
-// rounds each raster value to f32 before the 2-D blend, exactly as going through the
-// materialised Float32 raster would.
+// Two arithmetic modes (tsdr_precision):
+//   EXACT  mirrors ImageTransformations.imresize! / Interpolations BSpline(Linear()) as restated in
+//          oracle/tempest_oracle.c: f64 source coordinate sf*i+off (two roundings), f64 weights, one rounding
+//          to f32 per value.  Bit-identical to the oracle.
+//   FAST   evaluates the SAME coordinate exactly as a rational, x0(i) = ((2i+1)S - P) / 2P (0-based), carried
+//          along a line with integer adds (quotient k, remainder r); the weight is r/2P in f64 and the blend is
+//          one f64 FMA rounded once to f32.  Within 1 ulp of EXACT (the two differ only in how the last bits of
+//          the f64 intermediate round), ~2.5x fewer VALU cycles: the EXACT loop is f64-issue bound, not HBM bound.
 //
-// Layout: the raster is column-major (y_t,x_t): element (line l, pixel p) at p*y_t + l, so a
-// wavefront owns 64 consecutive LINES of one pixel column and its store is one contiguous
-// 256-byte segment.  Source samples of a tile (64 lines x TP pixels) are staged once in LDS
-// ([line][sample], odd row pitch): HBM sees every IQ sample once per tile row, coalesced in
-// 128-byte runs, and |IQ| is evaluated once per staged sample rather than once per pixel.
+// Layout: the raster is column-major (y_t,x_t): element (line l, pixel p) at p*y_t + l, so a wavefront owns 64
+// consecutive LINES of one pixel column and its store is one contiguous 256-byte segment.  Source samples of a
+// tile (64 lines x 128 pixels) are staged once in LDS ([line][sample], odd pitch): HBM sees every IQ sample once
+// per tile row in 128-byte runs and |IQ| is evaluated once per staged sample, not once per pixel.  Workgroups are
+// ordered so that the tiles stacked over one pixel strip run back to back on ONE XCD: the 256-byte segments of
+// vertically adjacent tiles share 128-byte lines, which then merge in that XCD's L2 instead of reaching HBM as
+// two partial writes.
 #include "common.h"
 
 namespace tsdr {
 
-template <bool CPLX>
+// ---- |IQ| -----------------------------------------------------------------------------------------------
+template <bool EXACT>
+__device__ inline float abs_iq(float re, float im) {
+  if (EXACT) return abs_c(re, im);
+  const float m = fmaf(re, re, im * im);
+  if (m > 1e-30f && m < 1e30f) return sqrtf(m);  // correctly rounded f32 sqrt; <= 1 ulp overall
+  return abs_c(re, im);                           // tiny / huge / non-finite: the scaled f64 form
+}
+
+template <bool CPLX, bool EXACT>
 __device__ inline float load_sample(const float *__restrict__ src, unsigned k) {
   if (CPLX) {
-    float2 z = reinterpret_cast<const float2 *>(src)[k];
-    return abs_c(z.x, z.y);
+    const float2 z = reinterpret_cast<const float2 *>(src)[k];
+    return abs_iq<EXACT>(z.x, z.y);
   }
   return src[k];
 }
 
-// ------------------------------------------------------------------------------------------
-// k_raster: one frame-tile of 64 lines x TP pixels per workgroup.
-// ------------------------------------------------------------------------------------------
-template <bool CPLX>
-__global__ __launch_bounds__(256) void k_raster(const float *__restrict__ in, size_t in_stride, unsigned S, int y_t,
-                                                int x_t, float *__restrict__ out, size_t out_stride, int TP, int W,
-                                                int tiles_p) {
+// ---- FAST coordinate: exact rational, incremental ---------------------------------------------------------
+struct FastAx {
+  unsigned S, P, D;       // D = 2P
+  unsigned qstep, rstep;  // 2S = qstep*D + rstep : advance of (k, r) per output sample
+  double invDd;           // 1/D
+};
+
+// a + d*(b - a) with one f64 FMA and one rounding to f32: within 1 ulp of the value whatever |b-a| is
+__device__ inline float fast_blend(float a, float b, double d) {
+  return (float)fma(d, (double)b - (double)a, (double)a);
+}
+
+static inline FastAx fast_axis(size_t S, size_t P) {
+  FastAx f;
+  f.S = (unsigned)S; f.P = (unsigned)P; f.D = (unsigned)(2 * P);
+  f.qstep = (unsigned)((2 * S) / (2 * P));
+  f.rstep = (unsigned)((2 * S) % (2 * P));
+  f.invDd = 1.0 / (double)(2 * P);
+  return f;
+}
+
+// floor division of num = (2*flat+1)*S - P by D (num may be negative for the first pixels of a frame)
+__device__ inline void fast_pos(const FastAx &f, unsigned flat, int &k, unsigned &r) {
+  const long long num = (long long)(2ull * flat + 1ull) * (long long)f.S - (long long)f.P;
+  long long q = (long long)floor((double)num * f.invDd);
+  long long rem = num - q * (long long)f.D;
+  if (rem < 0) { rem += f.D; q -= 1; }
+  else if (rem >= (long long)f.D) { rem -= f.D; q += 1; }
+  k = (int)q;
+  r = (unsigned)rem;
+}
+
+__device__ inline void fast_step(const FastAx &f, int &k, unsigned &r) {
+  k += (int)f.qstep;
+  r += f.rstep;
+  if (r >= f.D) { r -= f.D; k += 1; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_raster_tile: one tile of 64 lines x TP pixels per workgroup (TP = 128 whenever the staged span fits).
+// DOWN: tiles overlap by one line / one pixel (63 x TP-1 owned); the tile's raster values are kept in LDS and
+// the 600x800 output pixels whose top-left tap falls in the owned area are produced by the same workgroup.
+// ------------------------------------------------------------------------------------------------------------
+struct TileParams {
+  unsigned S;
+  int y_t, x_t;
+  int TP, W;            // pixels per tile, LDS row capacity (samples)
+  int tiles_l, tiles_p; // tiles per frame
+  int frames;
+  int own_l, own_p;     // owned lines / pixels per tile (64/TP, or 63/TP-1 with DOWN)
+  int h_out, w_out;     // DOWN only
+  int NR, NC;           // DOWN: candidate output rows / columns per tile
+};
+
+template <bool CPLX, bool EXACT, bool DOWN>
+__global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ in, size_t in_stride, TileParams q,
+                                                     FastAx fa, float *__restrict__ out, size_t out_stride,
+                                                     float *__restrict__ down, size_t down_stride) {
   extern __shared__ float lds[];
-  const int Wp = W | 1;
-  int *kfirst = reinterpret_cast<int *>(lds + 64 * Wp);
-  const int tl = blockIdx.x / tiles_p, tp = blockIdx.x - tl * tiles_p;
-  const int l0 = tl * 64, p0 = tp * TP;
-  const int f = blockIdx.y;
+  const int Wp = q.W | 1;
+  float *smp = lds;                                        // [64][Wp] staged samples
+  int *kfirst = reinterpret_cast<int *>(smp + 64 * Wp);    // [64]
+  float *tile = reinterpret_cast<float *>(kfirst + 64);    // DOWN: [TP][65] raster values (pixel-major)
+  // candidate tables (DOWN): rows then columns
+  int *rk = reinterpret_cast<int *>(tile + (DOWN ? q.TP * 65 : 0));
+  int *ck = rk + (DOWN ? q.NR : 0);
+  double *rd = reinterpret_cast<double *>(ck + (DOWN ? q.NC + ((q.NR + q.NC) & 1) : 0));
+  double *cd = rd + (DOWN ? q.NR : 0);
+
+  // XCD-aware order: unit u = (frame, pixel strip); all tiles_l tiles of a unit are consecutive slots of one XCD
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b & 7u, slot = b >> 3;
+  const int tl = (int)(slot % (unsigned)q.tiles_l);
+  const unsigned u = (slot / (unsigned)q.tiles_l) * 8u + xcd;
+  if (u >= (unsigned)(q.frames * q.tiles_p)) return;
+  const int f = (int)(u / (unsigned)q.tiles_p), tp = (int)(u % (unsigned)q.tiles_p);
+  const int l0 = tl * q.own_l, p0 = tp * q.own_p;
   const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
-  const unsigned P = (unsigned)y_t * (unsigned)x_t;
-  const RsAxis ax = rs_axis(S, P);
-  const bool same = (S == P);  // imresize copies when sizes match
+  const unsigned P = (unsigned)q.y_t * (unsigned)q.x_t;
+  const RsAxis ax = rs_axis(q.S, P);
+  const bool same = (q.S == P);
   const int tid = threadIdx.x;
 
   if (tid < 64) {
-    int l = min(l0 + tid, y_t - 1);
-    double d;
-    kfirst[tid] = (int)rs_pos(ax, (double)((unsigned)l * (unsigned)x_t + (unsigned)p0 + 1u), d);
+    const int l = min(l0 + tid, q.y_t - 1);
+    const unsigned flat = (unsigned)l * (unsigned)q.x_t + (unsigned)p0;
+    int k;
+    if (EXACT) { double d; k = (int)rs_pos(ax, (double)(flat + 1u), d); }
+    else { unsigned r; fast_pos(fa, flat, k, r); k = max(k, 0); }
+    kfirst[tid] = k;
+  }
+  if (DOWN) {
+    // candidate output rows/columns whose top-left tap may fall in this tile (monotone maps -> contiguous);
+    // k = -1 marks "not owned by this tile"
+    const RsAxis ay = rs_axis((size_t)q.y_t, (size_t)q.h_out), axx = rs_axis((size_t)q.x_t, (size_t)q.w_out);
+    if (tid < q.NR) {
+      const int rbase = max(0, (int)floor(((double)l0 + 0.5) / ay.sf - 0.5) - 1);
+      const int r = rbase + tid;
+      int k = -1; double d = 0.0;
+      if (r < q.h_out) {
+        k = (int)rs_pos(ay, (double)(r + 1), d);
+        const bool last = (tl == q.tiles_l - 1);
+        if (k < l0 || (!last && k >= l0 + q.own_l)) k = -1;
+      }
+      rk[tid] = k < 0 ? -1 : ((r << 8) | (k - l0));  // row index and local line (local line < 64)
+      rd[tid] = d;
+    }
+    const int t2 = tid - 64;
+    if (t2 >= 0 && t2 < q.NC) {
+      const int cbase = max(0, (int)floor(((double)p0 + 0.5) / axx.sf - 0.5) - 1);
+      const int c = cbase + t2;
+      int k = -1; double d = 0.0;
+      if (c < q.w_out) {
+        k = (int)rs_pos(axx, (double)(c + 1), d);
+        const bool last = (tp == q.tiles_p - 1);
+        if (k < p0 || (!last && k >= p0 + q.own_p)) k = -1;
+      }
+      ck[t2] = k < 0 ? -1 : ((c << 8) | (k - p0));   // column index and local pixel (local pixel < 128)
+      cd[t2] = d;
+    }
   }
   __syncthreads();
   {  // stage: 16 lanes per line -> 128-byte runs of IQ
     const int sub = tid >> 4, j0 = tid & 15;
     for (int r = sub; r < 64; r += 16) {
       const unsigned kf = (unsigned)kfirst[r];
-      for (int j = j0; j < W; j += 16) {
-        unsigned k = min(kf + (unsigned)j, S - 1u);
-        lds[r * Wp + j] = load_sample<CPLX>(src, k);
+      for (int j = j0; j < q.W; j += 16) {
+        const unsigned k = min(kf + (unsigned)j, q.S - 1u);
+        smp[r * Wp + j] = load_sample<CPLX, EXACT>(src, k);
       }
     }
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
-  const int l = l0 + lane;
-  if (l < y_t) {
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l = l0 + lane;
+    const int pw = q.TP >> 2;
+    const int pbeg = p0 + wave * pw, pend = min(pbeg + pw, q.x_t);
+    const bool line_ok = l < q.y_t;
+    // a line/pixel is stored by the tile that owns it (the halo line/pixel of a DOWN tile belongs to the next tile)
+    const bool store_line = line_ok && (lane < q.own_l || tl == q.tiles_l - 1);
+    const int pstore_end = (tp == q.tiles_p - 1) ? q.x_t : min(p0 + q.own_p, q.x_t);
     const int kf = kfirst[lane];
-    const int pw = TP >> 2;
-    const int pbeg = p0 + wave * pw, pend = min(pbeg + pw, x_t);
-    const float *row = lds + lane * Wp;
-    float *o = out + (size_t)f * out_stride + (size_t)l;
-    const unsigned base = (unsigned)l * (unsigned)x_t + 1u;
-    for (int p = pbeg; p < pend; ++p) {
-      double d;
-      int j = (int)rs_pos(ax, (double)(base + (unsigned)p), d) - kf;
-      float a = row[j], b = row[j + 1];
-      o[(size_t)p * y_t] = same ? (d == 1.0 ? b : a) : rs_blend(a, b, d);
+    const float *row = smp + lane * Wp;
+    float *o = out ? out + (size_t)f * out_stride + (size_t)(line_ok ? l : 0) : nullptr;
+    const unsigned flat0 = (unsigned)(line_ok ? l : q.y_t - 1) * (unsigned)q.x_t;
+    if (EXACT) {
+      const unsigned base = flat0 + 1u;
+      for (int p = pbeg; p < pend; ++p) {
+        double d;
+        const int j = (int)rs_pos(ax, (double)(base + (unsigned)p), d) - kf;
+        const float a = row[j], bb = row[j + 1];
+        const float v = same ? (d == 1.0 ? bb : a) : rs_blend(a, bb, d);
+        if (o && store_line && p < pstore_end) o[(size_t)p * q.y_t] = v;
+        if (DOWN) tile[(p - p0) * 65 + lane] = v;
+      }
+    } else {
+      int k; unsigned r;
+      fast_pos(fa, flat0 + (unsigned)pbeg, k, r);
+      for (int p = pbeg; p < pend; ++p) {
+        const int j = max(k, 0) - kf;
+        const float a = row[j], bb = row[j + 1];
+        const double d = k < 0 ? 0.0 : (double)r * fa.invDd;
+        const float v = fast_blend(a, bb, d);
+        if (o && store_line && p < pstore_end) o[(size_t)p * q.y_t] = v;
+        if (DOWN) tile[(p - p0) * 65 + lane] = v;
+        fast_step(fa, k, r);
+      }
+    }
+  }
+  if (!DOWN) return;
+  __syncthreads();
+  {
+    // output pixels: waves stride the candidate columns, lanes are candidate rows (NR <= 2*64)
+    const int wave = tid >> 6, lane = tid & 63;
+    float *dn = down + (size_t)f * down_stride;
+    for (int rr = lane; rr < q.NR; rr += 64) {
+      const int rkv = rk[rr];
+      if (rkv < 0) continue;
+      const int r = rkv >> 8, ly = rkv & 255;
+      const double dy = rd[rr];
+      for (int cc = wave; cc < q.NC; cc += 4) {
+        const int ckv = ck[cc];
+        if (ckv < 0) continue;
+        const int c = ckv >> 8, lx = ckv & 255;
+        const float *t0 = tile + lx * 65 + ly;
+        const float R00 = t0[0], R10 = t0[1], R01 = t0[65], R11 = t0[66];
+        float v;
+        if (EXACT) {
+          const double dx = cd[cc];
+          const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
+          const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
+          const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
+          v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
+        } else {
+          const double dx = cd[cc];
+          const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
+          const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
+          v = (float)fma(dy, bot - top, top);
+        }
+        dn[(size_t)c * q.h_out + r] = v;
+      }
     }
   }
 }
 
-// direct variant (no LDS) for ratios the tiled kernel cannot stage; lanes along lines.
+// direct variant (no LDS, EXACT arithmetic) for ratios the tiled kernel cannot stage; lanes along lines.
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__ in, size_t in_stride, unsigned S,
                                                        int y_t, int x_t, float *__restrict__ out, size_t out_stride) {
@@ -96,31 +263,47 @@ __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__
   const int lblocks = (y_t + 63) >> 6;
   const size_t total = (size_t)lblocks * x_t * 64;
   for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
-    int lane = (int)(w & 63);
-    size_t rest = w >> 6;
-    int p = (int)(rest % (size_t)x_t);
-    int l = (int)(rest / (size_t)x_t) * 64 + lane;
+    const int lane = (int)(w & 63);
+    const size_t rest = w >> 6;
+    const int p = (int)(rest % (size_t)x_t);
+    const int l = (int)(rest / (size_t)x_t) * 64 + lane;
     if (l >= y_t) continue;
     double d;
-    unsigned k = rs_pos(ax, (double)((unsigned)l * (unsigned)x_t + (unsigned)p + 1u), d);
-    float a = load_sample<CPLX>(src, k), b = load_sample<CPLX>(src, k + 1u);
+    const unsigned k = rs_pos(ax, (double)((unsigned)l * (unsigned)x_t + (unsigned)p + 1u), d);
+    const float a = load_sample<CPLX, true>(src, k), b = load_sample<CPLX, true>(src, k + 1u);
     out[(size_t)f * out_stride + (size_t)p * y_t + l] = same ? (d == 1.0 ? b : a) : rs_blend(a, b, d);
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_down_fused: sig_to_image |> downgradeImage without the raster.  Tile = 64 output rows x
-// TC output columns; the source lines those rows touch are staged in LDS.
-// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------
+// k_down_fused: sig_to_image |> downgradeImage without the raster.  Tile = 64 output rows x TC output columns;
+// the source lines those rows touch are staged in LDS; each output pixel evaluates its four raster taps (each
+// rounded to f32 as the materialised raster would hold it) and blends them.
+// ------------------------------------------------------------------------------------------------------------
 struct DownParams {
   unsigned S;
   int y_t, x_t, h_out, w_out;
   int TC, NL, W, tiles_c;
 };
 
-template <bool CPLX>
+template <bool EXACT>
+__device__ inline float raster_tap(const RsAxis &ax1, const FastAx &fa, bool same1, unsigned flat, const float *row, int kf) {
+  if (EXACT) {
+    double d;
+    const int j = (int)rs_pos(ax1, (double)(flat + 1u), d) - kf;
+    return same1 ? (d == 1.0 ? row[j + 1] : row[j]) : rs_blend(row[j], row[j + 1], d);
+  }
+  // FAST: x0 = sf*(flat+0.5) - 0.5 in f64 (one FMA), clamped below; weight and blend in f32
+  double x = fma(ax1.sf, (double)flat + 0.5, -0.5);
+  x = fmax(x, 0.0);
+  const double xf = floor(x);
+  const int j = (int)xf - kf;
+  return fast_blend(row[j], row[j + 1], x - xf);
+}
+
+template <bool CPLX, bool EXACT>
 __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
-                                                    float *__restrict__ out, size_t out_stride) {
+                                                    FastAx fa, float *__restrict__ out, size_t out_stride) {
   extern __shared__ float lds[];
   const int Wp = q.W | 1;
   int *kfirst = reinterpret_cast<int *>(lds + (size_t)q.NL * Wp);
@@ -140,16 +323,21 @@ __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in
   const int ly1 = (int)rs_pos(ay, (double)(min(r0 + 63, q.h_out - 1) + 1), dtmp) + 1;
   const int nl = ly1 - ly0 + 1;
   const int pxa = (int)rs_pos(axx, (double)(c0 + 1), dtmp);
-  for (int i = tid; i < nl; i += 256)
-    kfirst[i] = (int)rs_pos(ax1, (double)((unsigned)(ly0 + i) * (unsigned)q.x_t + (unsigned)pxa + 1u), dtmp);
+  for (int i = tid; i < nl; i += 256) {
+    const unsigned flat = (unsigned)(ly0 + i) * (unsigned)q.x_t + (unsigned)pxa;
+    int k;
+    if (EXACT) k = (int)rs_pos(ax1, (double)(flat + 1u), dtmp);
+    else k = (int)floor(fmax(fma(ax1.sf, (double)flat + 0.5, -0.5), 0.0));
+    kfirst[i] = k;
+  }
   __syncthreads();
   {
     const int sub = tid >> 4, j0 = tid & 15;
     for (int i = sub; i < nl; i += 16) {
       const unsigned kf = (unsigned)kfirst[i];
       for (int j = j0; j < q.W; j += 16) {
-        unsigned k = min(kf + (unsigned)j, q.S - 1u);
-        lds[i * Wp + j] = load_sample<CPLX>(src, k);
+        const unsigned k = min(kf + (unsigned)j, q.S - 1u);
+        lds[i * Wp + j] = load_sample<CPLX, EXACT>(src, k);
       }
     }
   }
@@ -163,33 +351,36 @@ __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in
   const float *row0 = lds + (size_t)i0 * Wp;
   const float *row1 = row0 + Wp;
   const int kf0 = kfirst[i0], kf1 = kfirst[i0 + 1];
-  const unsigned b0 = (unsigned)ky * (unsigned)q.x_t + 1u, b1 = b0 + (unsigned)q.x_t;
+  const unsigned b0 = (unsigned)ky * (unsigned)q.x_t, b1 = b0 + (unsigned)q.x_t;
   const int cend = min(c0 + q.TC, q.w_out);
   float *o = out + (size_t)f * out_stride + (size_t)r;
   for (int c = c0 + wave; c < cend; c += 4) {
-    double dx, d;
+    double dx;
     const unsigned kx = rs_pos(axx, (double)(c + 1), dx);
-    int j;
     // the four raster values, each rounded to f32 as the materialised raster would hold them
-    j = (int)rs_pos(ax1, (double)(b0 + kx), d) - kf0;
-    const float R00 = same1 ? (d == 1.0 ? row0[j + 1] : row0[j]) : rs_blend(row0[j], row0[j + 1], d);
-    j = (int)rs_pos(ax1, (double)(b0 + kx + 1u), d) - kf0;
-    const float R01 = same1 ? (d == 1.0 ? row0[j + 1] : row0[j]) : rs_blend(row0[j], row0[j + 1], d);
-    j = (int)rs_pos(ax1, (double)(b1 + kx), d) - kf1;
-    const float R10 = same1 ? (d == 1.0 ? row1[j + 1] : row1[j]) : rs_blend(row1[j], row1[j + 1], d);
-    j = (int)rs_pos(ax1, (double)(b1 + kx + 1u), d) - kf1;
-    const float R11 = same1 ? (d == 1.0 ? row1[j + 1] : row1[j]) : rs_blend(row1[j], row1[j + 1], d);
-    // first dimension (lines) outermost: wy0*(wx0*a00 + wx1*a01) + wy1*(wx0*a10 + wx1*a11)
-    const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
-    const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
-    const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
-    o[(size_t)c * q.h_out] = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
+    const float R00 = raster_tap<EXACT>(ax1, fa, same1, b0 + kx, row0, kf0);
+    const float R01 = raster_tap<EXACT>(ax1, fa, same1, b0 + kx + 1u, row0, kf0);
+    const float R10 = raster_tap<EXACT>(ax1, fa, same1, b1 + kx, row1, kf1);
+    const float R11 = raster_tap<EXACT>(ax1, fa, same1, b1 + kx + 1u, row1, kf1);
+    float v;
+    if (EXACT) {
+      // first dimension (lines) outermost: wy0*(wx0*a00 + wx1*a01) + wy1*(wx0*a10 + wx1*a11)
+      const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
+      const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
+      const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
+      v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
+    } else {
+      const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
+      const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
+      v = (float)fma(dy, bot - top, top);
+    }
+    o[(size_t)c * q.h_out] = v;
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// generic helpers
-// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------
+// generic helpers (EXACT arithmetic)
+// ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resize1d(const float *__restrict__ in, size_t n_in, size_t n_out,
                                                   float *__restrict__ out) {
   const RsAxis ax = rs_axis(n_in, n_out);
@@ -231,23 +422,98 @@ __global__ __launch_bounds__(256) void k_naive(const float *__restrict__ in, siz
     out[i] = in[i / up];
 }
 
-// ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------
 // host-side tiling plans
-// ------------------------------------------------------------------------------------------
-struct RasterPlan { bool tiled; int TP, W; size_t lds; };
+// ------------------------------------------------------------------------------------------------------------
+static int check_geom(tsdr_ctx *ctx, size_t S, int y_t, int x_t) {
+  if (y_t <= 0 || x_t <= 0) return set_err(ctx, TSDR_EINVAL, "y_t and x_t must be positive");
+  const size_t P = (size_t)y_t * (size_t)x_t;
+  if (S >= (size_t(1) << 31) || P >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "frame larger than 2^31 samples/pixels");
+  if (S != P && S < 2) return set_err(ctx, TSDR_EINVAL, "imresize needs at least 2 input samples");
+  return TSDR_OK;
+}
 
-static RasterPlan plan_raster(size_t S, size_t P) {
+template <bool CPLX, bool EXACT, bool DOWN>
+static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t in_stride, const TileParams &q,
+                       const FastAx &fa, size_t lds, float *out, size_t out_stride, float *down, size_t down_stride) {
+  const size_t units = (size_t)q.frames * q.tiles_p;
+  const size_t grid = 8 * ceil_div(units, 8) * (size_t)q.tiles_l;
+  if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "raster: grid too large");
+  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, EXACT, DOWN>), dim3((unsigned)grid), dim3(256), lds, in, in_stride, q, fa, out,
+              out_stride, down, down_stride);
+  return TSDR_OK;
+}
+
+// sig_to_image for `frames` consecutive frames (raster `out`, may be null when only `down` is wanted and the
+// tile kernel applies) and, when `down` != null, the (h_out,w_out) image of each frame from the same launch.
+// Returns TSDR_OK and sets *did_down when the down image was produced here.
+int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int frames,
+                    float *out, size_t out_stride, float *down = nullptr, size_t down_stride = 0, int h_out = 0,
+                    int w_out = 0, bool *did_down = nullptr) {
+  if (did_down) *did_down = false;
+  int rc = check_geom(ctx, S, y_t, x_t);
+  if (rc) return rc;
+  if (frames <= 0) return TSDR_OK;
+  const size_t P = (size_t)y_t * x_t;
   const double sf = (double)S / (double)P;
-  RasterPlan pl{false, 0, 0, 0};
+  const bool exact = ctx->precision == TSDR_EXACT || P >= (size_t(1) << 30);
+  // fused downgrade in the raster launch: only when both axes shrink (<= 66 x 130 candidates per tile)
+  const bool want_down = down && !(y_t == h_out && x_t == w_out) && y_t >= 2 * 64 && x_t >= 2 * 128 &&
+                         (double)y_t / h_out >= 1.0 && (double)x_t / w_out >= 1.0;
+  TileParams q{};
+  q.S = (unsigned)S; q.y_t = y_t; q.x_t = x_t; q.frames = frames;
+  bool tiled = false;
   for (int TP = 128; TP >= 4; TP >>= 1) {
-    long W = (long)((double)(TP - 1) * sf) + 4;
-    if (W <= 191) {
-      pl.tiled = true; pl.TP = TP; pl.W = (int)W;
-      pl.lds = (size_t)64 * (size_t)(W | 1) * 4 + 64 * 4;
-      break;
-    }
+    const long W = (long)((double)(TP - 1) * sf) + 4;
+    if (W <= 191) { tiled = true; q.TP = TP; q.W = (int)W; break; }
   }
-  return pl;
+  if (tiled) {
+    const bool dn = want_down && q.TP == 128;
+    q.own_l = dn ? 63 : 64;
+    q.own_p = dn ? q.TP - 1 : q.TP;
+    q.tiles_l = dn ? (y_t - 2) / 63 + 1 : (int)ceil_div((size_t)y_t, 64);
+    q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
+    size_t lds = (size_t)64 * (size_t)(q.W | 1) * 4 + 64 * 4;
+    if (dn) {
+      q.h_out = h_out; q.w_out = w_out;
+      q.NR = (int)ceil(64.0 / ((double)y_t / h_out)) + 4;
+      q.NC = (int)ceil((double)q.TP / ((double)x_t / w_out)) + 4;
+      if (q.NR > 128 || q.NC > 192) return set_err(ctx, TSDR_EINVAL, "raster: candidate table overflow");
+      lds += (size_t)q.TP * 65 * 4 + (size_t)(q.NR + q.NC + 1) * 4 + (size_t)(q.NR + q.NC) * 8 + 8;
+    }
+    const FastAx fa = fast_axis(S, P);
+#define TILE(C, E, D, NAME) launch_tile<C, E, D>(ctx, NAME, in, in_stride, q, fa, lds, out, out_stride, down, down_stride)
+    if (dn) {
+      if (cplx) rc = exact ? TILE(true, true, true, "raster_down_iq_exact") : TILE(true, false, true, "raster_down_iq");
+      else rc = exact ? TILE(false, true, true, "raster_down_f32_exact") : TILE(false, false, true, "raster_down_f32");
+      if (!rc && did_down) *did_down = true;
+    } else {
+      if (!out) return TSDR_OK;  // nothing to do here; caller falls back to k_down_fused
+      if (cplx) rc = exact ? TILE(true, true, false, "raster_iq_exact") : TILE(true, false, false, "raster_iq");
+      else rc = exact ? TILE(false, true, false, "raster_f32_exact") : TILE(false, false, false, "raster_f32");
+    }
+#undef TILE
+    return rc;
+  }
+  if (!out) return TSDR_OK;
+  dim3 grid((unsigned)stream_grid(ctx, ceil_div((size_t)y_t, 64) * 64 * (size_t)x_t), (unsigned)frames);
+  if (cplx) {
+    TSDR_LAUNCH(ctx, "raster_direct_iq", (k_raster_direct<true>), grid, dim3(256), 0, in, in_stride, (unsigned)S, y_t, x_t,
+                out, out_stride);
+  } else {
+    TSDR_LAUNCH(ctx, "raster_direct_f32", (k_raster_direct<false>), grid, dim3(256), 0, in, in_stride, (unsigned)S, y_t, x_t,
+                out, out_stride);
+  }
+  return TSDR_OK;
+}
+
+int resize2d_d(tsdr_ctx *ctx, const float *img, int h_in, int w_in, int h_out, int w_out, float *out) {
+  if (h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0) return set_err(ctx, TSDR_EINVAL, "resize2d: sizes must be positive");
+  const bool same = (h_in == h_out && w_in == w_out);
+  if (!same && (h_in < 2 || w_in < 2)) return set_err(ctx, TSDR_EINVAL, "resize2d: needs at least 2x2 input");
+  TSDR_LAUNCH(ctx, "resize2d", k_resize2d, dim3(stream_grid(ctx, (size_t)h_out * w_out)), dim3(256), 0, img, h_in, w_in,
+              h_out, w_out, out);
+  return TSDR_OK;
 }
 
 struct DownPlan { bool fused; DownParams q; size_t lds; };
@@ -278,55 +544,7 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out) {
   return pl;
 }
 
-static int check_geom(tsdr_ctx *ctx, size_t S, int y_t, int x_t) {
-  if (y_t <= 0 || x_t <= 0) return set_err(ctx, TSDR_EINVAL, "y_t and x_t must be positive");
-  const size_t P = (size_t)y_t * (size_t)x_t;
-  if (S >= (size_t(1) << 31) || P >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "frame larger than 2^31 samples/pixels");
-  if (S != P && S < 2) return set_err(ctx, TSDR_EINVAL, "imresize needs at least 2 input samples");
-  return TSDR_OK;
-}
-
-// sig_to_image for `frames` consecutive frames; in is real f32 (cplx=0) or interleaved IQ (cplx=1)
-int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t,
-                    int frames, float *out, size_t out_stride) {
-  int rc = check_geom(ctx, S, y_t, x_t);
-  if (rc) return rc;
-  if (frames <= 0) return TSDR_OK;
-  const size_t P = (size_t)y_t * x_t;
-  RasterPlan pl = plan_raster(S, P);
-  if (pl.tiled) {
-    const int tiles_p = (int)ceil_div((size_t)x_t, (size_t)pl.TP), tiles_l = (int)ceil_div((size_t)y_t, 64);
-    dim3 grid((unsigned)(tiles_p * tiles_l), (unsigned)frames);
-    if (cplx) {
-      TSDR_LAUNCH(ctx, "raster_iq", (k_raster<true>), grid, dim3(256), pl.lds, in, in_stride, (unsigned)S, y_t, x_t, out,
-                  out_stride, pl.TP, pl.W, tiles_p);
-    } else {
-      TSDR_LAUNCH(ctx, "raster_f32", (k_raster<false>), grid, dim3(256), pl.lds, in, in_stride, (unsigned)S, y_t, x_t, out,
-                  out_stride, pl.TP, pl.W, tiles_p);
-    }
-  } else {
-    dim3 grid((unsigned)stream_grid(ctx, ceil_div((size_t)y_t, 64) * 64 * (size_t)x_t), (unsigned)frames);
-    if (cplx) {
-      TSDR_LAUNCH(ctx, "raster_direct_iq", (k_raster_direct<true>), grid, dim3(256), 0, in, in_stride, (unsigned)S, y_t, x_t,
-                  out, out_stride);
-    } else {
-      TSDR_LAUNCH(ctx, "raster_direct_f32", (k_raster_direct<false>), grid, dim3(256), 0, in, in_stride, (unsigned)S, y_t,
-                  x_t, out, out_stride);
-    }
-  }
-  return TSDR_OK;
-}
-
-int resize2d_d(tsdr_ctx *ctx, const float *img, int h_in, int w_in, int h_out, int w_out, float *out) {
-  if (h_in <= 0 || w_in <= 0 || h_out <= 0 || w_out <= 0) return set_err(ctx, TSDR_EINVAL, "resize2d: sizes must be positive");
-  const bool same = (h_in == h_out && w_in == w_out);
-  if (!same && (h_in < 2 || w_in < 2)) return set_err(ctx, TSDR_EINVAL, "resize2d: needs at least 2x2 input");
-  TSDR_LAUNCH(ctx, "resize2d", k_resize2d, dim3(stream_grid(ctx, (size_t)h_out * w_out)), dim3(256), 0, img, h_in, w_in,
-              h_out, w_out, out);
-  return TSDR_OK;
-}
-
-// sig_to_image |> downgradeImage for `frames` frames, straight from the signal
+// sig_to_image |> downgradeImage for `frames` frames, straight from the signal (no raster in HBM)
 int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
                   int w_out, int frames, float *out, size_t out_stride) {
   int rc = check_geom(ctx, S, y_t, x_t);
@@ -337,18 +555,19 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   if (frames <= 0) return TSDR_OK;
   // imresize returns a copy when the sizes already match: the raster IS the result
   if (same2) return raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, out, out_stride);
+  const size_t P = (size_t)y_t * x_t;
+  const bool exact = ctx->precision == TSDR_EXACT;
   DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out);
   if (pl.fused) {
+    const FastAx fa = fast_axis(S, P);
     dim3 grid((unsigned)(ceil_div((size_t)h_out, 64) * (size_t)pl.q.tiles_c), (unsigned)frames);
-    if (cplx) {
-      TSDR_LAUNCH(ctx, "down_fused_iq", (k_down_fused<true>), grid, dim3(256), pl.lds, in, in_stride, pl.q, out, out_stride);
-    } else {
-      TSDR_LAUNCH(ctx, "down_fused_f32", (k_down_fused<false>), grid, dim3(256), pl.lds, in, in_stride, pl.q, out, out_stride);
-    }
+#define DOWNK(C, E, NAME) TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, E>), grid, dim3(256), pl.lds, in, in_stride, pl.q, fa, out, out_stride)
+    if (cplx) { if (exact) { DOWNK(true, true, "down_fused_iq_exact"); } else { DOWNK(true, false, "down_fused_iq"); } }
+    else { if (exact) { DOWNK(false, true, "down_fused_f32_exact"); } else { DOWNK(false, false, "down_fused_f32"); } }
+#undef DOWNK
     return TSDR_OK;
   }
   // fallback: materialise each raster in workspace, then the generic 2-D resize
-  const size_t P = (size_t)y_t * x_t;
   float *ras = (float *)ctx->scratch(WS_RASTER, P * 4);
   if (!ras) return TSDR_ENOMEM;
   for (int f = 0; f < frames; ++f) {
@@ -358,6 +577,18 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
     if (rc) return rc;
   }
   return TSDR_OK;
+}
+
+// raster (optional) + (h_out,w_out) image for every frame with as few passes over IQ as possible
+int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
+                      int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride) {
+  if (raster) {
+    bool did = false;
+    int rc = raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, raster, raster_stride, down, down_stride, h_out,
+                             w_out, &did);
+    if (rc || did) return rc;
+  }
+  return down_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, h_out, w_out, frames, down, down_stride);
 }
 
 }  // namespace tsdr

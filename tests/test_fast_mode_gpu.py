@@ -1,0 +1,77 @@
+"""GPU parity, TSDR_FAST mode (the default): exact-rational coordinates carried in integers, one f64
+FMA per blend.
+
+Bar (north_star): image pixels within 1e-5 relative, identical frame-sync indices.  FAST is designed
+to stay within 1 ulp of the f64-faithful evaluation; the tests assert 2.5e-7 relative (2 ulp) and
+identical indices against the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+rng = np.random.default_rng(99)
+RTOL = 2.5e-7
+
+
+def relerr(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want) / np.maximum(np.abs(want), 1e-30)))
+
+
+def test_default_mode_is_fast(ctx):
+    assert ctx.precision == "fast"
+
+
+@pytest.mark.parametrize("S,y_t,x_t", [(1200, 30, 40), (137, 30, 40), (3333, 70, 130), (26001, 125, 161),
+                                       (333333, 1125, 2576), (3333333, 1125, 2576), (833333, 2250, 4400),
+                                       (800000, 100, 128), (40001, 65, 300)])
+def test_sig_to_image_fast(ctx, S, y_t, x_t):
+    sig = (0.05 + rng.random(S, dtype=np.float32))  # positive, like |IQ|
+    got, want = ctx.sig_to_image(sig, y_t, x_t), O.sig_to_image(sig, y_t, x_t)
+    assert relerr(got, want) < RTOL, relerr(got, want)
+
+
+@pytest.mark.parametrize("case", [
+    dict(Fs=1.0e6, x_t=160, y_t=125, fv=50.0, nfr=3),     # S == P copy path, upscale to 600x800 (separate kernels)
+    dict(Fs=2.0e6, x_t=1056, y_t=628, fv=60.0, nfr=3),    # fused raster+downgrade launch
+    dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, nfr=3),    # C2
+    dict(Fs=200e6, x_t=2576, y_t=1125, fv=60.0, nfr=2),   # C3 (downsampling)
+    dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, nfr=2),    # C5 (4K60 total raster)
+])
+@pytest.mark.parametrize("want_raster", [True, False])
+def test_frames_fast(ctx, tsdr, synth, case, want_raster):
+    S = synth.samples_per_frame(case["Fs"], case["fv"])
+    iq = synth.synth_leak(case["Fs"], case["x_t"], case["y_t"], case["fv"], S * case["nfr"] + 321)
+    gs = np.zeros((600, 800), np.float32, order="F")
+    os_ = np.zeros((600, 800), np.float32, order="F")
+    g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, case["y_t"], case["x_t"], np.float32(0.1), gs, want_raster=want_raster)
+    o = O.frames(O.SyncXY(600, 800), iq, S, case["y_t"], case["x_t"], np.float32(0.1), os_, want_raster=want_raster)
+    assert g["n_frames"] == o["n_frames"] == case["nfr"]
+    assert np.array_equal(g["sync_idx"], o["sync_idx"]), (g["sync_idx"].tolist(), o["sync_idx"].tolist())
+    worst = 0.0
+    for f in range(case["nfr"]):
+        if want_raster:
+            worst = max(worst, relerr(g["raster"][f], o["raster"][f]))
+        worst = max(worst, relerr(g["frames"][f], o["frames"][f]))
+    assert worst < RTOL, worst
+    assert relerr(gs, os_) < RTOL
+
+
+def test_fast_and_exact_agree_on_extreme_samples(ctx):
+    # |IQ| guard: tiny / huge / non-finite samples take the scaled path in FAST mode too
+    vals = np.array([0.0, 1e-30, 1e-22, 1e-3, 1.0, 1e18, 3e38], np.float32)
+    re, im = np.meshgrid(vals, vals)
+    z = np.tile((re.ravel() + 1j * im.ravel()).astype(np.complex64), 40)  # 1960 samples
+    st_f = np.zeros((600, 800), np.float32, order="F")
+    st_e = np.zeros((600, 800), np.float32, order="F")
+    f = ctx.frames(None, z, 980, 70, 130, np.float32(0.5), st_f, do_align=False, want_raster=True)
+    ctx.set_precision("exact")
+    try:
+        e = ctx.frames(None, z, 980, 70, 130, np.float32(0.5), st_e, do_align=False, want_raster=True)
+    finally:
+        ctx.set_precision("fast")
+    for a, b in zip(f["raster"], e["raster"]):
+        ok = np.isfinite(b) & (b > 0)
+        assert np.max(np.abs(a[ok] - b[ok]) / b[ok]) < RTOL
+        assert np.array_equal(np.isfinite(a), np.isfinite(b))

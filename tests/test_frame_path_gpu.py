@@ -1,4 +1,5 @@
-"""GPU parity, frame path: HIP (through the C ABI) vs the CPU oracle on identical inputs.
+"""GPU parity, frame path, TSDR_EXACT mode: HIP (through the C ABI) vs the CPU oracle on identical inputs.
+(TSDR_FAST, the default mode, is checked against the same oracle in test_fast_mode_gpu.py.)
 
 Bar: BIT-EXACT for everything on the frame path (demodulation, resize/raster, projections,
 beta, sync indices, IIR) -- the kernels follow the oracle's IEEE operation sequence -- except
@@ -11,6 +12,14 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 rng = np.random.default_rng(20251017)
+
+
+@pytest.fixture(autouse=True)
+def exact_mode(ctx):
+    """This module checks the EXACT arithmetic mode (bit-identical to the oracle)."""
+    ctx.set_precision("exact")
+    yield
+    ctx.set_precision("fast")
 
 
 def bits(a):
