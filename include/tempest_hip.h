@@ -65,8 +65,9 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
 /* Arithmetic of the resize/raster kernels (sig_to_image, the frame loop):
  *   TSDR_EXACT: the reference's evaluation order -- f64 source coordinate sf*i+off and f64 weights,
  *               one rounding to f32 per value; bit-identical to the CPU oracle.
- *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend, within
- *               1 ulp (1.2e-7 relative) of TSDR_EXACT; ~2.5x fewer VALU cycles.  Default.
+ *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend (within
+ *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp): pixels within ~3 ulp
+ *               (4e-7 relative) of TSDR_EXACT; ~2.5x fewer VALU cycles.  Default.
  * Both are parity-tested; everything downstream of the 600x800 image (vsync, circshift, IIR) is
  * evaluated identically in the two modes. */
 enum tsdr_precision { TSDR_EXACT = 0, TSDR_FAST = 1 };

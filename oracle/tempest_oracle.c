@@ -528,6 +528,45 @@ void orc_sync_bounds(const orc_sync *s, int *b) {
 const float *orc_sync_beta_x(const orc_sync *s) { return s->beta_x; }
 const float *orc_sync_beta_y(const orc_sync *s) { return s->beta_y; }
 
+/* ---- summation orders ---------------------------------------------------------------
+ * The reference calls sum(image;dims=1), sum(image;dims=2) and sum(c_v) (FrameSynchronisation.jl
+ * :61,:71,:96).  Julia evaluates these with @simd / pairwise reductions whose association order
+ * depends on the machine's vector width, so no order is "the" reference order; any fixed order is
+ * an equally faithful restatement (they differ at the 1e-7 relative level).  The orders below are
+ * fixed once, documented, and reproduced operation for operation by the GPU kernels:
+ *   sum64(x,n): lane m (0..63) accumulates x[m], x[m+64], ... in ascending order starting from
+ *               0.0f; the 64 partials are folded by the tree v[i] += v[i+off], off = 32,16,..,1.
+ *   rows:       the n columns are cut into 8 chunks of ceil(n/8); each chunk is accumulated in
+ *               ascending order from 0.0f and the chunks are added left to right. */
+static float tree64(float *v) {
+  for (int off = 32; off > 0; off >>= 1)
+    for (int i = 0; i < off; i++) v[i] = v[i] + v[i + off];
+  return v[0];
+}
+static float sum64(const float *x, int n) {
+  float p[64];
+  for (int m = 0; m < 64; m++) {
+    float a = 0.0f;
+    for (int i = m; i < n; i += 64) a += x[i];
+    p[m] = a;
+  }
+  return tree64(p);
+}
+/* c_v[c] = sum of column c (y rows) ; c_h[r] = sum of row r (x columns); image column-major */
+static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
+  for (int c = 0; c < x; c++) cv[c] = sum64(img + (size_t)c * y, y);
+  const int chunk = (x + 7) / 8;
+  for (int r = 0; r < y; r++) {
+    float tot = 0.0f;
+    for (int j = 0; j < 8; j++) {
+      float a = 0.0f;
+      for (int c = j * chunk; c < (j + 1) * chunk && c < x; c++) a += img[(size_t)c * y + r];
+      tot = j == 0 ? a : tot + a;
+    }
+    ch[r] = tot;
+  }
+}
+
 /* DSP.filt(h,x) [RECALLED]: causal FIR, zero initial state, same length;
  * transposed direct form, plain f32 multiply-add. */
 static void fir_filt(const float *h, int nh, const float *x, int n, float *y) {
@@ -549,8 +588,7 @@ static inline int mod_index0(int k1, int n) { int m = (k1 - 1) % n; if (m < 0) m
  * (w_max-w_min+1) x n column-major. */
 void orc_fill_beta(float *beta, const float *cv, int n, int w_min, int w_max) {
   int W = w_max - w_min + 1;
-  float S = 0.0f;
-  for (int i = 0; i < n; i++) S += cv[i]; /* sum(c_v) */
+  const float S = sum64(cv, n); /* sum(c_v), order: see "summation orders" */
   for (int c = 1; c <= n; c++) {
     /* averagePixel(c_v,c,w_min-1,n): Int 0 accumulator promoted to f32 */
     float acc = 0.0f;
@@ -588,19 +626,15 @@ int orc_vsync(orc_sync *s, const float *img, int *s_y, int *s_x) {
   float *cv = (float *)malloc(sizeof(float) * (size_t)(x > y ? x : y));
   float *cf = (float *)malloc(sizeof(float) * (size_t)(x > y ? x : y));
   if (!cv || !cf) { free(cv); free(cf); return ORC_ENOMEM; }
-  for (int c = 0; c < x; c++) { /* sum(image;dims=1) */
-    float a = 0.0f;
-    for (int r = 0; r < y; r++) a += img[(size_t)c * y + r];
-    cv[c] = a;
-  }
+  float *ch = (float *)malloc(sizeof(float) * (size_t)y);
+  if (!ch) { free(cv); free(cf); return ORC_ENOMEM; }
+  project_sums(img, y, x, cv, ch); /* sum(image;dims=1) and sum(image;dims=2) */
   fir_filt(s->h, 5, cv, x, cf);
   orc_fill_beta(s->beta_x, cf, x, s->wmin_x, s->wmax_x);
   *s_y = argmax_col(s->beta_y, 1 + s->wmax_y - s->wmin_y, y); /* stale */
-  for (int r = 0; r < y; r++) cv[r] = 0.0f; /* sum(image;dims=2) */
-  for (int c = 0; c < x; c++)
-    for (int r = 0; r < y; r++) cv[r] += img[(size_t)c * y + r];
-  fir_filt(s->h, 5, cv, y, cf);
+  fir_filt(s->h, 5, ch, y, cf);
   orc_fill_beta(s->beta_y, cf, y, s->wmin_y, s->wmax_y);
+  free(ch);
   *s_x = argmax_col(s->beta_x, 1 + s->wmax_x - s->wmin_x, x);
   free(cv); free(cf);
   return ORC_OK;
@@ -609,14 +643,12 @@ int orc_vsync(orc_sync *s, const float *img, int *s_y, int *s_x) {
 /* projections + FIR only (test aid for the GPU projection kernel) */
 int orc_project(const orc_sync *s, const float *img, float *cv_f, float *ch_f) {
   int y = s->y_t, x = s->x_t;
-  float *t = (float *)malloc(sizeof(float) * (size_t)(x > y ? x : y));
-  if (!t) return ORC_ENOMEM;
-  for (int c = 0; c < x; c++) { float a = 0; for (int r = 0; r < y; r++) a += img[(size_t)c * y + r]; t[c] = a; }
-  fir_filt(s->h, 5, t, x, cv_f);
-  for (int r = 0; r < y; r++) t[r] = 0;
-  for (int c = 0; c < x; c++) for (int r = 0; r < y; r++) t[r] += img[(size_t)c * y + r];
-  fir_filt(s->h, 5, t, y, ch_f);
-  free(t);
+  float *tv = (float *)malloc(sizeof(float) * (size_t)x), *th = (float *)malloc(sizeof(float) * (size_t)y);
+  if (!tv || !th) { free(tv); free(th); return ORC_ENOMEM; }
+  project_sums(img, y, x, tv, th);
+  fir_filt(s->h, 5, tv, x, cv_f);
+  fir_filt(s->h, 5, th, y, ch_f);
+  free(tv); free(th);
   return ORC_OK;
 }
 

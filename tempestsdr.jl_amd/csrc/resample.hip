@@ -23,6 +23,8 @@
 // ordered so that the tiles stacked over one pixel strip run back to back on ONE XCD: the 256-byte segments of
 // vertically adjacent tiles share 128-byte lines, which then merge in that XCD's L2 instead of reaching HBM as
 // two partial writes.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace tsdr {
@@ -32,8 +34,8 @@ template <bool EXACT>
 __device__ inline float abs_iq(float re, float im) {
   if (EXACT) return abs_c(re, im);
   const float m = fmaf(re, re, im * im);
-  if (m > 1e-30f && m < 1e30f) return sqrtf(m);  // correctly rounded f32 sqrt; <= 1 ulp overall
-  return abs_c(re, im);                           // tiny / huge / non-finite: the scaled f64 form
+  if (m > 1e-30f && m < 1e30f) return __builtin_amdgcn_sqrtf(m);  // v_sqrt_f32 (1 ulp); <= 1.5 ulp overall
+  return abs_c(re, im);                                            // tiny / huge / non-finite: the f64 form
 }
 
 template <bool CPLX, bool EXACT>
@@ -97,22 +99,48 @@ struct TileParams {
   int own_l, own_p;     // owned lines / pixels per tile (64/TP, or 63/TP-1 with DOWN)
   int h_out, w_out;     // DOWN only
   int NR, NC;           // DOWN: candidate output rows / columns per tile
+  int lpl_log;          // log2(lanes per line) of the staging loop
 };
+
+// FAST pixel walk of one lane along its line: (k, r) advance by integer adds; every staged sample holds
+// {a, (b - a)/D} in f64, so a pixel is cvt(r) -> fma -> cvt.  CLAMP handles x0 < 0 (first pixels of a frame).
+template <bool CLAMP, bool DOWN, bool OUT>
+__device__ inline void fast_walk(const FastAx &fa, const double2 *__restrict__ row, int kf, int k, unsigned r, int npx,
+                                 float *__restrict__ o, size_t ostride, float *__restrict__ trow) {
+#pragma unroll 2
+  for (int i = 0; i < npx; ++i) {
+    const int j = (CLAMP ? max(k, 0) : k) - kf;
+    const double2 s = row[j];
+    const unsigned re = CLAMP ? (k < 0 ? 0u : r) : r;
+    const float v = (float)fma((double)re, s.y, s.x);
+    if (OUT) { if (!CLAMP || o) { *o = v; o += ostride; } }
+    if (DOWN) { *trow = v; trow += 65; }
+    const unsigned r2 = r + fa.rstep;
+    const bool c = r2 >= fa.D;
+    k += (int)fa.qstep + (c ? 1 : 0);
+    r = c ? r2 - fa.D : r2;
+  }
+}
 
 template <bool CPLX, bool EXACT, bool DOWN>
 __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ in, size_t in_stride, TileParams q,
                                                      FastAx fa, float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
-  extern __shared__ float lds[];
+  extern __shared__ double lds_d[];
   const int Wp = q.W | 1;
-  float *smp = lds;                                        // [64][Wp] staged samples
-  int *kfirst = reinterpret_cast<int *>(smp + 64 * Wp);    // [64]
-  float *tile = reinterpret_cast<float *>(kfirst + 64);    // DOWN: [TP][65] raster values (pixel-major)
-  // candidate tables (DOWN): rows then columns
-  int *rk = reinterpret_cast<int *>(tile + (DOWN ? q.TP * 65 : 0));
-  int *ck = rk + (DOWN ? q.NR : 0);
-  double *rd = reinterpret_cast<double *>(ck + (DOWN ? q.NC + ((q.NR + q.NC) & 1) : 0));
+  // staged samples: EXACT [64][Wp] f32 ; FAST [64][Wp] {a, (b-a)/D} f64 pairs
+  float *smp = reinterpret_cast<float *>(lds_d);
+  double2 *smp2 = reinterpret_cast<double2 *>(lds_d);
+  char *after = reinterpret_cast<char *>(lds_d) + (size_t)64 * Wp * (EXACT ? 4 : 16);
+  after += (16 - ((size_t)after & 15)) & 15;
+  // candidate tables (DOWN): doubles first (alignment), then ints, then the raster tile
+  double *rd = reinterpret_cast<double *>(after);
   double *cd = rd + (DOWN ? q.NR : 0);
+  int *kfirst = reinterpret_cast<int *>(cd + (DOWN ? q.NC : 0));  // [64]
+  int *vinfo = kfirst + 64;                                         // DOWN: {first valid row cand, #rows, first col cand, #cols}
+  int *rk = vinfo + 4;
+  int *ck = rk + (DOWN ? q.NR : 0);
+  float *tile = reinterpret_cast<float *>(ck + (DOWN ? q.NC : 0));  // DOWN: [TP][65] raster values (pixel-major)
 
   // XCD-aware order: unit u = (frame, pixel strip); all tiles_l tiles of a unit are consecutive slots of one XCD
   const unsigned b = blockIdx.x;
@@ -136,9 +164,11 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
     else { unsigned r; fast_pos(fa, flat, k, r); k = max(k, 0); }
     kfirst[tid] = k;
   }
+  if (DOWN && tid < 4) vinfo[tid] = (tid & 1) ? 0 : 0x7fffffff;
+  if (DOWN) __syncthreads();
   if (DOWN) {
     // candidate output rows/columns whose top-left tap may fall in this tile (monotone maps -> contiguous);
-    // k = -1 marks "not owned by this tile"
+    // -1 marks "not owned by this tile"
     const RsAxis ay = rs_axis((size_t)q.y_t, (size_t)q.h_out), axx = rs_axis((size_t)q.x_t, (size_t)q.w_out);
     if (tid < q.NR) {
       const int rbase = max(0, (int)floor(((double)l0 + 0.5) / ay.sf - 0.5) - 1);
@@ -149,8 +179,9 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
         const bool last = (tl == q.tiles_l - 1);
         if (k < l0 || (!last && k >= l0 + q.own_l)) k = -1;
       }
-      rk[tid] = k < 0 ? -1 : ((r << 8) | (k - l0));  // row index and local line (local line < 64)
+      rk[tid] = k < 0 ? -1 : ((r << 8) | (k - l0));  // row index and local line (< 64)
       rd[tid] = d;
+      if (k >= 0) { atomicMin(&vinfo[0], tid); atomicAdd(&vinfo[1], 1); }
     }
     const int t2 = tid - 64;
     if (t2 >= 0 && t2 < q.NC) {
@@ -162,91 +193,112 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
         const bool last = (tp == q.tiles_p - 1);
         if (k < p0 || (!last && k >= p0 + q.own_p)) k = -1;
       }
-      ck[t2] = k < 0 ? -1 : ((c << 8) | (k - p0));   // column index and local pixel (local pixel < 128)
+      ck[t2] = k < 0 ? -1 : ((c << 8) | (k - p0));   // column index and local pixel (< 128)
       cd[t2] = d;
+      if (k >= 0) { atomicMin(&vinfo[2], t2); atomicAdd(&vinfo[3], 1); }
     }
   }
   __syncthreads();
-  {  // stage: 16 lanes per line -> 128-byte runs of IQ
-    const int sub = tid >> 4, j0 = tid & 15;
-    for (int r = sub; r < 64; r += 16) {
+  {  // stage: 2^lpl_log lanes per line (chosen on the host to waste the fewest lane slots); the loads of
+     // up to four samples are issued back to back before any |IQ| math, so their latencies overlap
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
+    for (int r = sub; r < 64; r += nsub) {
       const unsigned kf = (unsigned)kfirst[r];
-      for (int j = j0; j < q.W; j += 16) {
-        const unsigned k = min(kf + (unsigned)j, q.S - 1u);
-        smp[r * Wp + j] = load_sample<CPLX, EXACT>(src, k);
+      for (int jb = j0; jb < q.W; jb += 4 * lpl) {
+        float re[4], im[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + u * lpl;
+          const unsigned k = min(kf + (unsigned)min(j, q.W - 1), q.S - 1u);
+          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
+          else { re[u] = src[k]; im[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + u * lpl;
+          if (j < q.W) {
+            const float a = CPLX ? abs_iq<EXACT>(re[u], im[u]) : re[u];
+            if (EXACT) smp[r * Wp + j] = a;
+            else smp2[r * Wp + j].x = (double)a;
+          }
+        }
       }
     }
   }
   __syncthreads();
+  if (!EXACT) {  // second pass: slope towards the next sample, pre-divided by D
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
+    for (int r = sub; r < 64; r += nsub)
+      for (int j = j0; j + 1 < q.W; j += lpl)
+        smp2[r * Wp + j].y = (smp2[r * Wp + j + 1].x - smp2[r * Wp + j].x) * fa.invDd;
+    __syncthreads();
+  }
   {
     const int wave = tid >> 6, lane = tid & 63;
     const int l = l0 + lane;
     const int pw = q.TP >> 2;
     const int pbeg = p0 + wave * pw, pend = min(pbeg + pw, q.x_t);
-    const bool line_ok = l < q.y_t;
-    // a line/pixel is stored by the tile that owns it (the halo line/pixel of a DOWN tile belongs to the next tile)
-    const bool store_line = line_ok && (lane < q.own_l || tl == q.tiles_l - 1);
-    const int pstore_end = (tp == q.tiles_p - 1) ? q.x_t : min(p0 + q.own_p, q.x_t);
-    const int kf = kfirst[lane];
-    const float *row = smp + lane * Wp;
-    float *o = out ? out + (size_t)f * out_stride + (size_t)(line_ok ? l : 0) : nullptr;
-    const unsigned flat0 = (unsigned)(line_ok ? l : q.y_t - 1) * (unsigned)q.x_t;
-    if (EXACT) {
-      const unsigned base = flat0 + 1u;
-      for (int p = pbeg; p < pend; ++p) {
-        double d;
-        const int j = (int)rs_pos(ax, (double)(base + (unsigned)p), d) - kf;
-        const float a = row[j], bb = row[j + 1];
-        const float v = same ? (d == 1.0 ? bb : a) : rs_blend(a, bb, d);
-        if (o && store_line && p < pstore_end) o[(size_t)p * q.y_t] = v;
-        if (DOWN) tile[(p - p0) * 65 + lane] = v;
-      }
-    } else {
-      int k; unsigned r;
-      fast_pos(fa, flat0 + (unsigned)pbeg, k, r);
-      for (int p = pbeg; p < pend; ++p) {
-        const int j = max(k, 0) - kf;
-        const float a = row[j], bb = row[j + 1];
-        const double d = k < 0 ? 0.0 : (double)r * fa.invDd;
-        const float v = fast_blend(a, bb, d);
-        if (o && store_line && p < pstore_end) o[(size_t)p * q.y_t] = v;
-        if (DOWN) tile[(p - p0) * 65 + lane] = v;
-        fast_step(fa, k, r);
+    // Overlapping (halo) lines/pixels of DOWN tiles are written by both neighbours: the values are
+    // bit-identical (same flat index, exact integer walk), so the duplicate store is benign and the loop
+    // needs no per-pixel predicate.  Lines past the frame are masked once, here.
+    if (l < q.y_t && pbeg < pend) {
+      const int kf = kfirst[lane];
+      float *o = out ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
+      float *trow = DOWN ? tile + (pbeg - p0) * 65 + lane : nullptr;
+      const unsigned flat0 = (unsigned)l * (unsigned)q.x_t + (unsigned)pbeg;
+      if (EXACT) {
+        const float *row = smp + lane * Wp;
+        for (int p = pbeg; p < pend; ++p) {
+          double d;
+          const int j = (int)rs_pos(ax, (double)(flat0 + (unsigned)(p - pbeg) + 1u), d) - kf;
+          const float a = row[j], bb = row[j + 1];
+          const float v = same ? (d == 1.0 ? bb : a) : rs_blend(a, bb, d);
+          if (o) { *o = v; o += q.y_t; }
+          if (DOWN) { *trow = v; trow += 65; }
+        }
+      } else {
+        const double2 *row = smp2 + lane * Wp;
+        int k; unsigned r;
+        fast_pos(fa, flat0, k, r);
+        // x0 < 0 only for the very first pixels of a frame: a tile-uniform test picks the clamping walk
+        const long long num0 = (long long)(2ull * ((unsigned long long)l0 * q.x_t + p0) + 1ull) * (long long)fa.S - (long long)fa.P;
+        if (num0 < 0) fast_walk<true, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+        else if (o) fast_walk<false, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+        else fast_walk<false, DOWN, false>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
       }
     }
   }
   if (!DOWN) return;
   __syncthreads();
   {
-    // output pixels: waves stride the candidate columns, lanes are candidate rows (NR <= 2*64)
-    const int wave = tid >> 6, lane = tid & 63;
+    // output pixels owned by this tile: the valid candidates are contiguous (monotone maps), so the
+    // nvr x nvc grid is walked flat by all 256 threads, rows fastest (coalesced stores)
     float *dn = down + (size_t)f * down_stride;
-    for (int rr = lane; rr < q.NR; rr += 64) {
-      const int rkv = rk[rr];
-      if (rkv < 0) continue;
-      const int r = rkv >> 8, ly = rkv & 255;
-      const double dy = rd[rr];
-      for (int cc = wave; cc < q.NC; cc += 4) {
-        const int ckv = ck[cc];
-        if (ckv < 0) continue;
-        const int c = ckv >> 8, lx = ckv & 255;
-        const float *t0 = tile + lx * 65 + ly;
-        const float R00 = t0[0], R10 = t0[1], R01 = t0[65], R11 = t0[66];
-        float v;
-        if (EXACT) {
-          const double dx = cd[cc];
-          const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
-          const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
-          const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
-          v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
-        } else {
-          const double dx = cd[cc];
-          const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
-          const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
-          v = (float)fma(dy, bot - top, top);
-        }
-        dn[(size_t)c * q.h_out + r] = v;
+    const int rfirst = vinfo[0], nvr = vinfo[1], cfirst = vinfo[2], nvc = vinfo[3];
+    const int total = nvr * nvc;
+    const float inv = nvr > 0 ? 1.0f / (float)nvr : 0.0f;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int ci = (int)(((float)idx + 0.5f) * inv);  // idx / nvr, exact for idx < 2^16
+      const int ri = idx - ci * nvr;
+      const int rkv = rk[rfirst + ri], ckv = ck[cfirst + ci];
+      const int r = rkv >> 8, ly = rkv & 255, c = ckv >> 8, lx = ckv & 255;
+      const double dy = rd[rfirst + ri], dx = cd[cfirst + ci];
+      const float *t0 = tile + lx * 65 + ly;
+      const float R00 = t0[0], R10 = t0[1], R01 = t0[65], R11 = t0[66];
+      float v;
+      if (EXACT) {
+        const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
+        const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
+        const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
+        v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
+      } else {
+        const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
+        const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
+        v = (float)fma(dy, bot - top, top);
       }
+      dn[(size_t)c * q.h_out + r] = v;
     }
   }
 }
@@ -458,28 +510,41 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   const double sf = (double)S / (double)P;
   const bool exact = ctx->precision == TSDR_EXACT || P >= (size_t(1) << 30);
   // fused downgrade in the raster launch: only when both axes shrink (<= 66 x 130 candidates per tile)
-  const bool want_down = down && !(y_t == h_out && x_t == w_out) && y_t >= 2 * 64 && x_t >= 2 * 128 &&
+  const bool want_down = down && !getenv("TSDR_NO_FUSED_DOWN") && !(y_t == h_out && x_t == w_out) && y_t >= 2 * 64 && x_t >= 2 * 128 &&
                          (double)y_t / h_out >= 1.0 && (double)x_t / w_out >= 1.0;
   TileParams q{};
   q.S = (unsigned)S; q.y_t = y_t; q.x_t = x_t; q.frames = frames;
   bool tiled = false;
-  for (int TP = 128; TP >= 4; TP >>= 1) {
+  // 64-pixel tiles when the downgrade is fused in: the raster tile kept in LDS then costs 16.6 KiB instead of
+  // 33 KiB, which doubles the resident workgroups per CU (measured: 0.18 ms vs 0.24 ms per C2 buffer)
+  int tp_max = want_down ? 64 : 128;
+  if (const char *e = getenv("TSDR_TILE_TP")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) tp_max = v; }
+  // staged-sample budget: <= 24 KiB of LDS per tile (EXACT 4 B/sample, FAST 16 B/sample)
+  const long w_cap = exact ? 191 : 24 * 1024 / (64 * 16) - 1;
+  for (int TP = tp_max; TP >= 4; TP >>= 1) {
     const long W = (long)((double)(TP - 1) * sf) + 4;
-    if (W <= 191) { tiled = true; q.TP = TP; q.W = (int)W; break; }
+    if (W <= w_cap) { tiled = true; q.TP = TP; q.W = (int)W; break; }
   }
   if (tiled) {
-    const bool dn = want_down && q.TP == 128;
+    const bool dn = want_down && q.TP >= 32;
     q.own_l = dn ? 63 : 64;
     q.own_p = dn ? q.TP - 1 : q.TP;
     q.tiles_l = dn ? (y_t - 2) / 63 + 1 : (int)ceil_div((size_t)y_t, 64);
     q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
-    size_t lds = (size_t)64 * (size_t)(q.W | 1) * 4 + 64 * 4;
+    // staging lanes per line: the power of two that wastes the fewest lane slots for this W
+    int best = 0; long best_slots = 1L << 60;
+    for (int lg = 2; lg <= 6; ++lg) {
+      const long lpl = 1L << lg, slots = (long)ceil_div((size_t)q.W, (size_t)lpl) * lpl;
+      if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
+    }
+    q.lpl_log = best;
+    size_t lds = (size_t)64 * (size_t)(q.W | 1) * (exact ? 4 : 16) + 16 + 64 * 4 + 16;
     if (dn) {
       q.h_out = h_out; q.w_out = w_out;
       q.NR = (int)ceil(64.0 / ((double)y_t / h_out)) + 4;
       q.NC = (int)ceil((double)q.TP / ((double)x_t / w_out)) + 4;
       if (q.NR > 128 || q.NC > 192) return set_err(ctx, TSDR_EINVAL, "raster: candidate table overflow");
-      lds += (size_t)q.TP * 65 * 4 + (size_t)(q.NR + q.NC + 1) * 4 + (size_t)(q.NR + q.NC) * 8 + 8;
+      lds += (size_t)q.TP * 65 * 4 + (size_t)(q.NR + q.NC + 4) * 4 + (size_t)(q.NR + q.NC) * 8;
     }
     const FastAx fa = fast_axis(S, P);
 #define TILE(C, E, D, NAME) launch_tile<C, E, D>(ctx, NAME, in, in_stride, q, fa, lds, out, out_stride, down, down_stride)

@@ -5,18 +5,23 @@
 //   init_gaussian_filter(5)      :124-129
 //   circshift + IIR              GUI.jl:172,175
 //
-// The arithmetic follows the oracle's evaluation ORDER, not only its formulas, so that for the
-// same image the projections, beta values and therefore the argmax indices are bit-identical:
-//   * column / row sums accumulate sequentially in f32 (one lane per column / row),
+// The arithmetic follows the oracle's evaluation ORDER, not only its formulas, so that for the same image
+// the projections, beta values and therefore the argmax indices are bit-identical:
+//   * sum64 order for column sums and for Sigma = sum(c_v): lane m accumulates elements m, m+64, ... in
+//     ascending order from 0.0f, then the 64 partials fold through the xor-butterfly 32,16,..,1
+//     (= the oracle's tree64); row sums are 8 column chunks, each accumulated in order, added left to right
+//     (Julia's own sum() order is SIMD-width dependent, so no order is "the" reference's; this one is fixed,
+//     documented in the oracle, and wavefront-shaped),
 //   * the 5-tap causal FIR uses the transposed-direct-form association
 //       y[i] = ((((h4 x[i-4]) + h3 x[i-3]) + h2 x[i-2]) + h1 x[i-1]) + h0 x[i],
-//   * Sigma = sum(c_v) is one sequential f32 chain,
 //   * each centre's running blank sum _Sigma is the reference's sequential recurrence over w.
-// Parallelism comes from frames x centres (one lane per centre, 64 centres per wavefront);
-// the argmax over (w,c) is a lane-local scan, a 64-wide shuffle reduction and one 64-bit
-// atomicMax per wavefront on a packed key (beta bits << 32 | ~c): beta >= +0 so its bit
-// pattern is order-preserving, NaN patterns sort above +Inf (Julia's findmax treats NaN as
-// maximal), and ~c makes the smallest column win ties = first maximum in column-major order.
+// Launches per buffer: k_proj (all sums of all frames) and k_beta (FIR + Sigma + beta scan + argmax).
+// In k_beta four lanes share one blank-band centre: each replays the cheap running-sum prefix (adds only,
+// same order => same bits) and evaluates a quarter of the widths (the two divisions per width are the cost).
+// The argmax over (w,c) is a lane-local scan, a 64-wide shuffle reduction and one 64-bit atomicMax per
+// wavefront on a packed key (beta bits << 32 | ~c): beta >= +0 so its bit pattern is order-preserving, NaN
+// patterns sort above +Inf (Julia's findmax treats NaN as maximal), and ~c makes the smallest column win
+// ties = first maximum in column-major order.
 #include "common.h"
 
 struct tsdr_sync {
@@ -26,7 +31,8 @@ struct tsdr_sync {
   float h[5];
   float *beta_x = nullptr;  // device, (1+wmax_x-wmin_x) x x_t
   float *beta_y = nullptr;  // device, (1+wmax_y-wmin_y) x y_t
-  int *pending = nullptr;   // device: [0] = s_y the next vsync call will return (argmax of beta_y)
+  int *pending = nullptr;   // device: [cur] = s_y the next vsync call will return (argmax of beta_y); double-buffered
+  int cur = 0;
 };
 
 namespace tsdr {
@@ -36,69 +42,63 @@ struct SyncGeom {
   float h0, h1, h2, h3, h4;
 };
 
-// ---- projections: raw sums --------------------------------------------------------------
-// proj layout per frame: [ cv_raw (x_t) | ch_raw (y_t) | cv_f (x_t) | ch_f (y_t) | Sigma_x | Sigma_y | pad ]
-__host__ __device__ inline size_t proj_stride(int y_t, int x_t) { return (size_t)2 * (x_t + y_t) + 4; }
+// proj layout per frame: [ cv_raw (x_t) | ch_raw (y_t) ]
+__host__ __device__ inline size_t proj_stride(int y_t, int x_t) { return (size_t)(x_t + y_t); }
 
-// grid.x = ceil(x_t/64) + ceil(y_t/64) wavefront-sized blocks, grid.y = frames
-__global__ __launch_bounds__(64) void k_sums(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                             float *__restrict__ proj) {
+__device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+off], off = 32..1 ; result in lane 0
+  for (int off = 32; off > 0; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---- projections -------------------------------------------------------------------------------------
+// grid.x = ceil(x_t/4) column blocks (one wavefront per column) + ceil(y_t/32) row blocks (32 rows x 8 chunks),
+// grid.y = frames; block 0 of each frame also zeroes the frame's two argmax keys.
+__global__ __launch_bounds__(256) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
+                                              float *__restrict__ proj, unsigned long long *__restrict__ keys) {
+  __shared__ float part[8][32];
   const int f = blockIdx.y;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride(y_t, x_t);
-  const int nbx = (x_t + 63) >> 6;
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x < nbx) {
-    // sum(image;dims=1): one lane per column, rows in order
-    const int c = blockIdx.x * 64 + lane;
+  const int ncb = (x_t + 3) >> 2;
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid < 2) keys[(size_t)f * 2 + tid] = 0ull;
+  if ((int)blockIdx.x < ncb) {
+    // sum(image;dims=1): sum64 order, one wavefront per column
+    const int c = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
     if (c >= x_t) return;
     const float *col = im + (size_t)c * y_t;
     float a = 0.0f;
-    int r = 0;
-    if ((((uintptr_t)col) & 15) == 0) {
-      for (; r + 4 <= y_t; r += 4) {
-        float4 v = *reinterpret_cast<const float4 *>(col + r);
-        a = __fadd_rn(a, v.x); a = __fadd_rn(a, v.y); a = __fadd_rn(a, v.z); a = __fadd_rn(a, v.w);
-      }
-    }
-    for (; r < y_t; ++r) a = __fadd_rn(a, col[r]);
-    pr[c] = a;
+    for (int r = lane; r < y_t; r += 64) a = __fadd_rn(a, col[r]);
+    a = wave_tree64(a);
+    if (lane == 0) pr[c] = a;
   } else {
-    // sum(image;dims=2): one lane per row, columns in order (coalesced across lanes)
-    const int r = (blockIdx.x - nbx) * 64 + lane;
-    if (r >= y_t) return;
+    // sum(image;dims=2): 8 chunks of ceil(x_t/8) columns, each in order, then left to right
+    const int rl = tid & 31, j = tid >> 5;
+    const int r = ((int)blockIdx.x - ncb) * 32 + rl;
+    const int chunk = (x_t + 7) >> 3;
     float a = 0.0f;
-    const float *p = im + r;
-#pragma unroll 8
-    for (int c = 0; c < x_t; ++c) a = __fadd_rn(a, p[(size_t)c * y_t]);
-    pr[x_t + r] = a;
-  }
-}
-
-// ---- FIR + Sigma; also zeroes the argmax keys.  grid = (2, frames), 256 threads ----------
-__global__ __launch_bounds__(256) void k_fir(float *__restrict__ proj, SyncGeom g,
-                                             unsigned long long *__restrict__ keys) {
-  extern __shared__ float s[];
-  const int f = blockIdx.y, axis = blockIdx.x;  // 0: x (columns, c_v), 1: y (rows, c_h)
-  const int n = axis == 0 ? g.x_t : g.y_t;
-  float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
-  const float *raw = pr + (axis == 0 ? 0 : g.x_t);
-  float *flt = pr + (g.x_t + g.y_t) + (axis == 0 ? 0 : g.x_t);
-  for (int i = threadIdx.x; i < n; i += 256) {
-    float acc = __fmul_rn(g.h4, i >= 4 ? raw[i - 4] : 0.0f);
-    acc = __fadd_rn(acc, __fmul_rn(g.h3, i >= 3 ? raw[i - 3] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h2, i >= 2 ? raw[i - 2] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h1, i >= 1 ? raw[i - 1] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h0, raw[i]));
-    s[i] = acc;
-    flt[i] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float S = 0.0f;
-    for (int i = 0; i < n; ++i) S = __fadd_rn(S, s[i]);
-    pr[2 * (g.x_t + g.y_t) + axis] = S;
-    keys[(size_t)f * 2 + axis] = 0ull;
+    if (r < y_t) {
+      const int c0 = j * chunk, c1 = min(c0 + chunk, x_t);
+      const float *p = im + r + (size_t)c0 * y_t;
+      int c = c0;
+      // latency-bound: issue 16 independent loads, then fold them in order
+      for (; c + 16 <= c1; c += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(size_t)u * y_t];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a = __fadd_rn(a, v[u]);
+        p += (size_t)16 * y_t;
+      }
+      for (; c < c1; ++c) { a = __fadd_rn(a, *p); p += y_t; }
+    }
+    part[j][rl] = a;
+    __syncthreads();
+    if (j == 0 && r < y_t) {
+      float tot = part[0][rl];
+      for (int jj = 1; jj < 8; ++jj) tot = __fadd_rn(tot, part[jj][rl]);
+      pr[x_t + r] = tot;
+    }
   }
 }
 
@@ -107,59 +107,82 @@ __device__ inline unsigned long long pack_key(float v, int c) {
   return ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c);
 }
 
-// ---- beta search: one lane per centre.  grid.x = ceil(x_t/64)+ceil(y_t/64), grid.y = frames --
-// write_frame: frame whose beta matrices are materialised into bx/by (-1: none)
+// FIR of the raw projection into LDS (cv[0..n)), and Sigma in sum64 order (returned to every lane)
+__device__ inline float fir_and_sigma(const float *__restrict__ raw, int n, const SyncGeom &g, float *cv, int lane) {
+  for (int i = lane; i < n; i += 64) {
+    float acc = __fmul_rn(g.h4, i >= 4 ? raw[i - 4] : 0.0f);
+    acc = __fadd_rn(acc, __fmul_rn(g.h3, i >= 3 ? raw[i - 3] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h2, i >= 2 ? raw[i - 2] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h1, i >= 1 ? raw[i - 1] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h0, raw[i]));
+    cv[i] = acc;
+  }
+  __syncthreads();
+  float a = 0.0f;
+  for (int i = lane; i < n; i += 64) a = __fadd_rn(a, cv[i]);
+  a = wave_tree64(a);
+  return __shfl(a, 0, 64);
+}
+
+// beta of one centre over widths [wa, wb] after replaying the running sum up to wa-1; returns the first
+// maximum of that range (NaN maximal); writes beta values when bout != nullptr
+__device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int wa, int wb, float S, float *bout) {
+  float acc = 0.0f;
+  int k = (c0 - (w_min - 1)) % n; if (k < 0) k += n;
+  for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) { acc = __fadd_rn(acc, cv[k]); if (++k == n) k = 0; }
+  float s = __fmul_rn(2.0f, acc);
+  int lo = (c0 - w_min) % n; if (lo < 0) lo += n;
+  int hi = (c0 + w_min) % n;
+  for (int w = w_min; w < wa; ++w) {  // prefix replay: adds only
+    s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
+    s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
+    if (--lo < 0) lo = n - 1;
+    if (++hi == n) hi = 0;
+  }
+  float bv = 0.0f;
+  bool have = false;
+  for (int w = wa; w <= wb; ++w) {
+    s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
+    s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
+    float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
+    v = __fmul_rn(v, v);
+    if (bout) bout[w - w_min] = v;
+    if (!have) { bv = v; have = true; }
+    else if (!(bv != bv) && (v != v || v > bv)) bv = v;
+    if (--lo < 0) lo = n - 1;
+    if (++hi == n) hi = 0;
+  }
+  return have ? bv : -1.0f;  // empty range: below every beta
+}
+
+// ---- FIR + Sigma + beta scan + argmax.  One wavefront = 16 centres x 4 width-quarters.
+// grid.x = ceil(x_t/16) + ceil(y_t/16), grid.y = frames.  write_frame: frame whose beta matrices are stored.
 __global__ __launch_bounds__(64) void k_beta(const float *__restrict__ proj, SyncGeom g,
                                              unsigned long long *__restrict__ keys, int write_frame,
                                              float *__restrict__ bx, float *__restrict__ by) {
   extern __shared__ float cv[];
   const int f = blockIdx.y;
-  const int nbx = (g.x_t + 63) >> 6;
+  const int nbx = (g.x_t + 15) >> 4;
   const int axis = (int)blockIdx.x < nbx ? 0 : 1;
   const int n = axis == 0 ? g.x_t : g.y_t;
   const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
-  const float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
-  const float *flt = pr + (g.x_t + g.y_t) + (axis == 0 ? 0 : g.x_t);
-  const float S = pr[2 * (g.x_t + g.y_t) + axis];
-  for (int i = threadIdx.x; i < n; i += 64) cv[i] = flt[i];
-  __syncthreads();
-  const int c0 = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64 + threadIdx.x;  // 0-based centre
+  const float *raw = proj + (size_t)f * proj_stride(g.y_t, g.x_t) + (axis == 0 ? 0 : g.x_t);
+  const int lane = threadIdx.x;
+  const float S = fir_and_sigma(raw, n, g, cv, lane);
+  const int c0 = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 16 + (lane >> 2);  // 0-based centre
+  const int qd = lane & 3;
+  const int W = w_max - w_min + 1, Wq = (W + 3) >> 2;
   unsigned long long key = 0ull;
   if (c0 < n) {
-    const int W = w_max - w_min + 1;
+    const int wa = w_min + qd * Wq, wb = min(wa + Wq - 1, w_max);
     float *bout = (f == write_frame) ? (axis == 0 ? bx : by) + (size_t)c0 * W : nullptr;
-    // averagePixel(c_v,c,w_min-1,n): sequential, circular
-    float acc = 0.0f;
-    int k = c0 - (w_min - 1);
-    k %= n; if (k < 0) k += n;
-    for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) {
-      acc = __fadd_rn(acc, cv[k]);
-      if (++k == n) k = 0;
-    }
-    float s = __fmul_rn(2.0f, acc);
-    int lo = c0 - w_min, hi = c0 + w_min;
-    lo %= n; if (lo < 0) lo += n;
-    hi %= n;
-    float bv = -1.0f;  // below any beta (>= +0); first comparison always takes the first value
-    bool have = false;
-    for (int w = w_min; w <= w_max; ++w) {
-      s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
-      s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
-      float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
-      v = __fmul_rn(v, v);
-      if (bout) bout[w - w_min] = v;
-      if (!have) { bv = v; have = true; }
-      else if (!(bv != bv) && (v != v || v > bv)) bv = v;
-      if (--lo < 0) lo = n - 1;
-      if (++hi == n) hi = 0;
-    }
-    key = pack_key(bv, c0);
+    if (wa <= wb) key = pack_key(beta_scan(cv, n, c0, w_min, wa, wb, S, bout), c0);
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  if (threadIdx.x == 0) atomicMax(&keys[(size_t)f * 2 + axis], key);
+  if (lane == 0) atomicMax(&keys[(size_t)f * 2 + axis], key);
 }
 
 __device__ inline int key_col1(unsigned long long key) {  // 1-based column of the packed argmax
@@ -167,14 +190,25 @@ __device__ inline int key_col1(unsigned long long key) {  // 1-based column of t
 }
 
 // ---- shift + IIR over the frames of one buffer (GUI.jl:172,175) ----------------------------
-// For frame f: s_x = argmax beta_x(f); s_y = argmax beta_y(f-1) (pending[0] for f = 0).
+// For frame f: s_x = argmax beta_x(f); s_y = argmax beta_y(f-1) (pend_in[0] for f = 0).
 // out = alpha*out + (1-alpha)*img_shifted, f32, two products and one sum (no FMA).
+// Block 0 also publishes (s_y,s_x) per frame and the s_y the NEXT call starts with (pend_out; the two
+// pending slots alternate between calls, so no block can read a value this launch has overwritten).
 __global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img, size_t img_stride, int h, int w,
                                                    int frames, const unsigned long long *__restrict__ keys,
-                                                   const int *__restrict__ pending, int do_align, float alpha,
+                                                   const int *__restrict__ pend_in, int *__restrict__ pend_out,
+                                                   int *__restrict__ sync_idx, int do_align, float alpha,
                                                    float *__restrict__ state, float *__restrict__ frames_out) {
   const size_t npx = (size_t)h * w;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (do_align && blockIdx.x == 0 && threadIdx.x == 0) {
+    int sy = pend_in[0];
+    for (int f = 0; f < frames; ++f) {
+      if (sync_idx) { sync_idx[2 * f] = sy; sync_idx[2 * f + 1] = key_col1(keys[(size_t)f * 2 + 0]); }
+      sy = key_col1(keys[(size_t)f * 2 + 1]);
+    }
+    pend_out[0] = sy;
+  }
   if (idx >= npx) return;
   const int i = (int)(idx % (size_t)h), j = (int)(idx / (size_t)h);
   float acc = state[idx];
@@ -182,7 +216,7 @@ __global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img
   for (int f = 0; f < frames; ++f) {
     size_t src = idx;
     if (do_align) {
-      const int sy = f == 0 ? pending[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
+      const int sy = f == 0 ? pend_in[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
       const int sx = key_col1(keys[(size_t)f * 2 + 0]);
       int si = i + sy; si %= h;
       int sj = j + sx; sj %= w;
@@ -195,16 +229,12 @@ __global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img
   state[idx] = acc;
 }
 
-// after k_shift_iir: publish (s_y,s_x) per frame and roll the pending s_y forward
-__global__ void k_publish(const unsigned long long *__restrict__ keys, int frames, int *__restrict__ pending,
-                          int *__restrict__ sync_idx) {
+// standalone vsync: publish (s_y,s_x) of one scanned image and roll the pending s_y
+__global__ void k_publish(const unsigned long long *__restrict__ keys, const int *__restrict__ pend_in,
+                          int *__restrict__ pend_out, int *__restrict__ s_yx) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int sy = pending[0];
-  for (int f = 0; f < frames; ++f) {
-    if (sync_idx) { sync_idx[2 * f] = sy; sync_idx[2 * f + 1] = key_col1(keys[(size_t)f * 2 + 0]); }
-    sy = key_col1(keys[(size_t)f * 2 + 1]);
-  }
-  pending[0] = sy;
+  if (s_yx) { s_yx[0] = pend_in[0]; s_yx[1] = key_col1(keys[0]); }
+  pend_out[0] = key_col1(keys[1]);
 }
 
 __global__ __launch_bounds__(256) void k_circshift(const float *__restrict__ in, int h, int w, int s_y, int s_x,
@@ -218,37 +248,20 @@ __global__ __launch_bounds__(256) void k_circshift(const float *__restrict__ in,
   out[idx] = in[(size_t)sj * h + si];
 }
 
-// standalone fill_beta!: beta (W x n) from an already filtered projection
+// standalone fill_beta!: beta (W x n) from an already filtered projection (one lane per centre)
 __global__ __launch_bounds__(64) void k_fill_beta(const float *__restrict__ cvin, int n, int w_min, int w_max,
                                                   float *__restrict__ beta) {
   extern __shared__ float cv[];
-  for (int i = threadIdx.x; i < n; i += 64) cv[i] = cvin[i];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n; i += 64) cv[i] = cvin[i];
   __syncthreads();
-  __shared__ float Ssh;
-  if (threadIdx.x == 0) {
-    float S = 0.0f;
-    for (int i = 0; i < n; ++i) S = __fadd_rn(S, cv[i]);
-    Ssh = S;
-  }
-  __syncthreads();
-  const float S = Ssh;
-  const int c0 = blockIdx.x * 64 + threadIdx.x;
+  float a = 0.0f;
+  for (int i = lane; i < n; i += 64) a = __fadd_rn(a, cv[i]);
+  const float S = __shfl(wave_tree64(a), 0, 64);
+  const int c0 = blockIdx.x * 64 + lane;
   if (c0 >= n) return;
   const int W = w_max - w_min + 1;
-  float acc = 0.0f;
-  int k = (c0 - (w_min - 1)) % n; if (k < 0) k += n;
-  for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) { acc = __fadd_rn(acc, cv[k]); if (++k == n) k = 0; }
-  float s = __fmul_rn(2.0f, acc);
-  int lo = (c0 - w_min) % n; if (lo < 0) lo += n;
-  int hi = (c0 + w_min) % n;
-  for (int w = w_min; w <= w_max; ++w) {
-    s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
-    s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
-    float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
-    beta[(size_t)c0 * W + (w - w_min)] = __fmul_rn(v, v);
-    if (--lo < 0) lo = n - 1;
-    if (++hi == n) hi = 0;
-  }
+  (void)beta_scan(cv, n, c0, w_min, w_min, w_max, S, beta + (size_t)c0 * W);
 }
 
 static SyncGeom geom_of(const tsdr_sync *s) {
@@ -269,11 +282,11 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   unsigned long long *keys = *keys_out ? *keys_out : (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
   if (!proj || !keys) return TSDR_ENOMEM;
   const SyncGeom g = geom_of(s);
-  const unsigned nb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
-  TSDR_LAUNCH(ctx, "sync_sums", k_sums, dim3(nb, (unsigned)frames), dim3(64), 0, img, img_stride, y, x, proj);
+  const unsigned npb = (unsigned)(ceil_div((size_t)x, 4) + ceil_div((size_t)y, 32));
+  TSDR_LAUNCH(ctx, "sync_proj", k_proj, dim3(npb, (unsigned)frames), dim3(256), 0, img, img_stride, y, x, proj, keys);
   const size_t nmax = (size_t)(x > y ? x : y);
-  TSDR_LAUNCH(ctx, "sync_fir", k_fir, dim3(2, (unsigned)frames), dim3(256), nmax * 4, proj, g, keys);
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nb, (unsigned)frames), dim3(64), nmax * 4, (const float *)proj, g, keys,
+  const unsigned nbb = (unsigned)(ceil_div((size_t)x, 16) + ceil_div((size_t)y, 16));
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nbb, (unsigned)frames), dim3(64), nmax * 4, (const float *)proj, g, keys,
               frames - 1, s->beta_x, s->beta_y);
   *keys_out = keys;
   return TSDR_OK;
@@ -283,9 +296,11 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx) {
   const size_t npx = (size_t)h * w;
+  const int *pin = do_align ? s->pending + s->cur : nullptr;
+  int *pout = do_align ? s->pending + (s->cur ^ 1) : nullptr;
   TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, img, img_stride, h, w,
-              frames, keys, do_align ? (const int *)s->pending : (const int *)nullptr, do_align, alpha, state, frames_out);
-  if (do_align) TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, keys, frames, s->pending, sync_idx);
+              frames, keys, pin, pout, sync_idx, do_align, alpha, state, frames_out);
+  if (do_align) s->cur ^= 1;
   return TSDR_OK;
 }
 
@@ -327,7 +342,8 @@ int tsdr_sync_reset(tsdr_sync *s) {
   const size_t nbx = (size_t)(1 + s->wmax_x - s->wmin_x) * s->x_t, nby = (size_t)(1 + s->wmax_y - s->wmin_y) * s->y_t;
   TSDR_HIP(ctx, hipMemsetAsync(s->beta_x, 0, nbx * 4, ctx->stream));
   TSDR_HIP(ctx, hipMemsetAsync(s->beta_y, 0, nby * 4, ctx->stream));
-  const int one[4] = {1, 0, 0, 0};  // findmax of an all-zero beta_y is index (1,1)
+  const int one[4] = {1, 1, 0, 0};  // findmax of an all-zero beta_y is index (1,1)
+  s->cur = 0;
   TSDR_HIP(ctx, hipMemcpyAsync(s->pending, one, 16, hipMemcpyHostToDevice, ctx->stream));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TSDR_OK;
@@ -354,8 +370,9 @@ int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   unsigned long long *keys = nullptr;
   int rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, &keys);
   if (rc) return rc;
-  TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys, 1, s->pending,
-              s_yx_dev);
+  TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
+              (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);
+  s->cur ^= 1;
   return TSDR_OK;
 }
 

@@ -104,6 +104,8 @@ WORKLOADS = {
     "C2": dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, acquisition=0.5),   # 1080p60 @ 20 MS/s
     "C3": dict(Fs=200e6, x_t=2576, y_t=1125, fv=60.0, acquisition=0.5),  # 10x oversampled
     "C5": dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, acquisition=0.5),   # 4K60 (not in the reference table)
+    # experiment only: column height a multiple of 32 floats, so every 256-byte store segment is line-aligned
+    "C2A": dict(Fs=20e6, x_t=2576, y_t=1152, fv=60.0, acquisition=0.5),
 }
 
 

@@ -2,8 +2,8 @@
 FMA per blend.
 
 Bar (north_star): image pixels within 1e-5 relative, identical frame-sync indices.  FAST is designed
-to stay within 1 ulp of the f64-faithful evaluation; the tests assert 2.5e-7 relative (2 ulp) and
-identical indices against the CPU oracle."""
+so that each blend stays within 1 ulp of the f64-faithful evaluation and |IQ| within 1.5 ulp (hardware
+v_sqrt_f32); the tests assert 4e-7 relative (about 3 ulp) and identical indices against the CPU oracle."""
 import numpy as np
 import pytest
 
@@ -11,7 +11,7 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 rng = np.random.default_rng(99)
-RTOL = 2.5e-7
+RTOL = 4e-7
 
 
 def relerr(got, want):
