@@ -54,6 +54,10 @@ struct tsdr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
+  hipStream_t launch_stream = nullptr;  // stream TSDR_LAUNCH targets (== stream except inside the chunk pipeline)
+  hipStream_t side_stream = nullptr;    // lazily created: vsync/IIR of finished frame chunks
+  hipEvent_t chunk_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t side_done = nullptr;
   std::string err;
   int cu_count = 0;
   int precision = TSDR_FAST;  // tsdr_precision
@@ -91,7 +95,7 @@ void prof_end(tsdr_ctx *ctx);
 #define TSDR_LAUNCH(ctx, kname, kernel, grid, block, shmem, ...)                              \
   do {                                                                                        \
     if ((ctx)->prof_on) tsdr::prof_begin((ctx), kname);                                       \
-    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);               \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->launch_stream, __VA_ARGS__);               \
     if ((ctx)->prof_on) tsdr::prof_end((ctx));                                                \
     hipError_t _le = hipGetLastError();                                                       \
     if (_le != hipSuccess) return tsdr::hip_fail((ctx), _le, kname);                          \

@@ -38,16 +38,17 @@ void prof_begin(tsdr_ctx *ctx, const char *name) {
   r.name = name;
   r.e0 = take_event(ctx);
   r.e1 = take_event(ctx);
-  (void)hipEventRecord(r.e0, ctx->stream);
+  (void)hipEventRecord(r.e0, ctx->launch_stream);
   ctx->prof.push_back(r);
 }
 
-void prof_end(tsdr_ctx *ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->stream); }
+void prof_end(tsdr_ctx *ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->launch_stream); }
 
 // fold finished event pairs into the per-kernel aggregate
 static int prof_collect(tsdr_ctx *ctx) {
   if (ctx->prof.empty()) return TSDR_OK;
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->side_stream) TSDR_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
   for (auto &r : ctx->prof) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -115,6 +116,7 @@ tsdr_ctx *tsdr_create(int device) {
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   ctx->own_stream = true;
+  ctx->launch_stream = ctx->stream;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   (void)hipEventCreate(&ctx->t0);
@@ -134,6 +136,9 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
   for (auto &kv : ctx->blu) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.bfft); }
+  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  for (auto e : ctx->chunk_ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -149,6 +154,7 @@ int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream) {
     TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     ctx->own_stream = true;
   }
+  ctx->launch_stream = ctx->stream;
   return TSDR_OK;
 }
 

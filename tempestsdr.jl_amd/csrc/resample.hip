@@ -107,18 +107,21 @@ struct TileParams {
 template <bool CLAMP, bool DOWN, bool OUT>
 __device__ inline void fast_walk(const FastAx &fa, const double2 *__restrict__ row, int kf, int k, unsigned r, int npx,
                                  float *__restrict__ o, size_t ostride, float *__restrict__ trow) {
+  // software pipeline: the LDS read of pixel i+1 is issued before pixel i is blended and stored
+  double2 s = row[(CLAMP ? max(k, 0) : k) - kf];
+  unsigned re = CLAMP ? (k < 0 ? 0u : r) : r;
 #pragma unroll 2
   for (int i = 0; i < npx; ++i) {
-    const int j = (CLAMP ? max(k, 0) : k) - kf;
-    const double2 s = row[j];
-    const unsigned re = CLAMP ? (k < 0 ? 0u : r) : r;
-    const float v = (float)fma((double)re, s.y, s.x);
-    if (OUT) { if (!CLAMP || o) { *o = v; o += ostride; } }
-    if (DOWN) { *trow = v; trow += 65; }
     const unsigned r2 = r + fa.rstep;
     const bool c = r2 >= fa.D;
     k += (int)fa.qstep + (c ? 1 : 0);
     r = c ? r2 - fa.D : r2;
+    const double2 sn = row[(CLAMP ? max(k, 0) : k) - kf];   // next pixel's {a, slope}; in range by the W bound
+    const float v = (float)fma((double)re, s.y, s.x);
+    if (OUT) { if (!CLAMP || o) { *o = v; o += ostride; } }
+    if (DOWN) { *trow = v; trow += 65; }
+    s = sn;
+    re = CLAMP ? (k < 0 ? 0u : r) : r;
   }
 }
 
@@ -164,38 +167,45 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
     else { unsigned r; fast_pos(fa, flat, k, r); k = max(k, 0); }
     kfirst[tid] = k;
   }
-  if (DOWN && tid < 4) vinfo[tid] = (tid & 1) ? 0 : 0x7fffffff;
-  if (DOWN) __syncthreads();
   if (DOWN) {
     // candidate output rows/columns whose top-left tap may fall in this tile (monotone maps -> contiguous);
     // -1 marks "not owned by this tile"
     const RsAxis ay = rs_axis((size_t)q.y_t, (size_t)q.h_out), axx = rs_axis((size_t)q.x_t, (size_t)q.w_out);
-    if (tid < q.NR) {
+    // wave 0 builds the row table (two rounds when NR > 64), wave 1 the column table; the valid entries of
+    // each are contiguous, so one ballot per round yields first index and count
+    const int wv = tid >> 6, ln = tid & 63;
+    if (wv == 0) {
       const int rbase = max(0, (int)floor(((double)l0 + 0.5) / ay.sf - 0.5) - 1);
-      const int r = rbase + tid;
-      int k = -1; double d = 0.0;
-      if (r < q.h_out) {
-        k = (int)rs_pos(ay, (double)(r + 1), d);
-        const bool last = (tl == q.tiles_l - 1);
-        if (k < l0 || (!last && k >= l0 + q.own_l)) k = -1;
+      const bool last = (tl == q.tiles_l - 1);
+      int first = 0x7fffffff, count = 0;
+      for (int base = 0; base < q.NR; base += 64) {
+        const int t = base + ln, r = rbase + t;
+        int k = -1; double d = 0.0;
+        if (t < q.NR && r < q.h_out) {
+          k = (int)rs_pos(ay, (double)(r + 1), d);
+          if (k < l0 || (!last && k >= l0 + q.own_l)) k = -1;
+        }
+        if (t < q.NR) { rk[t] = k < 0 ? -1 : ((r << 8) | (k - l0)); rd[t] = d; }  // row index, local line (< 64)
+        const unsigned long long m = __ballot(k >= 0);
+        if (m) { first = min(first, base + (int)__builtin_ctzll(m)); count += (int)__builtin_popcountll(m); }
       }
-      rk[tid] = k < 0 ? -1 : ((r << 8) | (k - l0));  // row index and local line (< 64)
-      rd[tid] = d;
-      if (k >= 0) { atomicMin(&vinfo[0], tid); atomicAdd(&vinfo[1], 1); }
-    }
-    const int t2 = tid - 64;
-    if (t2 >= 0 && t2 < q.NC) {
+      if (ln == 0) { vinfo[0] = first; vinfo[1] = count; }
+    } else if (wv == 1) {
       const int cbase = max(0, (int)floor(((double)p0 + 0.5) / axx.sf - 0.5) - 1);
-      const int c = cbase + t2;
-      int k = -1; double d = 0.0;
-      if (c < q.w_out) {
-        k = (int)rs_pos(axx, (double)(c + 1), d);
-        const bool last = (tp == q.tiles_p - 1);
-        if (k < p0 || (!last && k >= p0 + q.own_p)) k = -1;
+      const bool last = (tp == q.tiles_p - 1);
+      int first = 0x7fffffff, count = 0;
+      for (int base = 0; base < q.NC; base += 64) {
+        const int t = base + ln, c = cbase + t;
+        int k = -1; double d = 0.0;
+        if (t < q.NC && c < q.w_out) {
+          k = (int)rs_pos(axx, (double)(c + 1), d);
+          if (k < p0 || (!last && k >= p0 + q.own_p)) k = -1;
+        }
+        if (t < q.NC) { ck[t] = k < 0 ? -1 : ((c << 8) | (k - p0)); cd[t] = d; }  // column index, local pixel (< 128)
+        const unsigned long long m = __ballot(k >= 0);
+        if (m) { first = min(first, base + (int)__builtin_ctzll(m)); count += (int)__builtin_popcountll(m); }
       }
-      ck[t2] = k < 0 ? -1 : ((c << 8) | (k - p0));   // column index and local pixel (< 128)
-      cd[t2] = d;
-      if (k >= 0) { atomicMin(&vinfo[2], t2); atomicAdd(&vinfo[3], 1); }
+      if (ln == 0) { vinfo[2] = first; vinfo[3] = count; }
     }
   }
   __syncthreads();
@@ -519,8 +529,9 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   // 33 KiB, which doubles the resident workgroups per CU (measured: 0.18 ms vs 0.24 ms per C2 buffer)
   int tp_max = want_down ? 64 : 128;
   if (const char *e = getenv("TSDR_TILE_TP")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) tp_max = v; }
-  // staged-sample budget: <= 24 KiB of LDS per tile (EXACT 4 B/sample, FAST 16 B/sample)
-  const long w_cap = exact ? 191 : 24 * 1024 / (64 * 16) - 1;
+  // staged-sample budget per tile: EXACT 4 B/sample (<= 48 KiB), FAST 16 B/sample (<= 47 samples per line = 47 KiB;
+  // only down-sampling ratios get near it, up-sampling tiles stage ~11-18 samples per line)
+  const long w_cap = exact ? 191 : 47;
   for (int TP = tp_max; TP >= 4; TP >>= 1) {
     const long W = (long)((double)(TP - 1) * sf) + 4;
     if (W <= w_cap) { tiled = true; q.TP = TP; q.W = (int)W; break; }

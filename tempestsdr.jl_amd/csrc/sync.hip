@@ -68,7 +68,22 @@ __global__ __launch_bounds__(256) void k_proj(const float *__restrict__ img, siz
     if (c >= x_t) return;
     const float *col = im + (size_t)c * y_t;
     float a = 0.0f;
-    for (int r = lane; r < y_t; r += 64) a = __fadd_rn(a, col[r]);
+    int r = lane;
+    // latency-bound: issue eight independent 256-byte row-block loads, then fold them in order
+    for (; r + 7 * 64 < y_t; r += 8 * 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[r + u * 64];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a = __fadd_rn(a, v[u]);
+    }
+    {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (r + u * 64 < y_t) ? col[r + u * 64] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (r + u * 64 < y_t) a = __fadd_rn(a, v[u]);
+    }
     a = wave_tree64(a);
     if (lane == 0) pr[c] = a;
   } else {
@@ -274,10 +289,14 @@ static SyncGeom geom_of(const tsdr_sync *s) {
 
 // vsync statistics for `frames` images already on the device: fills keys[2*frames]
 // (x then y per frame); beta matrices of the LAST frame are materialised into the sync state.
-int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long **keys_out) {
+// proj_offset (floats): where this call's projections live inside WS_PROJ; the chunk pipeline pre-sizes the
+// workspace for the whole buffer and hands every chunk its own slice
+int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long **keys_out,
+                size_t proj_offset) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
-  float *proj = (float *)ctx->scratch(WS_PROJ, (size_t)frames * proj_stride(y, x) * 4);
+  float *proj = (float *)ctx->scratch(WS_PROJ, (proj_offset + (size_t)frames * proj_stride(y, x)) * 4);
+  if (proj) proj += proj_offset;
   // *keys_out != nullptr: caller-provided key buffer (2 per frame); else workspace
   unsigned long long *keys = *keys_out ? *keys_out : (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
   if (!proj || !keys) return TSDR_ENOMEM;
@@ -368,7 +387,7 @@ int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   if (!s || !img) return TSDR_EINVAL;
   tsdr_ctx *ctx = s->ctx;
   unsigned long long *keys = nullptr;
-  int rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, &keys);
+  int rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, &keys, 0);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
               (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);
