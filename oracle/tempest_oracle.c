@@ -536,6 +536,9 @@ const float *orc_sync_beta_y(const orc_sync *s) { return s->beta_y; }
  * fixed once, documented, and reproduced operation for operation by the GPU kernels:
  *   sum64(x,n): lane m (0..63) accumulates x[m], x[m+64], ... in ascending order starting from
  *               0.0f; the 64 partials are folded by the tree v[i] += v[i+off], off = 32,16,..,1.
+ *               Used for Sigma = sum(c_v).
+ *   columns:    rows are cut into blocks of 64; each block is accumulated in ascending order
+ *               from 0.0f and the block sums are added top to bottom (first block first).
  *   rows:       the n columns are cut into 8 chunks of ceil(n/8); each chunk is accumulated in
  *               ascending order from 0.0f and the chunks are added left to right. */
 static float tree64(float *v) {
@@ -554,7 +557,16 @@ static float sum64(const float *x, int n) {
 }
 /* c_v[c] = sum of column c (y rows) ; c_h[r] = sum of row r (x columns); image column-major */
 static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
-  for (int c = 0; c < x; c++) cv[c] = sum64(img + (size_t)c * y, y);
+  for (int c = 0; c < x; c++) {
+    const float *col = img + (size_t)c * y;
+    float tot = 0.0f;
+    for (int r0 = 0; r0 < y; r0 += 64) {
+      float a = 0.0f;
+      for (int r = r0; r < r0 + 64 && r < y; r++) a += col[r];
+      tot = r0 == 0 ? a : tot + a;
+    }
+    cv[c] = tot;
+  }
   const int chunk = (x + 7) / 8;
   for (int r = 0; r < y; r++) {
     float tot = 0.0f;

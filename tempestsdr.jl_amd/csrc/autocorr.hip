@@ -12,6 +12,7 @@
 // Multi-GPU: tsdr_autocorr_partial_d computes the partial sum over a range of m on one
 // GPU as a zero-padded cross-correlation of the segment with segment+halo; ranks all-reduce the
 // partial vectors (linear domain) and only then apply 10log10(abs2) via tsdr_autocorr_finish_d.
+#include <algorithm>
 #include <cmath>
 
 #include "common.h"
@@ -143,7 +144,15 @@ __global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, siz
     const unsigned long long o = __shfl_xor(best, off, 64);
     best = o > best ? o : best;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(key, best);
+  // one atomic per workgroup (thousands of wavefronts on one 64-bit word serialise at ~12 ns each)
+  __shared__ unsigned long long wbest[4];
+  if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long b = wbest[0];
+    for (int i = 1; i < 4; ++i) b = wbest[i] > b ? wbest[i] : b;
+    atomicMax(key, b);
+  }
 }
 
 static inline double jl_round(double v) { return nearbyint(v); }  // Julia round(): ties to even
@@ -267,7 +276,8 @@ int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *v
   unsigned long long *key = (unsigned long long *)ctx->scratch(WS_MISC, 16);
   if (!key) return TSDR_ENOMEM;
   TSDR_HIP(ctx, hipMemsetAsync(key, 0, 8, ctx->stream));
-  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(stream_grid(ctx, n)), dim3(256), 0, v, n, key);
+  const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
+  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key);
   unsigned long long h = 0;
   TSDR_HIP(ctx, hipMemcpyAsync(&h, key, 8, hipMemcpyDeviceToHost, ctx->stream));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));

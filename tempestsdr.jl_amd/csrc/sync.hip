@@ -7,21 +7,26 @@
 //
 // The arithmetic follows the oracle's evaluation ORDER, not only its formulas, so that for the same image
 // the projections, beta values and therefore the argmax indices are bit-identical:
-//   * sum64 order for column sums and for Sigma = sum(c_v): lane m accumulates elements m, m+64, ... in
-//     ascending order from 0.0f, then the 64 partials fold through the xor-butterfly 32,16,..,1
-//     (= the oracle's tree64); row sums are 8 column chunks, each accumulated in order, added left to right
-//     (Julia's own sum() order is SIMD-width dependent, so no order is "the" reference's; this one is fixed,
-//     documented in the oracle, and wavefront-shaped),
+//   * column sums: 64-row blocks, each accumulated in order, block sums added top to bottom; row sums: 8 column
+//     chunks, each accumulated in order, added left to right; Sigma = sum(c_v) in sum64 order (lane m
+//     accumulates elements m, m+64, ..., then the xor-butterfly 32,16,..,1 = the oracle's tree64).
+//     Julia's own sum() order is SIMD-width dependent, so no order is "the" reference's; these are fixed,
+//     documented in the oracle, and shaped so that ONE pass over the image yields every partial sum,
 //   * the 5-tap causal FIR uses the transposed-direct-form association
 //       y[i] = ((((h4 x[i-4]) + h3 x[i-3]) + h2 x[i-2]) + h1 x[i-1]) + h0 x[i],
 //   * each centre's running blank sum _Sigma is the reference's sequential recurrence over w.
-// Launches per buffer: k_proj (all sums of all frames) and k_beta (FIR + Sigma + beta scan + argmax).
-// In k_beta four lanes share one blank-band centre: each replays the cheap running-sum prefix (adds only,
-// same order => same bits) and evaluates a quarter of the widths (the two divisions per width are the cost).
+// Launches per buffer: k_proj (one pass over every image: per-(row block, chunk) partial sums) and k_beta
+// (fold partials -> FIR -> Sigma -> beta scan -> argmax).  In k_beta four lanes share one blank-band centre:
+// each replays the cheap running-sum prefix (adds only, same order => same bits) and evaluates a quarter of the
+// widths.  The two divisions per width are by small integers: they use a table of correctly rounded
+// reciprocals and Markstein's two-FMA correction, which returns the correctly rounded quotient (bit-identical
+// to IEEE division) at a third of the instruction count.
 // The argmax over (w,c) is a lane-local scan, a 64-wide shuffle reduction and one 64-bit atomicMax per
 // wavefront on a packed key (beta bits << 32 | ~c): beta >= +0 so its bit pattern is order-preserving, NaN
 // patterns sort above +Inf (Julia's findmax treats NaN as maximal), and ~c makes the smallest column win
 // ties = first maximum in column-major order.
+#include <algorithm>
+
 #include "common.h"
 
 struct tsdr_sync {
@@ -42,78 +47,51 @@ struct SyncGeom {
   float h0, h1, h2, h3, h4;
 };
 
-// proj layout per frame: [ cv_raw (x_t) | ch_raw (y_t) ]
-__host__ __device__ inline size_t proj_stride(int y_t, int x_t) { return (size_t)(x_t + y_t); }
+// proj layout per frame: colpart[nrb][x_t] (64-row block sums of every column) | rowpart[8][y_t] (chunk sums of
+// every row); nrb = ceil(y_t/64)
+__host__ __device__ inline size_t proj_stride(int y_t, int x_t) { return (size_t)((y_t + 63) >> 6) * x_t + (size_t)8 * y_t; }
 
 __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+off], off = 32..1 ; result in lane 0
   for (int off = 32; off > 0; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
   return v;
 }
 
-// ---- projections -------------------------------------------------------------------------------------
-// grid.x = ceil(x_t/4) column blocks (one wavefront per column) + ceil(y_t/32) row blocks (32 rows x 8 chunks),
-// grid.y = frames; block 0 of each frame also zeroes the frame's two argmax keys.
-__global__ __launch_bounds__(256) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                              float *__restrict__ proj, unsigned long long *__restrict__ keys) {
-  __shared__ float part[8][32];
+// ---- projections: ONE pass over the image ---------------------------------------------------------------
+// One wavefront per (64-row block, column chunk): lanes are rows.  Each lane folds its row across the chunk's
+// columns in order (-> rowpart[chunk][row]) while the values go through an LDS tile; then lanes become columns
+// and fold the tile's 64 rows in order (-> colpart[block][column]).  grid = (8 * nrb, frames).
+__global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
+                                             float *__restrict__ proj, unsigned long long *__restrict__ keys) {
+  extern __shared__ float tile[];  // [64][chunk | 1]
   const int f = blockIdx.y;
+  const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3, pitch = chunk | 1;
+  const int rb = blockIdx.x % nrb, j = blockIdx.x / nrb;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride(y_t, x_t);
-  const int ncb = (x_t + 3) >> 2;
-  const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && tid < 2) keys[(size_t)f * 2 + tid] = 0ull;
-  if ((int)blockIdx.x < ncb) {
-    // sum(image;dims=1): sum64 order, one wavefront per column
-    const int c = blockIdx.x * 4 + (tid >> 6), lane = tid & 63;
-    if (c >= x_t) return;
-    const float *col = im + (size_t)c * y_t;
-    float a = 0.0f;
-    int r = lane;
-    // latency-bound: issue eight independent 256-byte row-block loads, then fold them in order
-    for (; r + 7 * 64 < y_t; r += 8 * 64) {
-      float v[8];
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane < 2) keys[(size_t)f * 2 + lane] = 0ull;
+  const int r = rb * 64 + lane;
+  const bool rv = r < y_t;
+  const int c0 = j * chunk, c1 = min(c0 + chunk, x_t);
+  const float *p = im + (rv ? r : 0) + (size_t)c0 * y_t;
+  float a = 0.0f;
+  int c = c0;
+  for (; c + 16 <= c1; c += 16) {  // 16 independent coalesced loads in flight, folded in order
+    float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = col[r + u * 64];
+    for (int u = 0; u < 16; ++u) v[u] = p[(size_t)u * y_t];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a = __fadd_rn(a, v[u]);
-    }
-    {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = (r + u * 64 < y_t) ? col[r + u * 64] : 0.0f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) if (r + u * 64 < y_t) a = __fadd_rn(a, v[u]);
-    }
-    a = wave_tree64(a);
-    if (lane == 0) pr[c] = a;
-  } else {
-    // sum(image;dims=2): 8 chunks of ceil(x_t/8) columns, each in order, then left to right
-    const int rl = tid & 31, j = tid >> 5;
-    const int r = ((int)blockIdx.x - ncb) * 32 + rl;
-    const int chunk = (x_t + 7) >> 3;
-    float a = 0.0f;
-    if (r < y_t) {
-      const int c0 = j * chunk, c1 = min(c0 + chunk, x_t);
-      const float *p = im + r + (size_t)c0 * y_t;
-      int c = c0;
-      // latency-bound: issue 16 independent loads, then fold them in order
-      for (; c + 16 <= c1; c += 16) {
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(size_t)u * y_t];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) a = __fadd_rn(a, v[u]);
-        p += (size_t)16 * y_t;
-      }
-      for (; c < c1; ++c) { a = __fadd_rn(a, *p); p += y_t; }
-    }
-    part[j][rl] = a;
-    __syncthreads();
-    if (j == 0 && r < y_t) {
-      float tot = part[0][rl];
-      for (int jj = 1; jj < 8; ++jj) tot = __fadd_rn(tot, part[jj][rl]);
-      pr[x_t + r] = tot;
-    }
+    for (int u = 0; u < 16; ++u) { a = __fadd_rn(a, v[u]); tile[lane * pitch + (c - c0) + u] = v[u]; }
+    p += (size_t)16 * y_t;
+  }
+  for (; c < c1; ++c) { const float v = *p; a = __fadd_rn(a, v); tile[lane * pitch + (c - c0)] = v; p += y_t; }
+  if (rv) pr[(size_t)nrb * x_t + (size_t)j * y_t + r] = a;
+  __syncthreads();
+  const int nval = min(64, y_t - rb * 64);
+  for (int cl = lane; cl < c1 - c0; cl += 64) {
+    float t = 0.0f;
+    for (int rr = 0; rr < nval; ++rr) t = __fadd_rn(t, tile[rr * pitch + cl]);
+    pr[(size_t)rb * x_t + c0 + cl] = t;
   }
 }
 
@@ -122,26 +100,21 @@ __device__ inline unsigned long long pack_key(float v, int c) {
   return ((unsigned long long)bits << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c);
 }
 
-// FIR of the raw projection into LDS (cv[0..n)), and Sigma in sum64 order (returned to every lane)
-__device__ inline float fir_and_sigma(const float *__restrict__ raw, int n, const SyncGeom &g, float *cv, int lane) {
-  for (int i = lane; i < n; i += 64) {
-    float acc = __fmul_rn(g.h4, i >= 4 ? raw[i - 4] : 0.0f);
-    acc = __fadd_rn(acc, __fmul_rn(g.h3, i >= 3 ? raw[i - 3] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h2, i >= 2 ? raw[i - 2] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h1, i >= 1 ? raw[i - 1] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h0, raw[i]));
-    cv[i] = acc;
-  }
-  __syncthreads();
-  float a = 0.0f;
-  for (int i = lane; i < n; i += 64) a = __fadd_rn(a, cv[i]);
-  a = wave_tree64(a);
-  return __shfl(a, 0, 64);
+// x / d for a small positive integer d, given rd = RN(1/d): Markstein's correction returns RN(x/d) exactly
+// (q = RN(x*rd) is within 1 ulp, the residual x - q*d is exact in one FMA, RN(q + res*rd) is the correctly
+// rounded quotient).  Outside the safely normal range the IEEE division runs instead.
+__device__ inline float div_small(float x, float d, float rd) {
+  const float ax = fabsf(x);
+  if (!(ax > 1e-30f && ax < 1e30f)) return __fdiv_rn(x, d);
+  const float q = __fmul_rn(x, rd);
+  const float res = __fmaf_rn(-q, d, x);
+  return __fmaf_rn(res, rd, q);
 }
 
 // beta of one centre over widths [wa, wb] after replaying the running sum up to wa-1; returns the first
-// maximum of that range (NaN maximal); writes beta values when bout != nullptr
-__device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int wa, int wb, float S, float *bout) {
+// maximum of that range (NaN maximal); writes beta values when bout != nullptr.  rtab == nullptr: IEEE division.
+__device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int wa, int wb, float S, float *bout,
+                                  const float2 *rtab) {
   float acc = 0.0f;
   int k = (c0 - (w_min - 1)) % n; if (k < 0) k += n;
   for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) { acc = __fadd_rn(acc, cv[k]); if (++k == n) k = 0; }
@@ -159,7 +132,14 @@ __device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int
   for (int w = wa; w <= wb; ++w) {
     s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
     s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
-    float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
+    const float d1 = (float)(2 * (n - w)), d2 = (float)(2 * w);
+    float v;
+    if (rtab) {
+      const float2 rr = rtab[w - w_min];
+      v = __fadd_rn(div_small(__fsub_rn(S, s), d1, rr.x), div_small(s, d2, rr.y));
+    } else {
+      v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), d1), __fdiv_rn(s, d2));
+    }
     v = __fmul_rn(v, v);
     if (bout) bout[w - w_min] = v;
     if (!have) { bv = v; have = true; }
@@ -167,37 +147,117 @@ __device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int
     if (--lo < 0) lo = n - 1;
     if (++hi == n) hi = 0;
   }
-  return have ? bv : -1.0f;  // empty range: below every beta
+  return bv;
 }
 
-// ---- FIR + Sigma + beta scan + argmax.  One wavefront = 16 centres x 4 width-quarters.
-// grid.x = ceil(x_t/16) + ceil(y_t/16), grid.y = frames.  write_frame: frame whose beta matrices are stored.
-__global__ __launch_bounds__(64) void k_beta(const float *__restrict__ proj, SyncGeom g,
-                                             unsigned long long *__restrict__ keys, int write_frame,
-                                             float *__restrict__ bx, float *__restrict__ by) {
-  extern __shared__ float cv[];
+// ---- fold partials + FIR + Sigma + beta scan + argmax.  One workgroup = 64 blank-band centres.
+// Phase 1 (wave 0, one lane per centre): the reference's sequential running sum _Sigma(w), every value parked
+// in LDS.  Phase 2 (all 256 threads): the (centre, w) pairs are independent now -- thread t owns centre t & 63
+// and widths w_min + (t >> 6) + 4i.  grid.x = ceil(x_t/64) + ceil(y_t/64), grid.y = frames.
+// write_frame: frame whose beta matrices are stored.
+__global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, SyncGeom g,
+                                              unsigned long long *__restrict__ keys, int write_frame,
+                                              float *__restrict__ bx, float *__restrict__ by) {
+  extern __shared__ float sh[];
   const int f = blockIdx.y;
-  const int nbx = (g.x_t + 15) >> 4;
+  const int nbx = (g.x_t + 63) >> 6;
   const int axis = (int)blockIdx.x < nbx ? 0 : 1;
   const int n = axis == 0 ? g.x_t : g.y_t;
   const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
-  const float *raw = proj + (size_t)f * proj_stride(g.y_t, g.x_t) + (axis == 0 ? 0 : g.x_t);
-  const int lane = threadIdx.x;
-  const float S = fir_and_sigma(raw, n, g, cv, lane);
-  const int c0 = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 16 + (lane >> 2);  // 0-based centre
-  const int qd = lane & 3;
-  const int W = w_max - w_min + 1, Wq = (W + 3) >> 2;
+  const int W = w_max - w_min + 1, Wp = W | 1;
+  float *raw = sh;                                          // [n]
+  float *cv = sh + n;                                       // [n]
+  float2 *rtab = reinterpret_cast<float2 *>(sh + 2 * n);    // [W] {RN(1/(2(n-w))), RN(1/(2w))}
+  float *sw = sh + 2 * n + 2 * W;                           // [64][Wp] running sums
+  __shared__ float Ssh;
+  const float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
+  const int nrb = (g.y_t + 63) >> 6;
+  const int tid = threadIdx.x;
+  // fold the projection partials in their defined order (loads batched, adds in order)
+  for (int i = tid; i < n; i += 256) {
+    const float *q = axis == 0 ? pr + i : pr + (size_t)nrb * g.x_t + i;
+    const size_t st = axis == 0 ? (size_t)g.x_t : (size_t)g.y_t;
+    const int cnt = axis == 0 ? nrb : 8;
+    float tot = q[0];
+    int j = 1;
+    for (; j + 4 <= cnt; j += 4) {
+      const float v0 = q[(size_t)j * st], v1 = q[(size_t)(j + 1) * st], v2 = q[(size_t)(j + 2) * st], v3 = q[(size_t)(j + 3) * st];
+      tot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(tot, v0), v1), v2), v3);
+    }
+    for (; j < cnt; ++j) tot = __fadd_rn(tot, q[(size_t)j * st]);
+    raw[i] = tot;
+  }
+  for (int i = tid; i < W; i += 256) {
+    const int w = w_min + i;
+    rtab[i] = make_float2(__fdiv_rn(1.0f, (float)(2 * (n - w))), __fdiv_rn(1.0f, (float)(2 * w)));
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {  // FIR, transposed-direct-form association
+    float acc = __fmul_rn(g.h4, i >= 4 ? raw[i - 4] : 0.0f);
+    acc = __fadd_rn(acc, __fmul_rn(g.h3, i >= 3 ? raw[i - 3] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h2, i >= 2 ? raw[i - 2] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h1, i >= 1 ? raw[i - 1] : 0.0f));
+    acc = __fadd_rn(acc, __fmul_rn(g.h0, raw[i]));
+    cv[i] = acc;
+  }
+  __syncthreads();
+  const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64;
+  if (tid < 64) {
+    // Sigma in sum64 order
+    float a = 0.0f;
+    for (int i = tid; i < n; i += 64) a = __fadd_rn(a, cv[i]);
+    a = wave_tree64(a);
+    if (tid == 0) Ssh = a;
+    // phase 1: running sum of centre cbase + tid (FrameSynchronisation.jl:101-107), sequential
+    const int c0 = cbase + tid;
+    if (c0 < n) {
+      float acc = 0.0f;
+      int k = (c0 - (w_min - 1)) % n; if (k < 0) k += n;
+#pragma unroll 8
+      for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) { acc = __fadd_rn(acc, cv[k]); if (++k == n) k = 0; }
+      float s = __fmul_rn(2.0f, acc);
+      int lo = (c0 - w_min) % n; if (lo < 0) lo += n;
+      int hi = (c0 + w_min) % n;
+      float *dst = sw + tid * Wp;
+      // the LDS reads do not depend on s: unrolling lets them run ahead of the two-add dependency chain
+#pragma unroll 8
+      for (int i = 0; i < W; ++i) {
+        s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
+        s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
+        dst[i] = s;
+        if (--lo < 0) lo = n - 1;
+        if (++hi == n) hi = 0;
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: beta[w, c] = ((Sigma - s)/(2(n-w)) + s/(2w))^2 for this thread's centre and every 4th width
+  const float S = Ssh;
+  const int ci = tid & 63, c0 = cbase + ci;
   unsigned long long key = 0ull;
   if (c0 < n) {
-    const int wa = w_min + qd * Wq, wb = min(wa + Wq - 1, w_max);
     float *bout = (f == write_frame) ? (axis == 0 ? bx : by) + (size_t)c0 * W : nullptr;
-    if (wa <= wb) key = pack_key(beta_scan(cv, n, c0, w_min, wa, wb, S, bout), c0);
+    const float *src = sw + ci * Wp;
+    float bv = 0.0f;
+    bool have = false;
+#pragma unroll 4
+    for (int i = tid >> 6; i < W; i += 4) {
+      const int w = w_min + i;
+      const float sv = src[i];
+      const float2 rr = rtab[i];
+      float v = __fadd_rn(div_small(__fsub_rn(S, sv), (float)(2 * (n - w)), rr.x), div_small(sv, (float)(2 * w), rr.y));
+      v = __fmul_rn(v, v);
+      if (bout) bout[i] = v;
+      if (!have) { bv = v; have = true; }
+      else if (!(bv != bv) && (v != v || v > bv)) bv = v;
+    }
+    if (have) key = pack_key(bv, c0);
   }
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  if (lane == 0) atomicMax(&keys[(size_t)f * 2 + axis], key);
+  if ((tid & 63) == 0) atomicMax(&keys[(size_t)f * 2 + axis], key);
 }
 
 __device__ inline int key_col1(unsigned long long key) {  // 1-based column of the packed argmax
@@ -276,7 +336,7 @@ __global__ __launch_bounds__(64) void k_fill_beta(const float *__restrict__ cvin
   const int c0 = blockIdx.x * 64 + lane;
   if (c0 >= n) return;
   const int W = w_max - w_min + 1;
-  (void)beta_scan(cv, n, c0, w_min, w_min, w_max, S, beta + (size_t)c0 * W);
+  (void)beta_scan(cv, n, c0, w_min, w_min, w_max, S, beta + (size_t)c0 * W, nullptr);
 }
 
 static SyncGeom geom_of(const tsdr_sync *s) {
@@ -301,12 +361,15 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   unsigned long long *keys = *keys_out ? *keys_out : (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
   if (!proj || !keys) return TSDR_ENOMEM;
   const SyncGeom g = geom_of(s);
-  const unsigned npb = (unsigned)(ceil_div((size_t)x, 4) + ceil_div((size_t)y, 32));
-  TSDR_LAUNCH(ctx, "sync_proj", k_proj, dim3(npb, (unsigned)frames), dim3(256), 0, img, img_stride, y, x, proj, keys);
+  const unsigned nrb = (unsigned)ceil_div((size_t)y, 64);
+  const size_t chunk = ceil_div((size_t)x, 8);
+  TSDR_LAUNCH(ctx, "sync_proj", k_proj, dim3(8 * nrb, (unsigned)frames), dim3(64), 64 * (chunk | 1) * 4, img, img_stride, y,
+              x, proj, keys);
   const size_t nmax = (size_t)(x > y ? x : y);
-  const unsigned nbb = (unsigned)(ceil_div((size_t)x, 16) + ceil_div((size_t)y, 16));
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nbb, (unsigned)frames), dim3(64), nmax * 4, (const float *)proj, g, keys,
-              frames - 1, s->beta_x, s->beta_y);
+  const size_t wmax = (size_t)std::max(1 + s->wmax_x - s->wmin_x, 1 + s->wmax_y - s->wmin_y);
+  const unsigned nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nbb, (unsigned)frames), dim3(256), (2 * nmax + 2 * wmax + 64 * (wmax | 1)) * 4,
+              (const float *)proj, g, keys, frames - 1, s->beta_x, s->beta_y);
   *keys_out = keys;
   return TSDR_OK;
 }
