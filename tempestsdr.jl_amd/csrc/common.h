@@ -54,10 +54,7 @@ struct tsdr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  hipStream_t launch_stream = nullptr;  // stream TSDR_LAUNCH targets (== stream except inside the chunk pipeline)
-  hipStream_t side_stream = nullptr;    // lazily created: vsync/IIR of finished frame chunks
-  hipEvent_t chunk_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t side_done = nullptr;
+  hipStream_t launch_stream = nullptr;  // stream TSDR_LAUNCH targets (== stream)
   std::string err;
   int cu_count = 0;
   int precision = TSDR_FAST;  // tsdr_precision

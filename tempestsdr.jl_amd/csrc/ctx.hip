@@ -48,7 +48,6 @@ void prof_end(tsdr_ctx *ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->la
 static int prof_collect(tsdr_ctx *ctx) {
   if (ctx->prof.empty()) return TSDR_OK;
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->side_stream) TSDR_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
   for (auto &r : ctx->prof) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -136,9 +135,6 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
   for (auto &kv : ctx->blu) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.bfft); }
-  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-  for (auto e : ctx->chunk_ev) if (e) (void)hipEventDestroy(e);
-  if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -9,8 +9,6 @@
 // The two sequential couplings of the reference loop -- s_y lags one vsync call, and the IIR
 // recurrence -- are resolved inside shift_iir/sync_publish, so everything upstream is parallel
 // over frames.  No host synchronisation happens in the _d entry point.
-#include <cstdlib>
-
 #include "common.h"
 
 struct tsdr_sync;
@@ -19,7 +17,7 @@ namespace tsdr {
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride);
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long **keys_out,
-                size_t proj_offset = 0);
+                size_t proj_offset);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx);
@@ -58,7 +56,7 @@ int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t n
   if (rc) return rc;
   if (do_align) {
     unsigned long long *keys = keys_out;
-    rc = sync_scan_d(sync, img_out, npx, F, &keys);
+    rc = sync_scan_d(sync, img_out, npx, F, &keys, 0);
     if (rc) return rc;
   }
   return TSDR_OK;
@@ -75,78 +73,24 @@ int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, cons
                      do_align, alpha, imageOut_state, frames_out, do_align ? sync_idx : nullptr);
 }
 
-// lazily create the side stream and the events of the chunk pipeline
-static int ensure_pipeline(tsdr_ctx *ctx) {
-  if (ctx->side_stream) return TSDR_OK;
-  TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-  for (auto &e : ctx->chunk_ev) TSDR_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
-  return TSDR_OK;
-}
-
 int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,
                   int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx,
                   int *n_frames) {
   if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
   const size_t nb = nEch / S;
   if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
-  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W, P = (size_t)y_t * x_t;
+  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   float *img = (float *)ctx->scratch(WS_IMG, (nb ? nb : 1) * npx * 4);
   unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, (nb ? nb : 1) * 2 * 8);
   if (!img || !keys) return TSDR_ENOMEM;
-  // Chunk pipeline: the frames of the buffer are cut into up to 8 chunks.  The raster/downgrade launches of
-  // the chunks run back to back on the context's stream; the latency-bound tail of each finished chunk
-  // (projections -> beta scan -> circshift + IIR, which must run in frame order) goes to a side stream and
-  // hides under the next chunk's raster launch.  The side stream is joined before returning, so the caller
-  // still sees plain stream order on the context's stream.
-  // Measured on MI355X (C2, 30 frames): 1 chunk 0.245 ms, 2 chunks 0.271 ms, 3 chunks 0.297 ms -- the extra
-  // launches and cross-stream event waits cost more than the overlap gains, so the pipeline is opt-in.
-  int nch = 1;
-  if (const char *e = getenv("TSDR_CHUNKS")) nch = atoi(e);
-  if (nch > 8) nch = 8;
-  if (!do_align || nb < 2 * (size_t)nch || nch < 2) {
-    int nf = 0;
-    int rc = tsdr_frames_scan_d(ctx, sync, iq, nEch, S, y_t, x_t, do_align, img, raster_out, keys, &nf);
-    if (n_frames) *n_frames = nf;
-    if (rc || nf == 0) return rc;
-    return tsdr_frames_combine_d(ctx, sync, img, keys, nf, alpha, do_align, imageOut_state, frames_out, sync_idx);
-  }
-  int rc = frames_check(ctx, sync, do_align);
-  if (rc) return rc;
-  rc = ensure_pipeline(ctx);
-  if (rc) return rc;
-  if (n_frames) *n_frames = (int)nb;
-  // everything the side stream touches must be allocated before the pipeline starts (scratch() may sync)
-  {
-    int b[4];
-    tsdr_sync_bounds(sync, b);
-    if (!ctx->scratch(WS_PROJ, nb * (size_t)(TSDR_RENDER_H + TSDR_RENDER_W) * 4)) return TSDR_ENOMEM;
-  }
-  TSDR_HIP(ctx, hipEventRecord(ctx->side_done, ctx->stream));              // side work starts after prior main work
-  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_done, 0));
-  size_t f0 = 0;
-  for (int c = 0; c < nch; ++c) {
-    const size_t cnt = nb / nch + ((size_t)c < nb % nch ? 1 : 0);
-    rc = raster_and_down_d(ctx, iq + 2 * f0 * S, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, (int)cnt,
-                           raster_out ? raster_out + f0 * P : nullptr, P, img + f0 * npx, npx);
-    if (rc) break;
-    TSDR_HIP(ctx, hipEventRecord(ctx->chunk_ev[c], ctx->stream));
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->chunk_ev[c], 0));
-    ctx->launch_stream = ctx->side_stream;
-    unsigned long long *kc = keys + 2 * f0;
-    rc = sync_scan_d(sync, img + f0 * npx, npx, (int)cnt, &kc, f0 * (size_t)(TSDR_RENDER_H + TSDR_RENDER_W));
-    if (!rc)
-      rc = shift_iir_d(ctx, sync, img + f0 * npx, npx, TSDR_RENDER_H, TSDR_RENDER_W, (int)cnt, kc, do_align, alpha,
-                       imageOut_state, frames_out ? frames_out + f0 * npx : nullptr, sync_idx ? sync_idx + 2 * f0 : nullptr);
-    ctx->launch_stream = ctx->stream;
-    if (rc) break;
-    f0 += cnt;
-  }
-  // join: the context's stream continues only after the side stream has drained
-  hipError_t e = hipEventRecord(ctx->side_done, ctx->side_stream);
-  if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_done, 0);
-  if (e != hipSuccess && !rc) rc = hip_fail(ctx, e, "chunk pipeline join");
-  return rc;
+  // (Tried and dropped, MI355X/C2: cutting the buffer into frame chunks and running each chunk's vsync/IIR
+  // tail on a second stream under the next chunk's raster launch -- 0.245 ms -> 0.271 ms with 2 chunks, 0.297 ms
+  // with 3: the extra launches and cross-stream event waits cost more than the overlap returns.)
+  int nf = 0;
+  int rc = tsdr_frames_scan_d(ctx, sync, iq, nEch, S, y_t, x_t, do_align, img, raster_out, keys, &nf);
+  if (n_frames) *n_frames = nf;
+  if (rc || nf == 0) return rc;
+  return tsdr_frames_combine_d(ctx, sync, img, keys, nf, alpha, do_align, imageOut_state, frames_out, sync_idx);
 }
 
 int tsdr_frames(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,

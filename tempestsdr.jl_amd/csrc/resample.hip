@@ -101,6 +101,10 @@ struct TileParams {
   int NR, NC;           // DOWN: candidate output rows / columns per tile
   int lpl_log;          // log2(lanes per line) of the staging loop
   int xcd_group;        // neighbouring pixel strips dealt to the same XCD
+  int xcd_group_log;    // log2(xcd_group)
+  float inv_tiles_p;    // 1/tiles_p (unit -> frame, strip without an integer division)
+  RsAxis ax, ay, axx;   // sig->raster, raster lines->rows, raster pixels->columns (host-computed)
+  double inv_sfy, inv_sfx;
 };
 
 // FAST pixel walk of one lane along its line: (k, r) advance by integer adds; every staged sample holds
@@ -152,39 +156,33 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
   // at their seams merge in that L2; (2) neighbouring strips -- which read the same IQ lines -- run on the same
   // XCD close in time, so IQ is fetched into one L2 once instead of once per XCD (measured: FETCH_SIZE 3.5x
   // the IQ bytes with units dealt round-robin).
-  const unsigned b = blockIdx.x;
-  const unsigned xcd = b & 7u, slot = b >> 3;
+  // grid = (8, tiles_l, units per XCD): the linear block id is x + 8*(y + tiles_l*z), so x is the XCD slot, the
+  // line tiles of a unit are consecutive on it, and no integer division is needed to decode the tile
+  const unsigned xcd = blockIdx.x, ul = blockIdx.z;
+  const int tl = (int)blockIdx.y;
   const unsigned U = (unsigned)(q.frames * q.tiles_p);
-  const int tl = (int)(slot % (unsigned)q.tiles_l);
-  const unsigned ul = slot / (unsigned)q.tiles_l;                 // this XCD's ul-th unit
-  const unsigned G = (unsigned)q.xcd_group;                       // strips per group (neighbours share an XCD)
-  const unsigned u = ((ul / G) * 8u + xcd) * G + (ul % G);
+  const unsigned gl = (unsigned)q.xcd_group_log;
+  const unsigned u = ((((ul >> gl) << 3) + xcd) << gl) + (ul & ((1u << gl) - 1u));
   if (u >= U) return;
-  const int f = (int)(u / (unsigned)q.tiles_p), tp = (int)(u % (unsigned)q.tiles_p);
+  int f = (int)(((float)u + 0.5f) * q.inv_tiles_p);            // u / tiles_p (u < 2^20: exact)
+  int tp = (int)u - f * q.tiles_p;
+  if (tp < 0) { tp += q.tiles_p; --f; } else if (tp >= q.tiles_p) { tp -= q.tiles_p; ++f; }
   const int l0 = tl * q.own_l, p0 = tp * q.own_p;
   const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
   const unsigned P = (unsigned)q.y_t * (unsigned)q.x_t;
-  const RsAxis ax = rs_axis(q.S, P);
+  const RsAxis ax = q.ax;
   const bool same = (q.S == P);
   const int tid = threadIdx.x;
 
-  if (tid < 64) {
-    const int l = min(l0 + tid, q.y_t - 1);
-    const unsigned flat = (unsigned)l * (unsigned)q.x_t + (unsigned)p0;
-    int k;
-    if (EXACT) { double d; k = (int)rs_pos(ax, (double)(flat + 1u), d); }
-    else { unsigned r; fast_pos(fa, flat, k, r); k = max(k, 0); }
-    kfirst[tid] = k;
-  }
   if (DOWN) {
     // candidate output rows/columns whose top-left tap may fall in this tile (monotone maps -> contiguous);
     // -1 marks "not owned by this tile"
-    const RsAxis ay = rs_axis((size_t)q.y_t, (size_t)q.h_out), axx = rs_axis((size_t)q.x_t, (size_t)q.w_out);
+    const RsAxis ay = q.ay, axx = q.axx;
     // wave 0 builds the row table (two rounds when NR > 64), wave 1 the column table; the valid entries of
     // each are contiguous, so one ballot per round yields first index and count
     const int wv = tid >> 6, ln = tid & 63;
     if (wv == 0) {
-      const int rbase = max(0, (int)floor(((double)l0 + 0.5) / ay.sf - 0.5) - 1);
+      const int rbase = max(0, (int)floor(((double)l0 + 0.5) * q.inv_sfy - 0.5) - 2);
       const bool last = (tl == q.tiles_l - 1);
       int first = 0x7fffffff, count = 0;
       for (int base = 0; base < q.NR; base += 64) {
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       }
       if (ln == 0) { vinfo[0] = first; vinfo[1] = count; }
     } else if (wv == 1) {
-      const int cbase = max(0, (int)floor(((double)p0 + 0.5) / axx.sf - 0.5) - 1);
+      const int cbase = max(0, (int)floor(((double)p0 + 0.5) * q.inv_sfx - 0.5) - 2);
       const bool last = (tp == q.tiles_p - 1);
       int first = 0x7fffffff, count = 0;
       for (int base = 0; base < q.NC; base += 64) {
@@ -217,13 +215,23 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       if (ln == 0) { vinfo[2] = first; vinfo[3] = count; }
     }
   }
-  __syncthreads();
   {  // stage: 2^lpl_log lanes per line (chosen on the host to waste the fewest lane slots); the loads of
-     // up to four samples are issued back to back before any |IQ| math, so their latencies overlap
+     // up to four samples are issued back to back before any |IQ| math, so their latencies overlap.  Every
+     // staging thread derives its line's first sample index itself (no barrier before staging; the candidate
+     // tables above are only needed by the downgrade phase) and lane 0 of the line publishes it for the walk.
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
     for (int r = sub; r < 64; r += nsub) {
-      const unsigned kf = (unsigned)kfirst[r];
+      unsigned kf;
+      {
+        const int l = min(l0 + r, q.y_t - 1);
+        const unsigned flat = (unsigned)l * (unsigned)q.x_t + (unsigned)p0;
+        int k;
+        if (EXACT) { double d; k = (int)rs_pos(ax, (double)(flat + 1u), d); }
+        else { unsigned rr; fast_pos(fa, flat, k, rr); k = max(k, 0); }
+        kf = (unsigned)k;
+        if (j0 == 0) kfirst[r] = k;
+      }
       for (int jb = j0; jb < q.W; jb += 4 * lpl) {
         float re[4], im[4];
 #pragma unroll
@@ -355,29 +363,42 @@ struct DownParams {
   unsigned S;
   int y_t, x_t, h_out, w_out;
   int TC, NL, W, tiles_c;
+  int lpl_log;
 };
 
-template <bool EXACT>
-__device__ inline float raster_tap(const RsAxis &ax1, const FastAx &fa, bool same1, unsigned flat, const float *row, int kf) {
-  if (EXACT) {
-    double d;
-    const int j = (int)rs_pos(ax1, (double)(flat + 1u), d) - kf;
-    return same1 ? (d == 1.0 ? row[j + 1] : row[j]) : rs_blend(row[j], row[j + 1], d);
-  }
-  // FAST: x0 = sf*(flat+0.5) - 0.5 in f64 (one FMA), clamped below; weight and blend in f32
-  double x = fma(ax1.sf, (double)flat + 0.5, -0.5);
-  x = fmax(x, 0.0);
+enum { DM_EXACT = 0, DM_FAST_PAIR = 1, DM_FAST_F32 = 2 };
+
+// EXACT raster value at flat index `flat` (0-based) of a staged f32 line
+__device__ inline float raster_tap_exact(const RsAxis &ax1, bool same1, unsigned flat, const float *row, int kf) {
+  double d;
+  const int j = (int)rs_pos(ax1, (double)(flat + 1u), d) - kf;
+  return same1 ? (d == 1.0 ? row[j + 1] : row[j]) : rs_blend(row[j], row[j + 1], d);
+}
+// FAST raster value at 0-based source coordinate x >= 0 (f64): staged {a, b-a} pairs or plain f32 samples
+template <int MODE>
+__device__ inline float raster_tap_fast(double x, const void *row, int kf) {
   const double xf = floor(x);
   const int j = (int)xf - kf;
-  return fast_blend(row[j], row[j + 1], x - xf);
+  if (MODE == DM_FAST_PAIR) {
+    const double2 s = reinterpret_cast<const double2 *>(row)[j];
+    return (float)fma(x - xf, s.y, s.x);
+  }
+  const float *r = reinterpret_cast<const float *>(row);
+  return fast_blend(r[j], r[j + 1], x - xf);
 }
 
-template <bool CPLX, bool EXACT>
+template <bool CPLX, int MODE>
 __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
-                                                    FastAx fa, float *__restrict__ out, size_t out_stride) {
-  extern __shared__ float lds[];
+                                                    float *__restrict__ out, size_t out_stride) {
+  constexpr bool EXACT = MODE == DM_EXACT;
+  constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample
+  extern __shared__ double lds_dn[];
   const int Wp = q.W | 1;
-  int *kfirst = reinterpret_cast<int *>(lds + (size_t)q.NL * Wp);
+  char *base = reinterpret_cast<char *>(lds_dn);
+  double *cdx = reinterpret_cast<double *>(base + (((size_t)q.NL * Wp * SB + 15) & ~(size_t)15));  // [TC] column weight
+  double *cxs = cdx + q.TC;                                                                           // [TC] sf * kx
+  int *ckx = reinterpret_cast<int *>(cxs + q.TC);                                                     // [TC] kx
+  int *kfirst = ckx + q.TC;                                                                           // [NL]
   const int tr = blockIdx.x / q.tiles_c, tc = blockIdx.x - tr * q.tiles_c;
   const int r0 = tr * 64, c0 = tc * q.TC;
   const int f = blockIdx.y;
@@ -398,41 +419,82 @@ __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in
     const unsigned flat = (unsigned)(ly0 + i) * (unsigned)q.x_t + (unsigned)pxa;
     int k;
     if (EXACT) k = (int)rs_pos(ax1, (double)(flat + 1u), dtmp);
-    else k = (int)floor(fmax(fma(ax1.sf, (double)flat + 0.5, -0.5), 0.0));
-    kfirst[i] = k;
+    else k = max((int)floor(fmax(fma(ax1.sf, (double)flat + 0.5, -0.5), 0.0)) - 1, 0);  // one spare sample on the
+    kfirst[i] = k;                                                                        // left: tap coordinates
+  }                                                                                       // are built by additions
+  if (tid < q.TC) {  // per-column table: kx, weight, and the column's coordinate offset sf*kx
+    const int c = min(c0 + tid, q.w_out - 1);
+    double dx;
+    const int kx = (int)rs_pos(axx, (double)(c + 1), dx);
+    ckx[tid] = kx; cdx[tid] = dx; cxs[tid] = ax1.sf * (double)kx;
   }
   __syncthreads();
-  {
-    const int sub = tid >> 4, j0 = tid & 15;
-    for (int i = sub; i < nl; i += 16) {
+  {  // stage the source lines: loads of up to four samples are issued before any |IQ| math
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
+    for (int i = sub; i < nl; i += nsub) {
       const unsigned kf = (unsigned)kfirst[i];
-      for (int j = j0; j < q.W; j += 16) {
-        const unsigned k = min(kf + (unsigned)j, q.S - 1u);
-        lds[i * Wp + j] = load_sample<CPLX, EXACT>(src, k);
+      for (int jb = j0; jb < q.W; jb += 4 * lpl) {
+        float re[4], im[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned k = min(kf + (unsigned)min(jb + u * lpl, q.W - 1), q.S - 1u);
+          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
+          else { re[u] = src[k]; im[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + u * lpl;
+          if (j < q.W) {
+            const float a = CPLX ? abs_iq<EXACT>(re[u], im[u]) : re[u];
+            if (MODE == DM_FAST_PAIR) reinterpret_cast<double2 *>(base)[i * Wp + j].x = (double)a;
+            else reinterpret_cast<float *>(base)[i * Wp + j] = a;
+          }
+        }
       }
     }
   }
   __syncthreads();
+  if (MODE == DM_FAST_PAIR) {  // slope towards the next sample
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
+    double2 *s2 = reinterpret_cast<double2 *>(base);
+    for (int i = sub; i < nl; i += nsub)
+      for (int j = j0; j + 1 < q.W; j += lpl) s2[i * Wp + j].y = s2[i * Wp + j + 1].x - s2[i * Wp + j].x;
+    __syncthreads();
+  }
   const int wave = tid >> 6, lane = tid & 63;
   const int r = r0 + lane;
   if (r >= q.h_out) return;
   double dy;
   const int ky = (int)rs_pos(ay, (double)(r + 1), dy);
   const int i0 = ky - ly0;
-  const float *row0 = lds + (size_t)i0 * Wp;
-  const float *row1 = row0 + Wp;
+  const char *row0 = base + (size_t)i0 * Wp * SB;
+  const char *row1 = row0 + (size_t)Wp * SB;
   const int kf0 = kfirst[i0], kf1 = kfirst[i0 + 1];
   const unsigned b0 = (unsigned)ky * (unsigned)q.x_t, b1 = b0 + (unsigned)q.x_t;
   const int cend = min(c0 + q.TC, q.w_out);
   float *o = out + (size_t)f * out_stride + (size_t)r;
+  // FAST: 0-based source coordinate of raster pixel (ky, 0) and the per-line / per-pixel increments
+  const double xrow = fma(ax1.sf, (double)b0 + 0.5, -0.5), xline = ax1.sf * (double)q.x_t;
   for (int c = c0 + wave; c < cend; c += 4) {
-    double dx;
-    const unsigned kx = rs_pos(axx, (double)(c + 1), dx);
-    // the four raster values, each rounded to f32 as the materialised raster would hold them
-    const float R00 = raster_tap<EXACT>(ax1, fa, same1, b0 + kx, row0, kf0);
-    const float R01 = raster_tap<EXACT>(ax1, fa, same1, b0 + kx + 1u, row0, kf0);
-    const float R10 = raster_tap<EXACT>(ax1, fa, same1, b1 + kx, row1, kf1);
-    const float R11 = raster_tap<EXACT>(ax1, fa, same1, b1 + kx + 1u, row1, kf1);
+    const int ct = c - c0;
+    const double dx = cdx[ct];
+    float R00, R01, R10, R11;
+    if (EXACT) {
+      const unsigned kx = (unsigned)ckx[ct];
+      const float *f0 = reinterpret_cast<const float *>(row0), *f1 = reinterpret_cast<const float *>(row1);
+      R00 = raster_tap_exact(ax1, same1, b0 + kx, f0, kf0);
+      R01 = raster_tap_exact(ax1, same1, b0 + kx + 1u, f0, kf0);
+      R10 = raster_tap_exact(ax1, same1, b1 + kx, f1, kf1);
+      R11 = raster_tap_exact(ax1, same1, b1 + kx + 1u, f1, kf1);
+    } else {
+      const double x00 = xrow + cxs[ct];
+      R00 = raster_tap_fast<MODE>(fmax(x00, 0.0), row0, kf0);
+      R01 = raster_tap_fast<MODE>(fmax(x00 + ax1.sf, 0.0), row0, kf0);
+      R10 = raster_tap_fast<MODE>(x00 + xline, row1, kf1);           // line ky+1 >= 1: coordinate > 0
+      R11 = raster_tap_fast<MODE>(x00 + xline + ax1.sf, row1, kf1);
+    }
     float v;
     if (EXACT) {
       // first dimension (lines) outermost: wy0*(wx0*a00 + wx1*a01) + wy1*(wx0*a10 + wx1*a11)
@@ -509,10 +571,11 @@ static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t 
                        const FastAx &fa, size_t lds, float *out, size_t out_stride, float *down, size_t down_stride) {
   const size_t units = (size_t)q.frames * q.tiles_p;
   const size_t G = (size_t)q.xcd_group;
-  const size_t grid = 8 * ceil_div(units, 8 * G) * G * (size_t)q.tiles_l;
-  if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "raster: grid too large");
-  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, EXACT, DOWN>), dim3((unsigned)grid), dim3(256), lds, in, in_stride, q, fa, out,
-              out_stride, down, down_stride);
+  const size_t upx = ceil_div(units, 8 * G) * G;  // units per XCD slot
+  if (upx > 65535 || (size_t)q.tiles_l > 65535 || units >= (size_t(1) << 20))
+    return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
+  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, EXACT, DOWN>), dim3(8, (unsigned)q.tiles_l, (unsigned)upx), dim3(256), lds, in,
+              in_stride, q, fa, out, out_stride, down, down_stride);
   return TSDR_OK;
 }
 
@@ -534,8 +597,14 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
                          (double)y_t / h_out >= 1.0 && (double)x_t / w_out >= 1.0;
   TileParams q{};
   q.S = (unsigned)S; q.y_t = y_t; q.x_t = x_t; q.frames = frames;
-  q.xcd_group = 4;  // measured on C2: G=1 0.138 ms, G=4 0.132 ms, G=41 (a whole frame row) 0.146 ms
-  if (const char *e = getenv("TSDR_XCD_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4096) q.xcd_group = v; }
+  q.xcd_group_log = 2;  // groups of 4 strips; measured on C2: G=1 0.138 ms, G=4 0.132 ms, G=41 0.146 ms
+  if (const char *e = getenv("TSDR_XCD_GROUP_LOG")) { const int v = atoi(e); if (v >= 0 && v <= 12) q.xcd_group_log = v; }
+  q.xcd_group = 1 << q.xcd_group_log;
+  q.ax = rs_axis(S, (size_t)y_t * x_t);
+  if (h_out > 0 && w_out > 0) {
+    q.ay = rs_axis((size_t)y_t, (size_t)h_out); q.axx = rs_axis((size_t)x_t, (size_t)w_out);
+    q.inv_sfy = 1.0 / q.ay.sf; q.inv_sfx = 1.0 / q.axx.sf;
+  }
   bool tiled = false;
   // 64-pixel tiles when the downgrade is fused in: the raster tile kept in LDS then costs 16.6 KiB instead of
   // 33 KiB, which doubles the resident workgroups per CU (measured: 0.18 ms vs 0.24 ms per C2 buffer)
@@ -554,6 +623,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.own_p = dn ? q.TP - 1 : q.TP;
     q.tiles_l = dn ? (y_t - 2) / 63 + 1 : (int)ceil_div((size_t)y_t, 64);
     q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
+    q.inv_tiles_p = 1.0f / (float)q.tiles_p;
     // staging lanes per line: the power of two that wastes the fewest lane slots for this W
     int best = 0; long best_slots = 1L << 60;
     for (int lg = 2; lg <= 6; ++lg) {
@@ -564,8 +634,8 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     size_t lds = (size_t)64 * (size_t)(q.W | 1) * (exact ? 4 : 16) + 16 + 64 * 4 + 16;
     if (dn) {
       q.h_out = h_out; q.w_out = w_out;
-      q.NR = (int)ceil(64.0 / ((double)y_t / h_out)) + 4;
-      q.NC = (int)ceil((double)q.TP / ((double)x_t / w_out)) + 4;
+      q.NR = (int)ceil(64.0 / ((double)y_t / h_out)) + 5;
+      q.NC = (int)ceil((double)q.TP / ((double)x_t / w_out)) + 5;
       if (q.NR > 128 || q.NC > 192) return set_err(ctx, TSDR_EINVAL, "raster: candidate table overflow");
       lds += (size_t)q.TP * 65 * 4 + (size_t)(q.NR + q.NC + 4) * 4 + (size_t)(q.NR + q.NC) * 8;
     }
@@ -604,27 +674,38 @@ int resize2d_d(tsdr_ctx *ctx, const float *img, int h_in, int w_in, int h_out, i
   return TSDR_OK;
 }
 
-struct DownPlan { bool fused; DownParams q; size_t lds; };
+struct DownPlan { bool fused; int mode; DownParams q; size_t lds; };
 
-static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out) {
+static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool exact) {
   DownPlan pl;
   pl.fused = false;
   pl.lds = 0;
+  pl.mode = DM_EXACT;
   const double sf = (double)S / ((double)y_t * (double)x_t);
   const double sfy = (double)y_t / (double)h_out, sfx = (double)x_t / (double)w_out;
   const long NL = (long)(63.0 * sfy) + 3;
   static const int cand[] = {32, 16, 8, 4};
-  for (int pass = 0; pass < 2 && !pl.fused; ++pass) {
-    const size_t cap = pass == 0 ? 32 * 1024 : 60 * 1024;
+  // preference: FAST with {a, slope} f64 pairs (16 B/sample) when it fits 32 KiB, else f32 staging
+  for (int pass = 0; pass < 3 && !pl.fused; ++pass) {
+    const int sb = (!exact && pass == 0) ? 16 : 4;
+    if (exact && pass == 0) continue;
+    const size_t cap = pass == 2 ? 60 * 1024 : 32 * 1024;
     for (int TC : cand) {
       const long DPX = (long)((double)(TC - 1) * sfx) + 2;
-      const long W = (long)((double)DPX * sf) + 4;
-      const size_t lds = (size_t)NL * (size_t)(W | 1) * 4 + (size_t)NL * 4;
+      const long W = (long)((double)DPX * sf) + 4 + (exact ? 0 : 1);
+      const size_t lds = (((size_t)NL * (size_t)(W | 1) * sb + 15) & ~(size_t)15) + (size_t)TC * 20 + (size_t)NL * 4;
       if (lds <= cap && W < (1 << 20)) {
         pl.fused = true;
         pl.lds = lds;
+        pl.mode = exact ? DM_EXACT : (sb == 16 ? DM_FAST_PAIR : DM_FAST_F32);
         pl.q.S = (unsigned)S; pl.q.y_t = y_t; pl.q.x_t = x_t; pl.q.h_out = h_out; pl.q.w_out = w_out;
         pl.q.TC = TC; pl.q.NL = (int)NL; pl.q.W = (int)W; pl.q.tiles_c = (int)ceil_div((size_t)w_out, (size_t)TC);
+        int best = 2; long best_slots = 1L << 60;
+        for (int lg = 2; lg <= 6; ++lg) {
+          const long lpl = 1L << lg, slots = (long)ceil_div((size_t)W, (size_t)lpl) * lpl;
+          if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
+        }
+        pl.q.lpl_log = best;
         break;
       }
     }
@@ -645,13 +726,19 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   if (same2) return raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, out, out_stride);
   const size_t P = (size_t)y_t * x_t;
   const bool exact = ctx->precision == TSDR_EXACT;
-  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out);
+  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact);
   if (pl.fused) {
-    const FastAx fa = fast_axis(S, P);
     dim3 grid((unsigned)(ceil_div((size_t)h_out, 64) * (size_t)pl.q.tiles_c), (unsigned)frames);
-#define DOWNK(C, E, NAME) TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, E>), grid, dim3(256), pl.lds, in, in_stride, pl.q, fa, out, out_stride)
-    if (cplx) { if (exact) { DOWNK(true, true, "down_fused_iq_exact"); } else { DOWNK(true, false, "down_fused_iq"); } }
-    else { if (exact) { DOWNK(false, true, "down_fused_f32_exact"); } else { DOWNK(false, false, "down_fused_f32"); } }
+#define DOWNK(C, M, NAME) TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M>), grid, dim3(256), pl.lds, in, in_stride, pl.q, out, out_stride)
+    if (cplx) {
+      if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, "down_fused_iq_exact"); }
+      else if (pl.mode == DM_FAST_PAIR) { DOWNK(true, DM_FAST_PAIR, "down_fused_iq"); }
+      else { DOWNK(true, DM_FAST_F32, "down_fused_iq"); }
+    } else {
+      if (pl.mode == DM_EXACT) { DOWNK(false, DM_EXACT, "down_fused_f32_exact"); }
+      else if (pl.mode == DM_FAST_PAIR) { DOWNK(false, DM_FAST_PAIR, "down_fused_f32"); }
+      else { DOWNK(false, DM_FAST_F32, "down_fused_f32"); }
+    }
 #undef DOWNK
     return TSDR_OK;
   }
