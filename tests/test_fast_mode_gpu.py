@@ -75,3 +75,30 @@ def test_fast_and_exact_agree_on_extreme_samples(ctx):
         ok = np.isfinite(b) & (b > 0)
         assert np.max(np.abs(a[ok] - b[ok]) / b[ok]) < RTOL
         assert np.array_equal(np.isfinite(a), np.isfinite(b))
+
+
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_frames_many_frames(ctx, tsdr, synth, precision):
+    """A long buffer (66 frames of the 800x600@60 mode at 2 MS/s: > 1000 (frame, strip) units in one launch).
+    EXACT must stay bit-identical, FAST within tolerance."""
+    Fs, x_t, y_t, fv, nfr = 2.0e6, 1056, 628, 60.0, 66
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 11)
+    gs = np.zeros((600, 800), np.float32, order="F")
+    os_ = np.zeros((600, 800), np.float32, order="F")
+    ctx.set_precision(precision)
+    try:
+        g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), gs, want_raster=True)
+    finally:
+        ctx.set_precision("fast")
+    o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), os_, want_raster=True)
+    assert g["n_frames"] == o["n_frames"] == nfr
+    assert np.array_equal(g["sync_idx"], o["sync_idx"])
+    for f in (0, 1, nfr // 2, nfr - 1):
+        if precision == "exact":
+            assert np.array_equal(g["raster"][f].view(np.uint32), o["raster"][f].view(np.uint32)), f
+            assert np.array_equal(g["frames"][f].view(np.uint32), o["frames"][f].view(np.uint32)), f
+        else:
+            assert relerr(g["raster"][f], o["raster"][f]) < RTOL and relerr(g["frames"][f], o["frames"][f]) < RTOL
+    if precision == "exact":
+        assert np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
