@@ -286,3 +286,26 @@ def test_parallel_bindings_single_rank(ctx, tsdr, synth):
     got = res.cpu().numpy()
     assert np.max(np.abs(got - o)) < 2e-4, np.max(np.abs(got - o))
     assert pos == int(np.argmax(o))
+
+
+def test_full_c2_buffer_bitexact(ctx, tsdr, synth):
+    """BASELINE config C2 at full size: one 0.5 s buffer (10e6 IQ samples = 30 frames of 2576x1125@60 at
+    20 MS/s) through tsdr_frames, EXACT mode, against the oracle: sync indices, every frame, the raster of
+    the first and last frame and the final IIR state bit for bit."""
+    import zlib
+    wl = synth.WORKLOADS["C2"]
+    Fs, x_t, y_t, fv = wl["Fs"], wl["x_t"], wl["y_t"], wl["fv"]
+    n = int(round(wl["acquisition"] * Fs))
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, n)
+    gs = np.zeros((600, 800), np.float32, order="F")
+    os_ = np.zeros((600, 800), np.float32, order="F")
+    g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), gs, want_raster=True)
+    o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), os_, want_raster=True)
+    assert g["n_frames"] == o["n_frames"] == 30
+    assert np.array_equal(g["sync_idx"], o["sync_idx"]), (g["sync_idx"].tolist(), o["sync_idx"].tolist())
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes())
+    assert [crc(f) for f in g["frames"]] == [crc(f) for f in o["frames"]]
+    for f in (0, 29):
+        assert_bitexact(g["raster"][f], o["raster"][f], f"raster {f}")
+    assert_bitexact(gs, os_, "imageOut state after 30 frames")
