@@ -207,3 +207,29 @@ def test_sharded_autocorr_gloo_world2():
 def test_sharded_frames_gloo_world2():
     res = _spawn(_worker_frames)
     assert all(ok for _, ok in res), res
+
+
+# ---------------------------------------------------------------- configuration search (host picks)
+def test_search_flow_on_oracle(tsdr):
+    """search.py's peak picks (GUI.jl:56-81, :491-506, investigate_data.jl:92) driven by the ORACLE's
+    autocorrelation: the host logic is backend-agnostic, so this covers it without a GPU."""
+    search = importlib.import_module("tempestsdr_jl_amd.search")
+    synth = importlib.import_module("tempestsdr_jl_amd.synth")
+    vcm = importlib.import_module("tempestsdr_jl_amd.video_configurations")
+
+    class OracleCtx:
+        abs2 = staticmethod(O.abs2)
+        calculate_autocorrelation = staticmethod(O.calculate_autocorrelation)
+        zoom_autocorr = staticmethod(O.zoom_autocorr)
+
+    mode = vcm.allVideoConfigurations["800x600 @ 60Hz"]  # 1056 x 628 total
+    Fs = 2.0e6
+    iq = synth.synth_leak(Fs, mode.width, mode.height, mode.refresh, int(0.2 * Fs))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = search.search(OracleCtx, iq, Fs)
+    assert abs(got["fv"] - 60.0) < 0.2
+    assert abs(got["y_t"] - 628) <= 0.03 * 628
+    assert vcm.allVideoConfigurations[got["name"]].refresh == 60.0
+    with pytest.raises(IndexError):  # capture shorter than the 0.1 s window
+        search.extract_configuration(OracleCtx, iq[:1000], Fs)
