@@ -19,7 +19,9 @@
 
 namespace tsdr {
 
-int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale);
+int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale, int src_mode,
+             size_t src_n, size_t keep);
+enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2 };
 int get_tw(tsdr_ctx *ctx, int logN, TwTable **out);
 
 __device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -169,12 +171,20 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
   TwTable *tw = nullptr;
   int rc = get_tw(ctx, logM, &tw);
   if (rc) return rc;
-  TSDR_LAUNCH(ctx, "ac_pack", k_ac_pack, dim3(stream_grid(ctx, Mc)), dim3(256), 0, x, is_iq, n, Mc, z);
-  rc = fft_pow2(ctx, z, Z, logM - 1, 1, -1, 1.0f);
+  // forward transform straight from the samples: the first pass packs (x[2j], x[2j+1]) -- forming abs2.(iq) on
+  // the fly when asked -- and never reads the zero padding; no separate pack pass, no 33 MB round trip
+  const bool aligned = !is_iq || (reinterpret_cast<uintptr_t>(x) & 15u) == 0;  // the IQ loader reads float4 pairs
+  if (logM - 1 > 8 && aligned) {
+    rc = fft_pow2(ctx, reinterpret_cast<const float2 *>(x), Z, logM - 1, 1, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, n, 0);
+  } else {
+    TSDR_LAUNCH(ctx, "ac_pack", k_ac_pack, dim3(stream_grid(ctx, Mc)), dim3(256), 0, x, is_iq, n, Mc, z);
+    rc = fft_pow2(ctx, z, Z, logM - 1, 1, -1, 1.0f, SRC_C2C, 0, 0);
+  }
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)tw->lo,
               (const float2 *)tw->hi, tw->h);
-  rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc));
+  // only lags < n are ever folded: the last inverse pass stores a[0 .. n] = n/2 + 1 complex values
+  rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc), SRC_C2C, 0, n / 2 + 1);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "ac_fold", k_ac_fold, dim3(stream_grid(ctx, cnt)), dim3(256), 0, reinterpret_cast<const float *>(z), n, k0,
               cnt, log_scale, out);
@@ -244,10 +254,10 @@ int tsdr_autocorr_partial_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, 
   float2 *Z = (float2 *)ctx->scratch(WS_FFT_C, M * sizeof(float2));
   if (!z || !Z) return TSDR_ENOMEM;
   TSDR_LAUNCH(ctx, "pc_pack", k_pc_pack, dim3(stream_grid(ctx, M)), dim3(256), 0, x, is_iq, n, m0, cnt, vlen, M, z);
-  int rc = fft_pow2(ctx, z, Z, logM, 1, -1, 1.0f);
+  int rc = fft_pow2(ctx, z, Z, logM, 1, -1, 1.0f, SRC_C2C, 0, 0);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "pc_cross", k_pc_cross, dim3(stream_grid(ctx, M / 2 + 1)), dim3(256), 0, Z, M);
-  rc = fft_pow2(ctx, Z, z, logM, 1, +1, (float)(1.0 / (double)M));
+  rc = fft_pow2(ctx, Z, z, logM, 1, +1, (float)(1.0 / (double)M), SRC_C2C, 0, n_lags);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "pc_real", k_real_part, dim3(stream_grid(ctx, n_lags)), dim3(256), 0, (const float2 *)z, n_lags, part);
   return TSDR_OK;

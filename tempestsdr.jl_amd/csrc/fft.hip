@@ -8,17 +8,18 @@
 //                the result overwrites the same slots (layout [k_1]..[k_i][n_{i+1}]..[n_p]).
 //   pass p     : length-R_p DFT over the contiguous n_p, written to natural order
 //                k = K(k_1..k_{p-1}) + (R_1..R_{p-1}) * k_p.
-// A workgroup owns a tile of R x T elements in LDS (T = 16..: T neighbouring columns are
-// contiguous in HBM, so every global access is a >=128-byte run; the last pass tiles over k_1 so
-// its transposed store is contiguous too).  Inside LDS the DFT is an in-place radix-4 DIF
-// (one radix-2 stage first when log2 R is odd); the digit-reversed order is undone while storing.
-// Twiddles come from f64-generated tables: W_4096 for the in-LDS stages, and a two-level table
-// (W = hi[e >> h] * lo[e & mask]) for the inter-pass twiddles, so no sin/cos runs on the device
-// and twiddle error stays at ~1.5 ulp for any N.
+// A workgroup owns a tile of R x T elements (T = 16..: T neighbouring columns are contiguous in
+// HBM, so every global access is a >=128-byte run; the last pass tiles over k_1 so its transposed
+// store is contiguous too).  The length-R DFT is two register-resident radix-<=16 steps with one
+// exchange through LDS between them (see k_fft_pass).
+// In-tile twiddles come from an f64-generated W_4096 table; inter-pass twiddles are evaluated in
+// registers from the exact integer phase (tw_unit, <= 1.5 ulp for any N).  The two-level tables
+// (W = hi[e >> h] * lo[e & mask], get_tw) serve the real-FFT post-processing kernels.
 //
 // Other lengths: Bluestein (chirp-z) on top of the power-of-two engine; chirp phases are reduced
 // exactly (k^2 mod 2n in 64-bit integers) and evaluated in f64.
 #include <cmath>
+#include <utility>
 
 #include "common.h"
 
@@ -36,21 +37,16 @@ struct PassDesc {
   float scale;
   unsigned long long N;  // elements per transform
   unsigned A, B, tiles;  // strided: outer count, inner size (= stride of the DFT index), B/T
-  int logNtw, logBnext, logPprev, tw_h;
+  int logNtw, logBnext, logPprev;
   int nprev;
   int logRprev[4];       // radices of the passes before this one (pass order)
   int logR1;
   unsigned Aprime, k1tiles;  // last pass: A / R_1, R_1 / T
   unsigned rows;             // rows mode: number of transforms
+  int src_mode;              // first pass loader (SRC_*); only with batch == 1
+  unsigned long long src_n;  // real samples behind SRC_REAL / SRC_IQPOW
+  unsigned long long keep;   // last pass: complex outputs >= keep (per transform) are not stored
 };
-
-// position of frequency k after the in-place DIF stages
-__device__ inline int fft_pos(int k, int logR) {
-  int p = 0, rem = logR;
-  if (logR & 1) { p |= (k & 1) << (rem - 1); k >>= 1; rem -= 1; }
-  while (rem > 0) { p |= (k & 3) << (rem - 2); k >>= 2; rem -= 2; }
-  return p;
-}
 
 // K(a): a = k_1*(R_2..R_m) + ... + k_m  ->  k_1 + R_1*k_2 + R_1R_2*k_3 + ...
 __device__ inline unsigned digit_swap(unsigned a, int m, const int *logR) {
@@ -66,117 +62,330 @@ __device__ inline unsigned digit_swap(unsigned a, int m, const int *logR) {
   return K;
 }
 
-// in-place DIF on buf[idx*TP + t], idx < R, t < T; twR[e] = W_R^e (already conjugated for inverse)
-__device__ inline void lds_fft(float2 *buf, const float2 *twR, int logR, int logT, int TP, int dir, int tid) {
-  const int R = 1 << logR, T = 1 << logT;
-  int L = R;
-  if (logR & 1) {
-    const int half = R >> 1;
-    for (int w = tid; w < (half << logT); w += 256) {
-      const int t = w & (T - 1), j = w >> logT;
-      float2 a0 = buf[j * TP + t], a1 = buf[(j + half) * TP + t];
-      buf[j * TP + t] = cadd(a0, a1);
-      buf[(j + half) * TP + t] = cmul(csub(a0, a1), twR[j]);
-    }
-    L = half;
-    __syncthreads();
-  }
-  while (L >= 4) {
-    const int Q = L >> 2, logQ = 31 - __clz(Q), step = R / L;
-    for (int w = tid; w < ((R >> 2) << logT); w += 256) {
-      const int t = w & (T - 1), u = w >> logT;
-      const int g = u >> logQ, j = u & (Q - 1);
-      float2 *p0 = buf + (g * L + j) * TP + t;
-      float2 *p1 = p0 + Q * TP, *p2 = p1 + Q * TP, *p3 = p2 + Q * TP;
-      const float2 a0 = *p0, a1 = *p1, a2 = *p2, a3 = *p3;
-      const float2 b0 = cadd(a0, a2), b1 = csub(a0, a2), b2 = cadd(a1, a3);
-      const float2 d = csub(a1, a3);
-      // forward: -i*d ; inverse: +i*d
-      const float2 b3 = dir < 0 ? make_float2(d.y, -d.x) : make_float2(-d.y, d.x);
-      const int e = j * step;
-      *p0 = cadd(b0, b2);
-      *p1 = cmul(cadd(b1, b3), twR[e]);
-      *p2 = cmul(csub(b0, b2), twR[2 * e]);
-      *p3 = cmul(csub(b1, b3), twR[3 * e]);
-    }
-    L = Q;
-    __syncthreads();
+// ---- register DFTs ----------------------------------------------------------------------------
+// Forward DFT of N = 2, 4, 8 or 16 points held in registers: radix-2 decimation in frequency with the
+// twiddles as literals (trivial ones special-cased), result in bit-reversed order (X[k] at v[brev<N>(k)]).
+__device__ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                                        0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+__device__ constexpr float kSin16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                                        1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+
+template <int N, int I>
+__device__ inline float2 mul_w(float2 d) {  // d * exp(-2*pi*i*I/N), 0 <= I < N/2
+  constexpr int E = I * (16 / N);
+  if constexpr (E == 0) {
+    return d;
+  } else if constexpr (E == 4) {
+    return make_float2(d.y, -d.x);
+  } else if constexpr (E == 2) {
+    return make_float2((d.x + d.y) * kCos16[2], (d.y - d.x) * kCos16[2]);
+  } else if constexpr (E == 6) {
+    return make_float2((d.y - d.x) * kCos16[2], -(d.x + d.y) * kCos16[2]);
+  } else {
+    return make_float2(d.x * kCos16[E] + d.y * kSin16[E], d.y * kCos16[E] - d.x * kSin16[E]);
   }
 }
 
-__global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, PassDesc d,
-                                                  const float2 *__restrict__ tw_small, const float2 *__restrict__ tw_lo,
-                                                  const float2 *__restrict__ tw_hi) {
-  extern __shared__ float2 sm[];
-  const int R = 1 << d.logR, T = 1 << d.logT, TP = T + 1;
-  float2 *buf = sm;
-  float2 *twR = sm + R * TP;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < R; e += 256) {
-    float2 w = tw_small[e << (12 - d.logR)];
-    if (d.dir > 0) w.y = -w.y;
-    twR[e] = w;
+template <int N, int I>
+__device__ inline void bfly(float2 *v) {
+  const float2 a = v[I], b = v[I + N / 2];
+  v[I] = cadd(a, b);
+  v[I + N / 2] = mul_w<N, I>(csub(a, b));
+}
+
+template <int N, int... I>
+__device__ inline void dif_stage(float2 *v, std::integer_sequence<int, I...>) {
+  (bfly<N, I>(v), ...);
+}
+
+template <int N>
+__device__ inline void reg_dft(float2 *v) {
+  if constexpr (N >= 2) {
+    dif_stage<N>(v, std::make_integer_sequence<int, N / 2>{});
+    reg_dft<N / 2>(v);
+    reg_dft<N / 2>(v + N / 2);
   }
+}
+
+template <int N>
+__device__ constexpr int brev(int k) {
+  int r = 0;
+  for (int b = 1; b < N; b <<= 1) { r = (r << 1) | (k & 1); k >>= 1; }
+  return r;
+}
+
+// exp(-2*pi*i*e / 2^L) for 0 <= e < 2^L, 2 <= L <= 31, without tables: the phase is reduced to an octant
+// exactly in integers, and sin/cos(pi/4 * x), x in [0, 1], come from degree-7/8 polynomials (Chebyshev
+// interpolants in x^2; measured error <= 8.6e-8 absolute over all f32 x, i.e. <= 1.5 ulp).  A gathered
+// table read costs one L1 tag cycle per distinct line per lane and made the pass gather-bound.
+__device__ inline float2 tw_unit(unsigned e, int L) {
+  const unsigned q = e << (32 - L);
+  const unsigned o = q >> 29;
+  unsigned r = q & 0x1FFFFFFFu;
+  if (o & 1u) r = 0x20000000u - r;
+  const float x = (float)r * 0x1p-29f;
+  const float u = x * x;
+  const float sn = fmaf(fmaf(fmaf(-3.595429006963968e-05f, u, 0.0024900068528950214f), u, -0.08074543625116348f), u,
+                        0.7853981852531433f) * x;
+  const float cs = fmaf(fmaf(fmaf(fmaf(3.5297971407999285e-06f, u, -0.0003259385994169861f), u, 0.015854325145483017f), u,
+                             -0.3084251284599304f), u, 1.0f);
+  const bool swap = ((o + 1u) >> 1) & 1u;
+  float cr = swap ? sn : cs, sr = swap ? cs : sn;
+  if ((o + 2u) & 4u) cr = -cr;
+  if (!(o & 4u)) sr = -sr;
+  return make_float2(cr, sr);
+}
+
+__device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000000 for the inverse transform
+  return make_float2(v.x, __uint_as_float(__float_as_uint(v.y) ^ smask));
+}
+
+// element g of the (single) transform for the fused loaders of the first pass:
+//   SRC_C2C   in[g]
+//   SRC_REAL  (x[2g], x[2g+1])            real f32 sequence of src_n samples packed two per complex, zero beyond
+//   SRC_IQPOW (|iq[2g]|^2, |iq[2g+1]|^2)  the same with x = abs2.(iq) formed on the fly (GUI.jl:70)
+enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2 };
+
+__device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g) {
+  if (src_mode == SRC_C2C) return in[g];
+  const unsigned long long i0 = 2ull * g;
+  if (i0 >= src_n) return make_float2(0.f, 0.f);  // zero padding is never read
+  if (src_mode == SRC_REAL) {
+    const float *x = reinterpret_cast<const float *>(in);
+    return make_float2(x[i0], i0 + 1 < src_n ? x[i0 + 1] : 0.f);
+  }
+  const float4 z = reinterpret_cast<const float4 *>(in)[g];  // iq[2g], iq[2g+1]
+  return make_float2(z.x * z.x + z.y * z.y, i0 + 1 < src_n ? z.z * z.z + z.w * z.w : 0.f);
+}
+
+// One pass over a tile of R x T (<= 4096) elements per 256-thread workgroup, 16 elements per thread.
+// R = RA * RB (RA <= 16): with n = j0 + RB*m and k = ka + RA*kb
+//   X[ka + RA*kb] = sum_j0 W_RB^(j0*kb) * ( W_R^(j0*ka) * sum_m W_RA^(m*ka) x[j0 + RB*m] ).
+// Step 1 runs the RA-point DFTs over m in registers (thread = column t, residue j0), multiplies by W_R^(j0*ka)
+// and passes the tile through LDS once; step 2 runs the RB-point DFTs over j0 in registers (thread = column t,
+// frequency ka) and stores straight from registers.  So the tile crosses LDS once (write + read) instead of
+// once per radix-4 stage, and all 16 global loads of a thread are in flight together.
+//   STRIDED: global -> registers (columns t are contiguous in HBM), ..., registers -> global with the
+//            inter-pass twiddle.
+//   LAST   : rows are contiguous over the DFT index, so the tile is first staged through LDS with a linear,
+//            fully coalesced load; the store is contiguous over the k_1 tile.
+//   ROWS   : as LAST, and the result is staged back through LDS for a linear store.
+// The inverse transform is conj(F(conj(x))): the sign bit of the imaginary part is flipped on the way in and
+// out, every twiddle is the forward one.
+template <int LOGR>
+struct Split {
+  static constexpr int LA = LOGR <= 4 ? LOGR : (LOGR + 1) / 2;
+  static constexpr int LB = LOGR - LA;
+};
+
+template <int LOGR, int MODE>
+__global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in, float2 *__restrict__ out, PassDesc d,
+                                                  const float2 *__restrict__ tw_small) {
+  constexpr int LA = Split<LOGR>::LA, LB = Split<LOGR>::LB;
+  constexpr int R = 1 << LOGR, RA = 1 << LA, RB = 1 << LB;
+  constexpr int CA = 16 / RA, CB = 16 / RB;  // DFTs per thread in step 1 / step 2
+  extern __shared__ float2 sm[];
+  const int logT = d.logT, T = 1 << logT, TP = T + 1;
+  const int SA = (RB << logT) + (T < 32 ? T : 0);  // pitch of one ka plane of the exchange buffer
+  float2 *buf = sm;                                // staging tile [j][TP] and exchange buffer [ka][SA] (aliased)
+  float2 *twR = sm + 4096 + 256 + 16;
+  const int tid = threadIdx.x;
+  const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
+  if (RB > 1)
+    for (int e = tid; e < R; e += 256) twR[e] = tw_small[e << (12 - LOGR)];
   const unsigned bid = blockIdx.x;
-  const int work = R << d.logT;
-  if (d.mode == FFT_STRIDED) {
-    const unsigned tile = bid % d.tiles, a = (bid / d.tiles) % d.A, b = bid / (d.tiles * d.A);
-    const size_t base = (size_t)b * d.N + (size_t)a * R * d.B + (size_t)tile * T;
-    for (int w = tid; w < work; w += 256) {
-      const int t = w & (T - 1), j = w >> d.logT;
-      buf[j * TP + t] = in[base + (size_t)j * d.B + t];
+  const int work = R << logT;
+  const int n1 = RB << logT, n2 = RA << logT;  // DFT slots of step 1 / step 2
+
+  constexpr int CO = RB > 1 ? CB : CA;  // output slots per thread
+  constexpr int RO = RB > 1 ? RB : RA;  // outputs per slot
+  const int no = RB > 1 ? n2 : n1;
+
+  float2 v[16];
+  float2 tw[MODE == FFT_STRIDED ? 16 : 1];
+  size_t base = 0, tbase = 0, row0 = 0;
+  unsigned tile = 0, a = 0, kt = 0, arest = 0;
+  if (MODE == FFT_STRIDED) {
+    tile = bid % d.tiles;
+    a = (bid / d.tiles) % d.A;
+    const unsigned b = bid / (d.tiles * d.A);
+    base = (size_t)b * d.N + (size_t)a * R * d.B + (size_t)tile * T;
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1), j0 = s >> logT;
+#pragma unroll
+      for (int m = 0; m < RA; ++m)
+        v[q * RA + m] = s < n1 ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
+                               : make_float2(0.f, 0.f);
     }
-    __syncthreads();
-    lds_fft(buf, twR, d.logR, d.logT, TP, d.dir, tid);
+    // inter-pass twiddles of this thread's 16 outputs: independent of the data, so they are evaluated here,
+    // under the latency of the loads just issued
     const unsigned Ka = digit_swap(a, d.nprev, d.logRprev);
     const unsigned mask = (d.logNtw >= 32) ? 0xFFFFFFFFu : ((1u << d.logNtw) - 1u);
-    const unsigned lomask = (1u << d.tw_h) - 1u;
-    for (int w = tid; w < work; w += 256) {
-      const int t = w & (T - 1), k = w >> d.logT;
-      float2 v = buf[fft_pos(k, d.logR) * TP + t];
-      const unsigned nnext = (tile * T + (unsigned)t) >> d.logBnext;
-      const unsigned e = (nnext * (Ka + ((unsigned)k << d.logPprev))) & mask;
-      float2 tw = cmul(tw_hi[e >> d.tw_h], tw_lo[e & lomask]);
-      if (d.dir > 0) tw.y = -tw.y;
-      out[base + (size_t)k * d.B + t] = cmul(v, tw);
-    }
-  } else if (d.mode == FFT_LAST) {
-    const unsigned kt = bid % d.k1tiles, arest = (bid / d.k1tiles) % d.Aprime, b = bid / (d.k1tiles * d.Aprime);
-    const size_t tbase = (size_t)b * d.N;
-    for (int w = tid; w < work; w += 256) {
-      const int j = w & (R - 1), t = w >> d.logR;
-      const size_t a = (size_t)(kt * T + (unsigned)t) * d.Aprime + arest;
-      buf[j * TP + t] = in[tbase + a * R + j];
-    }
-    __syncthreads();
-    lds_fft(buf, twR, d.logR, d.logT, TP, d.dir, tid);
-    // digits k_2..k_{p-1} of arest -> their natural-order weight (already multiples of R_1)
-    const unsigned Kp = digit_swap(arest, d.nprev - 1, d.logRprev + 1) << d.logR1;
-    const size_t obase = tbase + (size_t)kt * T + Kp;
-    for (int w = tid; w < work; w += 256) {
-      const int t = w & (T - 1), k = w >> d.logT;
-      float2 v = buf[fft_pos(k, d.logR) * TP + t];
-      out[obase + ((size_t)k << d.logPprev) + t] = make_float2(v.x * d.scale, v.y * d.scale);
+#pragma unroll
+    for (int q = 0; q < CO; ++q) {
+      const int s = min(tid + 256 * q, no - 1);
+      const unsigned nnext = (tile * T + (unsigned)(s & (T - 1))) >> d.logBnext;
+#pragma unroll
+      for (int i = 0; i < RO; ++i) {
+        const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+        tw[q * RO + i] = tw_unit((nnext * (Ka + ((unsigned)k << d.logPprev))) & mask, d.logNtw);
+      }
     }
   } else {
-    const size_t row0 = (size_t)bid * T;
-    for (int w = tid; w < work; w += 256) {
-      const int j = w & (R - 1), t = w >> d.logR;
-      const size_t row = row0 + t;
-      buf[j * TP + t] = row < d.rows ? in[row * R + j] : make_float2(0.f, 0.f);
+    if (MODE == FFT_LAST) {
+      kt = bid % d.k1tiles;
+      arest = (bid / d.k1tiles) % d.Aprime;
+      tbase = (size_t)(bid / (d.k1tiles * d.Aprime)) * d.N;
+    } else {
+      row0 = (size_t)bid * T;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int w = min(tid + 256 * u, work - 1);
+      const int j = w & (R - 1), t = w >> LOGR;
+      if (MODE == FFT_LAST) {
+        v[u] = in[tbase + ((size_t)(kt * T + (unsigned)t) * d.Aprime + arest) * R + j];
+      } else {
+        const size_t row = row0 + t;
+        v[u] = row < d.rows ? in[row * R + j] : make_float2(0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int w = tid + 256 * u;
+      if (w < work) buf[(w & (R - 1)) * TP + (w >> LOGR)] = conj_if(v[u], smask);
     }
     __syncthreads();
-    lds_fft(buf, twR, d.logR, d.logT, TP, d.dir, tid);
-    for (int w = tid; w < work; w += 256) {
-      const int k = w & (R - 1), t = w >> d.logR;
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = min(tid + 256 * q, n1 - 1);
+      const int t = s & (T - 1), j0 = s >> logT;
+#pragma unroll
+      for (int m = 0; m < RA; ++m) v[q * RA + m] = buf[(j0 + RB * m) * TP + t];
+    }
+  }
+  __syncthreads();  // twR visible; staging tile fully read before the exchange buffer overwrites it
+
+  // ---- step 1: RA-point DFTs over m, twiddle, exchange ----
+#pragma unroll
+  for (int q = 0; q < CA; ++q) reg_dft<RA>(v + q * RA);
+  if (RB > 1) {
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = tid + 256 * q;
+      const int j0 = s >> logT;
+      if (s < n1) {
+#pragma unroll
+        for (int ka = 0; ka < RA; ++ka) {
+          float2 x = v[q * RA + brev<RA>(ka)];
+          if (ka) x = cmul(x, twR[j0 * ka]);
+          buf[ka * SA + s] = x;  // (j0, t) is the slot number itself
+        }
+      }
+    }
+    __syncthreads();
+    // ---- step 2: RB-point DFTs over j0 ----
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const int s = min(tid + 256 * q, n2 - 1);
+      const int t = s & (T - 1), ka = s >> logT;
+#pragma unroll
+      for (int j0 = 0; j0 < RB; ++j0) v[q * RB + j0] = buf[ka * SA + (j0 << logT) + t];
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) reg_dft<RB>(v + q * RB);
+  } else {
+    // single-step radix (R <= 16): put the result in natural order, one "DFT of one point" per slot below
+    float2 n[16];
+#pragma unroll
+    for (int q = 0; q < CA; ++q)
+#pragma unroll
+      for (int ka = 0; ka < RA; ++ka) n[q * RA + ka] = v[q * RA + brev<RA>(ka)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = n[i];
+  }
+  // Register i of the thread now holds, for RB > 1, slot q = i / RB (column t, frequency ka) and X[ka + RA*kb]
+  // with kb = brev(i % RB); for RB == 1, slot q = i / RA (column t) and X[i % RA].
+
+  if (MODE == FFT_STRIDED) {
+#pragma unroll
+    for (int q = 0; q < CO; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1);
+      if (s < no) {
+#pragma unroll
+        for (int i = 0; i < RO; ++i) {
+          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+          const float2 x = RB > 1 ? v[q * RB + brev<RB>(i)] : v[q * RA + i];
+          out[base + (size_t)k * d.B + t] = conj_if(cmul(x, tw[q * RO + i]), smask);
+        }
+      }
+    }
+  } else if (MODE == FFT_LAST) {
+    // digits k_2..k_{p-1} of arest -> their natural-order weight (already multiples of R_1)
+    const unsigned Kp = digit_swap(arest, d.nprev - 1, d.logRprev + 1) << d.logR1;
+    const size_t orel = (size_t)kt * T + Kp;
+#pragma unroll
+    for (int q = 0; q < CO; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1);
+      if (s < no) {
+#pragma unroll
+        for (int i = 0; i < RO; ++i) {
+          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+          const float2 x = RB > 1 ? v[q * RB + brev<RB>(i)] : v[q * RA + i];
+          const size_t o = orel + ((size_t)k << d.logPprev) + t;
+          // outputs past `keep` are never looked at by the caller (e.g. lags beyond the window)
+          if (o < d.keep) out[tbase + o] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+        }
+      }
+    }
+  } else {
+    __syncthreads();  // exchange buffer fully read
+#pragma unroll
+    for (int q = 0; q < CO; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1);
+      if (s < no) {
+#pragma unroll
+        for (int i = 0; i < RO; ++i) {
+          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+          buf[k * TP + t] = RB > 1 ? v[q * RB + brev<RB>(i)] : v[q * RA + i];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int w = tid + 256 * u;
+      const int k = w & (R - 1), t = w >> LOGR;
       const size_t row = row0 + t;
-      if (row < d.rows) {
-        float2 v = buf[fft_pos(k, d.logR) * TP + t];
-        out[row * R + k] = make_float2(v.x * d.scale, v.y * d.scale);
+      if (w < work && row < d.rows) {
+        const float2 x = buf[k * TP + t];
+        out[row * R + k] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
       }
     }
   }
 }
+
+typedef void (*fft_pass_fn)(const float2 *, float2 *, PassDesc, const float2 *);
+
+template <int MODE>
+static fft_pass_fn pass_fn(int logR) {
+  switch (logR) {
+    case 1: return k_fft_pass<1, MODE>;
+    case 2: return k_fft_pass<2, MODE>;
+    case 3: return k_fft_pass<3, MODE>;
+    case 4: return k_fft_pass<4, MODE>;
+    case 5: return k_fft_pass<5, MODE>;
+    case 6: return k_fft_pass<6, MODE>;
+    case 7: return k_fft_pass<7, MODE>;
+    default: return k_fft_pass<8, MODE>;
+  }
+}
+static const size_t kPassLds = (4096 + 256 + 16 + 256) * sizeof(float2);
 
 // ---- twiddle tables ------------------------------------------------------------------------
 static int ensure_tw_small(tsdr_ctx *ctx) {
@@ -220,7 +429,8 @@ int get_tw(tsdr_ctx *ctx, int logN, TwTable **out) {
 // ---- power-of-two driver ---------------------------------------------------------------------
 // in/out may alias.  Uses WS_FFT_B when more than one pass is needed: callers must not hand
 // WS_FFT_B buffers to this function.
-int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale) {
+int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale, int src_mode,
+             size_t src_n, size_t keep) {
   if (logN < 0 || logN > 31) return set_err(ctx, TSDR_EINVAL, "fft: unsupported power-of-two length 2^%d", logN);
   if (batch == 0) return TSDR_OK;
   int rc = ensure_tw_small(ctx);
@@ -237,6 +447,10 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   PassDesc d{};
   d.dir = dir < 0 ? -1 : 1;
   d.N = N;
+  d.src_mode = SRC_C2C;
+  d.src_n = 0;
+  d.keep = keep ? keep : N;
+  if (src_mode != SRC_C2C && (batch != 1 || logN <= 8)) return set_err(ctx, TSDR_EINVAL, "fft: fused loader needs one multi-pass transform");
   if (p == 1) {
     d.mode = FFT_ROWS;
     d.logR = logN;
@@ -244,11 +458,9 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
     d.scale = scale;
     d.rows = (unsigned)batch;
     if (batch >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "fft: too many rows");
-    const int R = 1 << d.logR, T = 1 << d.logT;
-    const size_t lds = ((size_t)R * (T + 1) + R) * sizeof(float2);
+    const int T = 1 << d.logT;
     const unsigned grid = (unsigned)ceil_div(batch, (size_t)T);
-    TSDR_LAUNCH(ctx, "fft_rows", k_fft_pass, dim3(grid), dim3(256), lds, in, out, d, (const float2 *)ctx->tw_small,
-                (const float2 *)nullptr, (const float2 *)nullptr);
+    TSDR_LAUNCH(ctx, "fft_rows", pass_fn<FFT_ROWS>(d.logR), dim3(grid), dim3(256), kPassLds, in, out, d, (const float2 *)ctx->tw_small);
     return TSDR_OK;
   }
   float2 *work = (float2 *)ctx->scratch(WS_FFT_B, N * batch * sizeof(float2));
@@ -258,6 +470,8 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   for (int i = 0; i < p - 1; ++i) {
     const int logB = logN - logP - bits[i];
     d.mode = FFT_STRIDED;
+    d.src_mode = i == 0 ? src_mode : SRC_C2C;
+    d.src_n = src_n;
     d.logR = bits[i];
     d.logT = std::min(12 - bits[i], logB);
     d.scale = 1.0f;
@@ -269,20 +483,16 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
     d.logPprev = logP;
     d.nprev = i;
     for (int j = 0; j < i; ++j) d.logRprev[j] = bits[j];
-    TwTable *tw = nullptr;
-    rc = get_tw(ctx, d.logNtw, &tw);
-    if (rc) return rc;
-    d.tw_h = tw->h;
-    const int R = 1 << d.logR, T = 1 << d.logT;
-    const size_t lds = ((size_t)R * (T + 1) + R) * sizeof(float2);
     const size_t grid = batch * d.A * d.tiles;
     if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
-    TSDR_LAUNCH(ctx, "fft_strided", k_fft_pass, dim3((unsigned)grid), dim3(256), lds, src, work, d,
-                (const float2 *)ctx->tw_small, (const float2 *)tw->lo, (const float2 *)tw->hi);
+    static const char *const kStridedName[3] = {"fft_strided1", "fft_strided2", "fft_strided3"};
+    TSDR_LAUNCH(ctx, kStridedName[i], pass_fn<FFT_STRIDED>(d.logR), dim3((unsigned)grid), dim3(256), kPassLds, src, work, d,
+                (const float2 *)ctx->tw_small);
     src = work;
     logP += bits[i];
   }
   d.mode = FFT_LAST;
+  d.src_mode = SRC_C2C;
   d.logR = bits[p - 1];
   d.logR1 = bits[0];
   d.logT = std::min(12 - bits[p - 1], bits[0]);
@@ -293,12 +503,10 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   d.Aprime = 1u << (logP - bits[0]);
   d.k1tiles = 1u << (bits[0] - d.logT);
   {
-    const int R = 1 << d.logR, T = 1 << d.logT;
-    const size_t lds = ((size_t)R * (T + 1) + R) * sizeof(float2);
     const size_t grid = batch * d.Aprime * d.k1tiles;
     if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
-    TSDR_LAUNCH(ctx, "fft_last", k_fft_pass, dim3((unsigned)grid), dim3(256), lds, (const float2 *)work, out, d,
-                (const float2 *)ctx->tw_small, (const float2 *)nullptr, (const float2 *)nullptr);
+    TSDR_LAUNCH(ctx, "fft_last", pass_fn<FFT_LAST>(d.logR), dim3((unsigned)grid), dim3(256), kPassLds, (const float2 *)work, out, d,
+                (const float2 *)ctx->tw_small);
   }
   return TSDR_OK;
 }
@@ -376,7 +584,7 @@ static int get_bluestein(tsdr_ctx *ctx, size_t n, BluesteinPlan **out) {
   float2 *tmp = (float2 *)ctx->scratch(WS_FFT_D, pl.L * sizeof(float2));
   if (!tmp) return TSDR_ENOMEM;
   TSDR_LAUNCH(ctx, "blu_b", k_blu_b, dim3(stream_grid(ctx, pl.L)), dim3(256), 0, (const float2 *)pl.chirp, n, pl.L, tmp);
-  int rc = fft_pow2(ctx, tmp, pl.bfft, ilog2(pl.L), 1, -1, 1.0f);
+  int rc = fft_pow2(ctx, tmp, pl.bfft, ilog2(pl.L), 1, -1, 1.0f, SRC_C2C, 0, 0);
   if (rc) return rc;
   auto ins = ctx->blu.emplace(n, pl);
   *out = &ins.first->second;
@@ -395,7 +603,7 @@ int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n
       TSDR_LAUNCH(ctx, "r2c", k_r2c, dim3(stream_grid(ctx, n * batch)), dim3(256), 0, x, n * batch, out);
       src = out;
     }
-    return fft_pow2(ctx, src, out, ilog2(n), batch, d, scale);
+    return fft_pow2(ctx, src, out, ilog2(n), batch, d, scale, SRC_C2C, 0, 0);
   }
   BluesteinPlan *pl = nullptr;
   int rc = get_bluestein(ctx, n, &pl);
@@ -407,11 +615,11 @@ int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n
   const int inv = d > 0;
   TSDR_LAUNCH(ctx, "blu_pre", k_blu_pre, dim3(stream_grid(ctx, L * batch)), dim3(256), 0, x, is_complex, inv, n, L, batch,
               (const float2 *)pl->chirp, a);
-  rc = fft_pow2(ctx, a, a2, ilog2(L), batch, -1, 1.0f);
+  rc = fft_pow2(ctx, a, a2, ilog2(L), batch, -1, 1.0f, SRC_C2C, 0, 0);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "blu_mul", k_cmul_bcast, dim3(stream_grid(ctx, L * batch)), dim3(256), 0, a2, (const float2 *)pl->bfft, L,
               batch);
-  rc = fft_pow2(ctx, a2, a, ilog2(L), batch, +1, (float)(1.0 / (double)L));
+  rc = fft_pow2(ctx, a2, a, ilog2(L), batch, +1, (float)(1.0 / (double)L), SRC_C2C, 0, 0);
   if (rc) return rc;
   const float scale = inv ? (float)(1.0 / (double)n) : 1.0f;
   TSDR_LAUNCH(ctx, "blu_post", k_blu_post, dim3(stream_grid(ctx, n * batch)), dim3(256), 0, (const float2 *)a, n, L, batch,

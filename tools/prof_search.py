@@ -1,0 +1,27 @@
+"""Per-kernel HIP-event breakdown of the configuration search (development aid; GPU box only)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tempest_loader import load_package
+T = load_package()
+
+ctx = T.Context()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+k_hi = n // 2
+Fs = 200e6
+g = torch.Generator().manual_seed(1)
+iq = torch.view_as_real(torch.randn(n, dtype=torch.complex64, generator=g)).contiguous().cuda()
+out = torch.empty(k_hi, dtype=torch.float32, device="cuda")
+n_out = C.c_size_t(0)
+def once():
+    ctx.call("tsdr_autocorr_iq_d", C.c_void_p(iq.data_ptr()), n, Fs, 0.0, k_hi / Fs, 1, C.c_void_p(out.data_ptr()), C.byref(n_out))
+for _ in range(3): once()
+ctx.synchronize()
+ctx.profile(True); ctx.profile_reset()
+for _ in range(10): once()
+ctx.synchronize()
+tot = 0
+for k, v in sorted(ctx.profile_results().items()):
+    cnt, ms = v["launches"], v["total_ms"]
+    print(f"{k:16s} n={cnt:4d} avg={ms/cnt*1e3:8.2f} us  per-search={ms/10*1e3:8.2f} us"); tot += ms / 10
+print("total per search", round(tot * 1e3, 2), "us")
