@@ -15,13 +15,15 @@
 #include <algorithm>
 #include <cmath>
 
-#include "common.h"
+#include "fft_dev.h"
 
 namespace tsdr {
 
 int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale, int src_mode,
              size_t src_n, size_t keep);
-enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2 };
+bool fft_mixed_ok(size_t N);
+int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
+              size_t src_n, size_t keep);
 int get_tw(tsdr_ctx *ctx, int logN, TwTable **out);
 
 __device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -49,8 +51,9 @@ __global__ __launch_bounds__(256) void k_ac_pack(const float *__restrict__ x, in
 // inverse transform (times 1/2) is the real sequence with spectrum P[k] = |X[k]|^2.
 //   X[k]    = E + W O,  X[Mc-k] = conj(E - W O),  E = (Z[k]+conj Z[Mc-k])/2, O = -i (Z[k]-conj Z[Mc-k])/2
 //   Y[k]    = (P + P') + i conj(W) (P - P'),   Y[Mc-k] = (P + P') + i W (P - P'),   W = W_M^k
+// tw_lo == nullptr: M = 2*Mc is not a power of two and W comes from tw_frac(k, 8/M).
 __global__ __launch_bounds__(256) void k_ac_power(float2 *__restrict__ Z, size_t Mc, const float2 *__restrict__ tw_lo,
-                                                  const float2 *__restrict__ tw_hi, int tw_h) {
+                                                  const float2 *__restrict__ tw_hi, int tw_h, double inv_m8) {
   const size_t half = Mc >> 1;
   const unsigned lomask = (1u << tw_h) - 1u;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= half; k += (size_t)gridDim.x * blockDim.x) {
@@ -59,14 +62,14 @@ __global__ __launch_bounds__(256) void k_ac_power(float2 *__restrict__ Z, size_t
     const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
     const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (Z[k]-conj Z[kk])/2
     const float2 O = make_float2(D.y, -D.x);                                // -i*D
-    const float2 W = cmulf(tw_hi[k >> tw_h], tw_lo[k & lomask]);
+    const float2 W = tw_lo ? cmulf(tw_hi[k >> tw_h], tw_lo[k & lomask]) : tw_frac((unsigned)k, inv_m8);
     const float2 WO = cmulf(W, O);
     const float2 X0 = make_float2(E.x + WO.x, E.y + WO.y), X1 = make_float2(E.x - WO.x, E.y - WO.y);
     const float P0 = X0.x * X0.x + X0.y * X0.y, P1 = X1.x * X1.x + X1.y * X1.y;
     const float s = P0 + P1, d = P0 - P1;
     // i*conj(W)*d = d*(W.y, W.x)... i*(Wx - iWy) = Wy + i Wx
     Z[k] = make_float2(s + d * W.y, d * W.x);
-    if (k != 0 && k != half) Z[kk] = make_float2(s - d * W.y, d * W.x);  // i*W*d = d*(-Wy + i Wx)
+    if (k != 0 && kk != k) Z[kk] = make_float2(s - d * W.y, d * W.x);  // i*W*d = d*(-Wy + i Wx)
   }
 }
 
@@ -162,6 +165,30 @@ static inline double jl_round(double v) { return nearbyint(v); }  // Julia round
 // shared core: x (real f32, or IQ whose abs2 is taken on the fly), first n samples
 static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, size_t k0, size_t cnt, int log_scale,
                          float *out) {
+  // n = 2*Mc with Mc = 2^a 3^b 5^c (the usual case: decimal sample rates, or a power of two): the circular
+  // correlation of length n is transformed natively -- no zero padding, no fold, half the bytes (or less) of the
+  // padded route below, which remains for every other n.
+  const bool half_pow2 = (n & 1) == 0 && is_pow2(n / 2);
+  if ((n & 1) == 0 && n > 1024 && (half_pow2 || fft_mixed_ok(n / 2)) &&
+      (!is_iq || (reinterpret_cast<uintptr_t>(x) & 15u) == 0)) {
+    const size_t Mc = n / 2;
+    float2 *z = (float2 *)ctx->scratch(WS_FFT_A, Mc * sizeof(float2));
+    float2 *Z = (float2 *)ctx->scratch(WS_FFT_C, Mc * sizeof(float2));
+    if (!z || !Z) return TSDR_ENOMEM;
+    auto fft = [&](const float2 *src, float2 *dst, int dir, float scale, int src_mode, size_t keep) {
+      return half_pow2 ? fft_pow2(ctx, src, dst, ilog2(Mc), 1, dir, scale, src_mode, n, keep)
+                       : fft_mixed(ctx, src, dst, Mc, 1, dir, scale, src_mode, n, keep);
+    };
+    int rc = fft(reinterpret_cast<const float2 *>(x), Z, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, 0);
+    if (rc) return rc;
+    TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)nullptr,
+                (const float2 *)nullptr, 0, 4.0 / (double)Mc);
+    rc = fft(Z, z, +1, (float)(0.5 / (double)Mc), SRC_C2C, (k0 + cnt + 1) / 2);
+    if (rc) return rc;
+    TSDR_LAUNCH(ctx, "ac_finish", k_ac_finish, dim3(stream_grid(ctx, cnt)), dim3(256), 0, reinterpret_cast<const float *>(z),
+                k0, cnt, log_scale, out);
+    return TSDR_OK;
+  }
   const int logM = ilog2(2 * n);
   const size_t M = size_t(1) << logM, Mc = M >> 1;
   if (logM > 31) return set_err(ctx, TSDR_EINVAL, "autocorr: window too long");
@@ -182,7 +209,7 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
   }
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)tw->lo,
-              (const float2 *)tw->hi, tw->h);
+              (const float2 *)tw->hi, tw->h, 0.0);
   // only lags < n are ever folded: the last inverse pass stores a[0 .. n] = n/2 + 1 complex values
   rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc), SRC_C2C, 0, n / 2 + 1);
   if (rc) return rc;

@@ -19,18 +19,10 @@
 // Other lengths: Bluestein (chirp-z) on top of the power-of-two engine; chirp phases are reduced
 // exactly (k^2 mod 2n in 64-bit integers) and evaluated in f64.
 #include <cmath>
-#include <utility>
 
-#include "common.h"
+#include "fft_dev.h"
 
 namespace tsdr {
-
-__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ inline float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-
-enum { FFT_STRIDED = 0, FFT_LAST = 1, FFT_ROWS = 2 };
 
 struct PassDesc {
   int mode, logR, logT, dir;
@@ -60,102 +52,6 @@ __device__ inline unsigned digit_swap(unsigned a, int m, const int *logR) {
     K += kj << wlog;
   }
   return K;
-}
-
-// ---- register DFTs ----------------------------------------------------------------------------
-// Forward DFT of N = 2, 4, 8 or 16 points held in registers: radix-2 decimation in frequency with the
-// twiddles as literals (trivial ones special-cased), result in bit-reversed order (X[k] at v[brev<N>(k)]).
-__device__ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
-                                        0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
-__device__ constexpr float kSin16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
-                                        1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
-
-template <int N, int I>
-__device__ inline float2 mul_w(float2 d) {  // d * exp(-2*pi*i*I/N), 0 <= I < N/2
-  constexpr int E = I * (16 / N);
-  if constexpr (E == 0) {
-    return d;
-  } else if constexpr (E == 4) {
-    return make_float2(d.y, -d.x);
-  } else if constexpr (E == 2) {
-    return make_float2((d.x + d.y) * kCos16[2], (d.y - d.x) * kCos16[2]);
-  } else if constexpr (E == 6) {
-    return make_float2((d.y - d.x) * kCos16[2], -(d.x + d.y) * kCos16[2]);
-  } else {
-    return make_float2(d.x * kCos16[E] + d.y * kSin16[E], d.y * kCos16[E] - d.x * kSin16[E]);
-  }
-}
-
-template <int N, int I>
-__device__ inline void bfly(float2 *v) {
-  const float2 a = v[I], b = v[I + N / 2];
-  v[I] = cadd(a, b);
-  v[I + N / 2] = mul_w<N, I>(csub(a, b));
-}
-
-template <int N, int... I>
-__device__ inline void dif_stage(float2 *v, std::integer_sequence<int, I...>) {
-  (bfly<N, I>(v), ...);
-}
-
-template <int N>
-__device__ inline void reg_dft(float2 *v) {
-  if constexpr (N >= 2) {
-    dif_stage<N>(v, std::make_integer_sequence<int, N / 2>{});
-    reg_dft<N / 2>(v);
-    reg_dft<N / 2>(v + N / 2);
-  }
-}
-
-template <int N>
-__device__ constexpr int brev(int k) {
-  int r = 0;
-  for (int b = 1; b < N; b <<= 1) { r = (r << 1) | (k & 1); k >>= 1; }
-  return r;
-}
-
-// exp(-2*pi*i*e / 2^L) for 0 <= e < 2^L, 2 <= L <= 31, without tables: the phase is reduced to an octant
-// exactly in integers, and sin/cos(pi/4 * x), x in [0, 1], come from degree-7/8 polynomials (Chebyshev
-// interpolants in x^2; measured error <= 8.6e-8 absolute over all f32 x, i.e. <= 1.5 ulp).  A gathered
-// table read costs one L1 tag cycle per distinct line per lane and made the pass gather-bound.
-__device__ inline float2 tw_unit(unsigned e, int L) {
-  const unsigned q = e << (32 - L);
-  const unsigned o = q >> 29;
-  unsigned r = q & 0x1FFFFFFFu;
-  if (o & 1u) r = 0x20000000u - r;
-  const float x = (float)r * 0x1p-29f;
-  const float u = x * x;
-  const float sn = fmaf(fmaf(fmaf(-3.595429006963968e-05f, u, 0.0024900068528950214f), u, -0.08074543625116348f), u,
-                        0.7853981852531433f) * x;
-  const float cs = fmaf(fmaf(fmaf(fmaf(3.5297971407999285e-06f, u, -0.0003259385994169861f), u, 0.015854325145483017f), u,
-                             -0.3084251284599304f), u, 1.0f);
-  const bool swap = ((o + 1u) >> 1) & 1u;
-  float cr = swap ? sn : cs, sr = swap ? cs : sn;
-  if ((o + 2u) & 4u) cr = -cr;
-  if (!(o & 4u)) sr = -sr;
-  return make_float2(cr, sr);
-}
-
-__device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000000 for the inverse transform
-  return make_float2(v.x, __uint_as_float(__float_as_uint(v.y) ^ smask));
-}
-
-// element g of the (single) transform for the fused loaders of the first pass:
-//   SRC_C2C   in[g]
-//   SRC_REAL  (x[2g], x[2g+1])            real f32 sequence of src_n samples packed two per complex, zero beyond
-//   SRC_IQPOW (|iq[2g]|^2, |iq[2g+1]|^2)  the same with x = abs2.(iq) formed on the fly (GUI.jl:70)
-enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2 };
-
-__device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g) {
-  if (src_mode == SRC_C2C) return in[g];
-  const unsigned long long i0 = 2ull * g;
-  if (i0 >= src_n) return make_float2(0.f, 0.f);  // zero padding is never read
-  if (src_mode == SRC_REAL) {
-    const float *x = reinterpret_cast<const float *>(in);
-    return make_float2(x[i0], i0 + 1 < src_n ? x[i0 + 1] : 0.f);
-  }
-  const float4 z = reinterpret_cast<const float4 *>(in)[g];  // iq[2g], iq[2g+1]
-  return make_float2(z.x * z.x + z.y * z.y, i0 + 1 < src_n ? z.z * z.z + z.w * z.w : 0.f);
 }
 
 // One pass over a tile of R x T (<= 4096) elements per 256-thread workgroup, 16 elements per thread.
@@ -511,6 +407,10 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   return TSDR_OK;
 }
 
+bool fft_mixed_ok(size_t N);
+int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
+              size_t src_n, size_t keep);
+
 // ---- Bluestein ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chirp(float2 *__restrict__ chirp, unsigned long long n) {
   for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n;
@@ -604,6 +504,15 @@ int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n
       src = out;
     }
     return fft_pow2(ctx, src, out, ilog2(n), batch, d, scale, SRC_C2C, 0, 0);
+  }
+  if (fft_mixed_ok(n)) {  // 2^a 3^b 5^c: native mixed-radix passes (fft_mixed.hip)
+    const float scale = d > 0 ? (float)(1.0 / (double)n) : 1.0f;
+    const float2 *src = reinterpret_cast<const float2 *>(x);
+    if (!is_complex) {
+      TSDR_LAUNCH(ctx, "r2c", k_r2c, dim3(stream_grid(ctx, n * batch)), dim3(256), 0, x, n * batch, out);
+      src = out;
+    }
+    return fft_mixed(ctx, src, out, n, batch, d, scale, SRC_C2C, 0, 0);
   }
   BluesteinPlan *pl = nullptr;
   int rc = get_bluestein(ctx, n, &pl);

@@ -1,0 +1,137 @@
+// fft_dev.h -- device helpers shared by the power-of-two (fft.hip) and mixed-radix (fft_mixed.hip) engines.
+#pragma once
+#include <utility>
+
+#include "common.h"
+
+namespace tsdr {
+
+enum { FFT_STRIDED = 0, FFT_LAST = 1, FFT_ROWS = 2 };
+
+__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+// Forward DFT of N = 2, 4, 8 or 16 points held in registers: radix-2 decimation in frequency with the
+// twiddles as literals (trivial ones special-cased), result in bit-reversed order (X[k] at v[brev<N>(k)]).
+__device__ constexpr float kCos16[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                                        0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+__device__ constexpr float kSin16[8] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f,
+                                        1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f};
+
+template <int N, int I>
+__device__ inline float2 mul_w(float2 d) {  // d * exp(-2*pi*i*I/N), 0 <= I < N/2
+  constexpr int E = I * (16 / N);
+  if constexpr (E == 0) {
+    return d;
+  } else if constexpr (E == 4) {
+    return make_float2(d.y, -d.x);
+  } else if constexpr (E == 2) {
+    return make_float2((d.x + d.y) * kCos16[2], (d.y - d.x) * kCos16[2]);
+  } else if constexpr (E == 6) {
+    return make_float2((d.y - d.x) * kCos16[2], -(d.x + d.y) * kCos16[2]);
+  } else {
+    return make_float2(d.x * kCos16[E] + d.y * kSin16[E], d.y * kCos16[E] - d.x * kSin16[E]);
+  }
+}
+
+template <int N, int I>
+__device__ inline void bfly(float2 *v) {
+  const float2 a = v[I], b = v[I + N / 2];
+  v[I] = cadd(a, b);
+  v[I + N / 2] = mul_w<N, I>(csub(a, b));
+}
+
+template <int N, int... I>
+__device__ inline void dif_stage(float2 *v, std::integer_sequence<int, I...>) {
+  (bfly<N, I>(v), ...);
+}
+
+template <int N>
+__device__ inline void reg_dft(float2 *v) {
+  if constexpr (N >= 2) {
+    dif_stage<N>(v, std::make_integer_sequence<int, N / 2>{});
+    reg_dft<N / 2>(v);
+    reg_dft<N / 2>(v + N / 2);
+  }
+}
+
+template <int N>
+__device__ constexpr int brev(int k) {
+  int r = 0;
+  for (int b = 1; b < N; b <<= 1) { r = (r << 1) | (k & 1); k >>= 1; }
+  return r;
+}
+
+// Twiddles without tables.  A gathered table read costs one L1 tag cycle per distinct line per lane and made
+// the passes gather-bound, so the phase is reduced to an octant o (0..7) plus x in [0, 1] -- exactly, in
+// integers, for power-of-two N -- and sin/cos(pi/4 * x) come from degree-7/8 polynomials (Chebyshev
+// interpolants in x^2; measured error <= 8.6e-8 absolute over all f32 x, i.e. <= 1.5 ulp).
+// tw_octant: exp(-i*pi/4*(o + x)) for even o, exp(-i*pi/4*(o + 1 - x)) for odd o (the caller mirrors x).
+__device__ inline float2 tw_octant(unsigned o, float x) {
+  const float u = x * x;
+  const float sn = fmaf(fmaf(fmaf(-3.595429006963968e-05f, u, 0.0024900068528950214f), u, -0.08074543625116348f), u,
+                        0.7853981852531433f) * x;
+  const float cs = fmaf(fmaf(fmaf(fmaf(3.5297971407999285e-06f, u, -0.0003259385994169861f), u, 0.015854325145483017f), u,
+                             -0.3084251284599304f), u, 1.0f);
+  const bool swap = ((o + 1u) >> 1) & 1u;
+  float cr = swap ? sn : cs, sr = swap ? cs : sn;
+  if ((o + 2u) & 4u) cr = -cr;
+  if (!(o & 4u)) sr = -sr;
+  return make_float2(cr, sr);
+}
+
+// exp(-2*pi*i*e / 2^L) for 0 <= e < 2^L, 2 <= L <= 31
+__device__ inline float2 tw_unit(unsigned e, int L) {
+  const unsigned q = e << (32 - L);
+  const unsigned o = q >> 29;
+  unsigned r = q & 0x1FFFFFFFu;
+  if (o & 1u) r = 0x20000000u - r;
+  return tw_octant(o, (float)r * 0x1p-29f);
+}
+
+// exp(-2*pi*i*q/2^32), and the phase q = floor(2^32 * e/N) (within 2 units) from inv = floor(2^64/N) = hi:lo
+__device__ inline float2 tw_q32(unsigned q) {
+  const unsigned o = q >> 29;
+  unsigned r = q & 0x1FFFFFFFu;
+  if (o & 1u) r = 0x20000000u - r;
+  return tw_octant(o, (float)r * 0x1p-29f);
+}
+__device__ inline unsigned phase_q32(unsigned e, unsigned inv_hi, unsigned inv_lo) {
+  return e * inv_hi + __umulhi(e, inv_lo);
+}
+
+__device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000000 for the inverse transform
+  return make_float2(v.x, __uint_as_float(__float_as_uint(v.y) ^ smask));
+}
+
+// element g of the (single) transform for the fused loaders of the first pass:
+//   SRC_C2C   in[g]
+//   SRC_REAL  (x[2g], x[2g+1])            real f32 sequence of src_n samples packed two per complex, zero beyond
+//   SRC_IQPOW (|iq[2g]|^2, |iq[2g+1]|^2)  the same with x = abs2.(iq) formed on the fly (GUI.jl:70)
+enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2 };
+
+__device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g) {
+  if (src_mode == SRC_C2C) return in[g];
+  const unsigned long long i0 = 2ull * g;
+  if (i0 >= src_n) return make_float2(0.f, 0.f);  // zero padding is never read
+  if (src_mode == SRC_REAL) {
+    const float *x = reinterpret_cast<const float *>(in);
+    return make_float2(x[i0], i0 + 1 < src_n ? x[i0 + 1] : 0.f);
+  }
+  const float4 z = reinterpret_cast<const float4 *>(in)[g];  // iq[2g], iq[2g+1]
+  return make_float2(z.x * z.x + z.y * z.y, i0 + 1 < src_n ? z.z * z.z + z.w * z.w : 0.f);
+}
+
+// exp(-2*pi*i*e/N) for any N: inv_n = 1/N in f64, 0 <= e < N.  The phase e/N is formed in f64 (relative
+// error 2^-52), so the octant split is exact to ~1e-16 of a turn.
+__device__ inline float2 tw_frac(unsigned e, double inv_n8) {  // inv_n8 = 8/N
+  const double ph = (double)e * inv_n8;
+  const unsigned o = (unsigned)ph;
+  const double f = ph - (double)o;
+  const float x = (float)((o & 1u) ? 1.0 - f : f);
+  return tw_octant(o & 7u, x);
+}
+
+}  // namespace tsdr

@@ -1,0 +1,505 @@
+// fft_mixed.hip -- complex f32 FFT for lengths N = 2^a * 3^b * 5^c (FFTW.jl fft/ifft semantics).
+//
+// Sample rates in this domain are decimal (20 MS/s, 200 MS/s ...), so the transform lengths the reference asks
+// for -- two refresh periods of samples for the autocorrelation (Autocorrelations.jl:27), spectrum windows,
+// resampler blocks -- are of the form 2^a * 5^b far more often than 2^a (4e6 = 2^8 * 5^6).  Padding such a length
+// to a power of two doubles the bytes every pass moves; this engine transforms it natively.
+//
+// Same multi-pass structure as fft.hip: N = R_1 * ... * R_p with every R_i <= 256, one launch per factor, pass
+// i < p a length-R_i DFT at stride B_i = R_{i+1}..R_p followed by the twiddle W_{P_i R_i R_{i+1}}^(n_{i+1} K),
+// the last pass contiguous and written in natural order.  The differences:
+//   * the radices are arbitrary, so tile coordinates come from integer divisions by launch constants instead of
+//     shifts, tiles are ragged at the end of a row, and twiddle phases e/N are 32-bit fixed-point fractions from a
+//     64-bit reciprocal (phase_q32);
+//   * inside a tile the length-R DFT is an in-place decimation-in-frequency over LDS with stage radices
+//     from {2, 3, 4, 5, 8, 9, 10, 16, 25} (register DFTs), and the mixed-radix digit reversal is undone through a
+//     position -> frequency map while storing.
+// The factors are ordered so that the last one carries the factors of two: every stride B_i is then a multiple
+// of 16 elements and the T-wide runs of a tile stay 128-byte aligned.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "fft_dev.h"
+
+namespace tsdr {
+
+enum { MIX_MAX_PASS = 6, MIX_MAX_STAGE = 8 };
+
+struct MixDesc {
+  int mode, dir, logT, nst;
+  float scale;
+  unsigned R;
+  unsigned char rad[MIX_MAX_STAGE];  // stage radices, product R
+  unsigned long long N;              // elements per transform
+  unsigned A, B, tiles;              // strided: outer count, inner size (= stride of the DFT index), ceil(B/T)
+  unsigned Bnext, Pprev;             // B / R_{i+1};  R_1..R_{i-1}
+  unsigned ntw_hi, ntw_lo;           // floor(2^64 / (Pprev * R * R_{i+1})): twiddle phase e/Ntw as a 32-bit fraction
+  unsigned r_hi, r_lo;               // floor(2^64 / R)
+  int nprev;
+  unsigned Rprev[MIX_MAX_PASS], Wprev[MIX_MAX_PASS];  // radices of the earlier passes and their weights in k
+  unsigned R1, Aprime, k1tiles;      // last pass: first radix, A / R_1, ceil(R_1 / T)
+  unsigned rows;                     // rows mode: number of transforms
+  int src_mode;
+  unsigned long long src_n, keep;
+};
+
+// a = k_1*(R_2..R_m) + ... + k_m  ->  k_1*W_1 + ... + k_m*W_m  (uniform per workgroup: scalar code)
+__device__ inline unsigned digit_swap_g(unsigned a, int m, const unsigned *R, const unsigned *W) {
+  unsigned K = 0;
+  for (int j = m - 1; j >= 0; --j) {
+    const unsigned q = a / R[j];
+    K += (a - q * R[j]) * W[j];
+    a = q;
+  }
+  return K;
+}
+
+// x * exp(-2*pi*i*K/N) with the constant taken from a literal table
+__device__ constexpr float kCos25[17] = {1.f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f,
+    0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f, -0.63742398974868975f,
+    -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f, -0.99211470131447788f, -0.92977648588825146f,
+    -0.80901699437494778f, -0.63742398974868952f};
+__device__ constexpr float kSin25[17] = {0.f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f,
+    0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f, 0.77051324277578925f,
+    0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f, -0.12533323356430429f, -0.36812455268467792f,
+    -0.58778525229247269f, -0.77051324277578936f};
+__device__ constexpr float kCos10[5] = {1.f, 0.80901699437494745f, 0.30901699437494745f, -0.30901699437494734f, -0.80901699437494734f};
+__device__ constexpr float kSin10[5] = {0.f, 0.58778525229247314f, 0.95105651629515353f, 0.95105651629515364f, 0.58778525229247325f};
+__device__ constexpr float kCos9[5] = {1.f, 0.76604444311897801f, 0.17364817766693041f, -0.5f, -0.93969262078590832f};
+__device__ constexpr float kSin9[5] = {0.f, 0.64278760968653925f, 0.98480775301220802f, 0.86602540378443871f, 0.34202014332566888f};
+
+template <int N, int K>
+__device__ inline float2 mul_c(float2 x) {
+  if constexpr (K == 0) {
+    return x;
+  } else {
+    constexpr float c = N == 25 ? kCos25[K] : N == 10 ? kCos10[K] : kCos9[K];
+    constexpr float sn = N == 25 ? kSin25[K] : N == 10 ? kSin10[K] : kSin9[K];
+    return make_float2(x.x * c + x.y * sn, x.y * c - x.x * sn);
+  }
+}
+
+// forward DFT of r points, natural order, in place
+template <int r>
+__device__ inline void dft_nat(float2 *x);
+
+// r = P*Q as two register steps: n = Q'*a + b ... X[c + P*d] = sum_b W_Q^(b d) W_r^(b c) sum_a W_P^(a c) x[Q*a + b]
+template <int P, int Q, int B, int... C>
+__device__ inline void two_step_col(const float2 *x, float2 *y, std::integer_sequence<int, C...>) {
+  float2 t[P];
+#pragma unroll
+  for (int a = 0; a < P; ++a) t[a] = x[Q * a + B];
+  dft_nat<P>(t);
+  ((y[Q * C + B] = mul_c<P * Q, B * C>(t[C])), ...);
+}
+template <int P, int Q, int... B>
+__device__ inline void two_step_cols(const float2 *x, float2 *y, std::integer_sequence<int, B...>) {
+  (two_step_col<P, Q, B>(x, y, std::make_integer_sequence<int, P>{}), ...);
+}
+template <int P, int Q>
+__device__ inline void dft_two_step(float2 *x) {
+  float2 y[P * Q];
+  two_step_cols<P, Q>(x, y, std::make_integer_sequence<int, Q>{});  // y[Q*c + b]
+#pragma unroll
+  for (int c = 0; c < P; ++c) {
+    float2 t[Q];
+#pragma unroll
+    for (int b = 0; b < Q; ++b) t[b] = y[Q * c + b];
+    dft_nat<Q>(t);
+#pragma unroll
+    for (int d = 0; d < Q; ++d) x[c + P * d] = t[d];
+  }
+}
+
+template <int r>
+__device__ inline void dft_nat(float2 *x) {
+  if constexpr (r == 3) {
+    const float s = 0.86602540378443865f;
+    const float2 t = cadd(x[1], x[2]), d = csub(x[1], x[2]);
+    const float2 m = make_float2(x[0].x - 0.5f * t.x, x[0].y - 0.5f * t.y);
+    const float2 q = make_float2(s * d.y, -s * d.x);  // -i*s*d
+    x[0] = cadd(x[0], t);
+    x[1] = cadd(m, q);
+    x[2] = csub(m, q);
+  } else if constexpr (r == 5) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]), b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
+    const float2 p1 = make_float2(x[0].x + (c1 * a1.x + c2 * a2.x), x[0].y + (c1 * a1.y + c2 * a2.y));
+    const float2 p2 = make_float2(x[0].x + (c2 * a1.x + c1 * a2.x), x[0].y + (c2 * a1.y + c1 * a2.y));
+    const float2 q1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const float2 q2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    x[0] = cadd(x[0], cadd(a1, a2));
+    x[1] = make_float2(p1.x + q1.y, p1.y - q1.x);  // p1 - i q1
+    x[4] = make_float2(p1.x - q1.y, p1.y + q1.x);
+    x[2] = make_float2(p2.x + q2.y, p2.y - q2.x);
+    x[3] = make_float2(p2.x - q2.y, p2.y + q2.x);
+  } else if constexpr (r == 25) {
+    dft_two_step<5, 5>(x);
+  } else if constexpr (r == 10) {
+    dft_two_step<5, 2>(x);
+  } else if constexpr (r == 9) {
+    dft_two_step<3, 3>(x);
+  } else {
+    reg_dft<r>(x);
+    float2 y[r];
+#pragma unroll
+    for (int c = 0; c < r; ++c) y[c] = x[brev<r>(c)];
+#pragma unroll
+    for (int c = 0; c < r; ++c) x[c] = y[c];
+  }
+}
+
+// One DIF stage of radix r on sub-transforms of length L: for every group g and j < Q = L/r
+//   y_c = sum_m x[g*L + j + m*Q] W_r^(m c),   x[g*L + j + c*Q] <- y_c * W_L^(j c)
+template <int r>
+__device__ inline void mix_stage(float2 *buf, const float2 *twR, unsigned R, unsigned L, int logT, int TP, int tid) {
+  const unsigned Q = L / r, step = R / L;
+  const unsigned nb = (R / r) << logT;
+  const unsigned T = 1u << logT;
+  const float invQ = 1.0f / (float)Q;
+  for (unsigned w = tid; w < nb; w += 256) {
+    const unsigned t = w & (T - 1u), u = w >> logT;
+    const unsigned g = (unsigned)(((float)u + 0.5f) * invQ), j = u - g * Q;  // u < 4096: exact
+    float2 *p = buf + (g * L + j) * TP + t;
+    float2 x[r];
+#pragma unroll
+    for (int m = 0; m < r; ++m) x[m] = p[m * Q * TP];
+    dft_nat<r>(x);
+    p[0] = x[0];
+    if (Q > 1) {
+#pragma unroll
+      for (int c = 1; c < r; ++c) p[c * Q * TP] = cmul(x[c], twR[j * c * step]);
+    } else {
+#pragma unroll
+      for (int c = 1; c < r; ++c) p[c * TP] = x[c];
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ in, float2 *__restrict__ out, MixDesc d) {
+  extern __shared__ float2 sm[];
+  const unsigned R = d.R;
+  const int logT = d.logT, TP = (1 << logT) + 1;
+  const unsigned T = 1u << logT;
+  float2 *buf = sm;
+  float2 *twR = sm + R * TP;
+  unsigned short *kmap = reinterpret_cast<unsigned short *>(twR + R);  // position after the stages -> frequency
+  const int tid = threadIdx.x;
+  const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
+  for (unsigned e = tid; e < R; e += 256) {
+    twR[e] = tw_q32(phase_q32(e, d.r_hi, d.r_lo));
+    unsigned rem = e, k = 0, mult = 1, L = R;
+    for (int s = 0; s < d.nst; ++s) {
+      const unsigned r = d.rad[s], Q = L / r, dig = rem / Q;
+      rem -= dig * Q;
+      k += dig * mult;
+      mult *= r;
+      L = Q;
+    }
+    kmap[e] = (unsigned short)k;
+  }
+  const unsigned bid = blockIdx.x;
+  const unsigned work = R << logT;
+  const float invR = 1.0f / (float)R;
+  constexpr int NB = 8;
+
+  size_t base = 0, tbase = 0, row0 = 0;
+  unsigned tile = 0, a = 0, kt = 0, arest = 0, col0 = 0;
+  if (d.mode == FFT_STRIDED) {
+    tile = bid % d.tiles;
+    a = (bid / d.tiles) % d.A;
+    const unsigned b = bid / (d.tiles * d.A);
+    col0 = tile * T;
+    base = (size_t)b * d.N + (size_t)a * R * d.B + col0;
+    for (unsigned w0 = tid; w0 < work; w0 += 256 * NB) {
+      float2 v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const unsigned w = w0 + 256 * u;
+        const unsigned t = w & (T - 1u), j = w >> logT;
+        v[u] = (w < work && col0 + t < d.B) ? fft_load(in, d.src_mode, d.src_n, base + (size_t)j * d.B + t)
+                                             : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const unsigned w = w0 + 256 * u;
+        if (w < work) buf[(w >> logT) * TP + (w & (T - 1u))] = conj_if(v[u], smask);
+      }
+    }
+  } else {
+    if (d.mode == FFT_LAST) {
+      kt = bid % d.k1tiles;
+      arest = (bid / d.k1tiles) % d.Aprime;
+      tbase = (size_t)(bid / (d.k1tiles * d.Aprime)) * d.N;
+    } else {
+      row0 = (size_t)bid * T;
+    }
+    for (unsigned w0 = tid; w0 < work; w0 += 256 * NB) {
+      float2 v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const unsigned w = min(w0 + 256 * u, work - 1u);
+        const unsigned t = (unsigned)(((float)w + 0.5f) * invR), j = w - t * R;  // w < 2^13: exact
+        if (d.mode == FFT_LAST) {
+          const unsigned k1 = kt * T + t;
+          v[u] = k1 < d.R1 ? in[tbase + ((size_t)k1 * d.Aprime + arest) * R + j] : make_float2(0.f, 0.f);
+        } else {
+          const size_t row = row0 + t;
+          v[u] = row < d.rows ? in[row * R + j] : make_float2(0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const unsigned w = w0 + 256 * u;
+        if (w < work) {
+          const unsigned t = (unsigned)(((float)w + 0.5f) * invR), j = w - t * R;
+          buf[j * TP + t] = conj_if(v[u], smask);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  unsigned L = R;
+  for (int s = 0; s < d.nst; ++s) {
+    const unsigned r = d.rad[s];
+    switch (r) {
+      case 2: mix_stage<2>(buf, twR, R, L, logT, TP, tid); break;
+      case 3: mix_stage<3>(buf, twR, R, L, logT, TP, tid); break;
+      case 4: mix_stage<4>(buf, twR, R, L, logT, TP, tid); break;
+      case 5: mix_stage<5>(buf, twR, R, L, logT, TP, tid); break;
+      case 8: mix_stage<8>(buf, twR, R, L, logT, TP, tid); break;
+      case 9: mix_stage<9>(buf, twR, R, L, logT, TP, tid); break;
+      case 10: mix_stage<10>(buf, twR, R, L, logT, TP, tid); break;
+      case 25: mix_stage<25>(buf, twR, R, L, logT, TP, tid); break;
+      default: mix_stage<16>(buf, twR, R, L, logT, TP, tid); break;
+    }
+    L /= r;
+  }
+
+  if (d.mode == FFT_STRIDED) {
+    const unsigned Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
+    const unsigned t = tid & (T - 1u);  // T <= 256: fixed per thread
+    const unsigned col = col0 + t;
+    const unsigned nnext = col / d.Bnext;
+    if (col < d.B) {
+      for (unsigned w0 = tid; w0 < work; w0 += 256 * NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const unsigned w = w0 + 256 * u;
+          if (w < work) {
+            const unsigned p = w >> logT, k = kmap[p];
+            const float2 tw = tw_q32(phase_q32(nnext * (Ka + k * d.Pprev), d.ntw_hi, d.ntw_lo));
+            out[base + (size_t)k * d.B + t] = conj_if(cmul(buf[p * TP + t], tw), smask);
+          }
+        }
+      }
+    }
+  } else if (d.mode == FFT_LAST) {
+    // digits k_2..k_{p-1} of arest -> their natural-order weight
+    const unsigned Kp = digit_swap_g(arest, d.nprev - 1, d.Rprev + 1, d.Wprev + 1);
+    const unsigned t = tid & (T - 1u);
+    const unsigned k1 = kt * T + t;
+    if (k1 < d.R1) {
+      const size_t orel = (size_t)k1 + Kp;
+      for (unsigned w = tid; w < work; w += 256) {
+        const unsigned p = w >> logT, k = kmap[p];
+        const size_t o = orel + (size_t)k * d.Pprev;
+        if (o < d.keep) {
+          const float2 x = buf[p * TP + t];
+          out[tbase + o] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+        }
+      }
+    }
+  } else {
+    for (unsigned w = tid; w < work; w += 256) {
+      const unsigned t = (unsigned)(((float)w + 0.5f) * invR), p = w - t * R;
+      const size_t row = row0 + t;
+      if (row < d.rows) {
+        const float2 x = buf[p * TP + t];
+        out[row * R + kmap[p]] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+      }
+    }
+  }
+}
+
+// ---- planning --------------------------------------------------------------------------------
+struct MixPlan {
+  int p = 0;
+  unsigned R[MIX_MAX_PASS];
+  std::vector<unsigned char> rad[MIX_MAX_PASS];
+};
+
+static void stage_radices(unsigned e2, unsigned e3, unsigned e5, std::vector<unsigned char> &out) {
+  out.clear();
+  while (e5 >= 2) { out.push_back(25); e5 -= 2; }
+  if (e5) {
+    if (e2) { out.push_back(10); --e2; } else out.push_back(5);
+  }
+  while (e3 >= 2) { out.push_back(9); e3 -= 2; }
+  if (e3) out.push_back(3);
+  while (e2 >= 4) { out.push_back(16); e2 -= 4; }
+  if (e2 == 3) out.push_back(8);
+  if (e2 == 2) out.push_back(4);
+  if (e2 == 1) out.push_back(2);
+}
+
+// true when N = 2^a 3^b 5^c (N >= 2) and a pass split with every factor <= 256 exists
+bool fft_mixed_plan(size_t N, MixPlan *plan) {
+  if (N < 2 || N >= (size_t(1) << 31)) return false;
+  unsigned ex[3] = {0, 0, 0};
+  const unsigned pr[3] = {2, 3, 5};
+  size_t m = N;
+  for (int i = 0; i < 3; ++i)
+    while (m % pr[i] == 0) { m /= pr[i]; ++ex[i]; }
+  if (m != 1) return false;
+  const int pmin = std::max(1, (int)std::ceil(std::log((double)N) / std::log(256.0) - 1e-9));
+  for (int p = pmin; p <= MIX_MAX_PASS; ++p) {
+    unsigned prod[MIX_MAX_PASS], e[MIX_MAX_PASS][3];
+    for (int i = 0; i < p; ++i) { prod[i] = 1; e[i][0] = e[i][1] = e[i][2] = 0; }
+    unsigned left[3] = {ex[0], ex[1], ex[2]};
+    // the last factor takes up to four 2s first, so that every stride is a multiple of 16 elements
+    if (p > 1) {
+      const unsigned k = std::min(left[0], 4u);
+      prod[p - 1] <<= k;
+      e[p - 1][0] = k;
+      left[0] -= k;
+    }
+    bool ok = true;
+    for (int pi = 2; pi >= 0 && ok; --pi) {  // 5s, then 3s, then 2s: each into the smallest factor so far
+      while (left[pi] && ok) {
+        int best = -1;
+        for (int i = 0; i < p; ++i)
+          if (prod[i] * pr[pi] <= 256 && (best < 0 || prod[i] < prod[best])) best = i;
+        if (best < 0) { ok = false; break; }
+        prod[best] *= pr[pi];
+        ++e[best][pi];
+        --left[pi];
+      }
+    }
+    if (!ok) continue;
+    plan->p = p;
+    for (int i = 0; i < p; ++i) {
+      plan->R[i] = prod[i];
+      stage_radices(e[i][0], e[i][1], e[i][2], plan->rad[i]);
+      if (plan->rad[i].size() > MIX_MAX_STAGE) { ok = false; break; }
+    }
+    if (ok) return true;
+  }
+  return false;
+}
+
+bool fft_mixed_ok(size_t N) {
+  MixPlan pl;
+  return fft_mixed_plan(N, &pl);
+}
+
+static int floor_log2(unsigned v) { int l = 0; while ((2u << l) <= v) ++l; return l; }
+static int ceil_log2(unsigned v) { int l = 0; while ((1u << l) < v) ++l; return l; }
+
+// Tile width: as wide as 4096 elements allow, narrowed (not below 16 columns = 128-byte runs) until the launch has
+// enough workgroups to keep several resident per CU -- a workgroup is a chain of dependent LDS stages, and with one
+// or two of them per CU nothing hides that latency.
+static int pick_logT(int maxlog, int minlog, size_t other, size_t span) {
+  int logT = std::max(maxlog, 0);
+  while (logT > minlog && other * ceil_div(span, (size_t)1 << logT) < 2048) --logT;
+  return logT;
+}
+
+static size_t mix_lds(unsigned R, int logT) {
+  return ((size_t)R * ((1u << logT) + 1) + R) * sizeof(float2) + ((size_t)R * 2 + 15) / 16 * 16;
+}
+
+// in/out may alias.  Uses WS_FFT_B when more than one pass is needed (callers must not hand WS_FFT_B buffers in).
+// src_mode/src_n: fused first-pass loader (fft_dev.h), batch == 1 and p > 1 only; keep: complex outputs per
+// transform the caller will look at (0 = all).
+int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
+              size_t src_n, size_t keep) {
+  MixPlan pl;
+  if (!fft_mixed_plan(N, &pl)) return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
+  if (batch == 0) return TSDR_OK;
+  if (N * batch >= (size_t(1) << 40)) return set_err(ctx, TSDR_EINVAL, "fft: batch too large");
+  const int p = pl.p;
+  if (src_mode != SRC_C2C && (batch != 1 || p == 1)) return set_err(ctx, TSDR_EINVAL, "fft: fused loader needs one multi-pass transform");
+  MixDesc d{};
+  d.dir = dir < 0 ? -1 : 1;
+  d.N = N;
+  d.src_mode = SRC_C2C;
+  d.keep = keep ? keep : N;
+  auto set_radix = [&](int i) {
+    d.R = pl.R[i];
+    d.nst = (int)pl.rad[i].size();
+    for (int s = 0; s < d.nst; ++s) d.rad[s] = pl.rad[i][s];
+    const unsigned __int128 inv = ((unsigned __int128)1 << 64) / d.R;
+    d.r_hi = (unsigned)(inv >> 32);
+    d.r_lo = (unsigned)inv;
+  };
+  if (p == 1) {
+    d.mode = FFT_ROWS;
+    set_radix(0);
+    d.logT = pick_logT(std::min(8, floor_log2(4096u / d.R)), 0, 1, batch);
+    d.scale = scale;
+    d.rows = (unsigned)batch;
+    if (batch >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "fft: too many rows");
+    const unsigned grid = (unsigned)ceil_div(batch, (size_t)1 << d.logT);
+    TSDR_LAUNCH(ctx, "fftm_rows", k_fft_mix, dim3(grid), dim3(256), mix_lds(d.R, d.logT), in, out, d);
+    return TSDR_OK;
+  }
+  float2 *work = (float2 *)ctx->scratch(WS_FFT_B, N * batch * sizeof(float2));
+  if (!work) return TSDR_ENOMEM;
+  size_t P = 1;  // R_1..R_{i-1}
+  size_t B = N;
+  const float2 *src = in;
+  static const char *const kStridedName[MIX_MAX_PASS] = {"fftm_strided1", "fftm_strided2", "fftm_strided3",
+                                                         "fftm_strided4", "fftm_strided5", "fftm_strided6"};
+  for (int i = 0; i < p - 1; ++i) {
+    set_radix(i);
+    B /= d.R;
+    d.mode = FFT_STRIDED;
+    d.src_mode = i == 0 ? src_mode : SRC_C2C;
+    d.src_n = src_n;
+    d.logT = pick_logT(std::min({8, floor_log2(4096u / d.R), ceil_log2((unsigned)B)}), 4, batch * P, B);
+    d.scale = 1.0f;
+    d.A = (unsigned)P;
+    d.B = (unsigned)B;
+    d.tiles = (unsigned)ceil_div(B, (size_t)1 << d.logT);
+    d.Bnext = (unsigned)(B / pl.R[i + 1]);
+    d.Pprev = (unsigned)P;
+    {
+      const unsigned __int128 inv = ((unsigned __int128)1 << 64) / ((unsigned __int128)P * d.R * pl.R[i + 1]);
+      d.ntw_hi = (unsigned)(inv >> 32);
+      d.ntw_lo = (unsigned)inv;
+    }
+    d.nprev = i;
+    size_t wgt = 1;
+    for (int j = 0; j < i; ++j) { d.Rprev[j] = pl.R[j]; d.Wprev[j] = (unsigned)wgt; wgt *= pl.R[j]; }
+    const size_t grid = batch * d.A * d.tiles;
+    if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
+    TSDR_LAUNCH(ctx, kStridedName[i], k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), src, work, d);
+    src = work;
+    P *= d.R;
+  }
+  set_radix(p - 1);
+  d.mode = FFT_LAST;
+  d.src_mode = SRC_C2C;
+  d.R1 = pl.R[0];
+  d.logT = pick_logT(std::min({8, floor_log2(4096u / d.R), ceil_log2(d.R1)}), 4, batch * (P / pl.R[0]), d.R1);
+  d.scale = scale;
+  d.Pprev = (unsigned)P;
+  d.nprev = p - 1;
+  {
+    size_t wgt = 1;
+    for (int j = 0; j < p - 1; ++j) { d.Rprev[j] = pl.R[j]; d.Wprev[j] = (unsigned)wgt; wgt *= pl.R[j]; }
+  }
+  d.Aprime = (unsigned)(P / pl.R[0]);
+  d.k1tiles = (unsigned)ceil_div((size_t)d.R1, (size_t)1 << d.logT);
+  const size_t grid = batch * d.Aprime * d.k1tiles;
+  if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
+  TSDR_LAUNCH(ctx, "fftm_last", k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), (const float2 *)work, out, d);
+  return TSDR_OK;
+}
+
+}  // namespace tsdr

@@ -100,6 +100,7 @@ struct TileParams {
   int h_out, w_out;     // DOWN only
   int NR, NC;           // DOWN: candidate output rows / columns per tile
   int lpl_log;          // log2(lanes per line) of the staging loop
+  int cs;               // k_raster_fast: consecutive samples per staging lane (<= 4)
   int xcd_group;        // neighbouring pixel strips dealt to the same XCD
   int xcd_group_log;    // log2(xcd_group)
   float inv_tiles_p;    // 1/tiles_p (unit -> frame, strip without an integer division)
@@ -130,15 +131,49 @@ __device__ inline void fast_walk(const FastAx &fa, const double2 *__restrict__ r
   }
 }
 
-template <bool CPLX, bool EXACT, bool DOWN>
+// The same walk in f32 (D < 2^24, so r is an exact f32 integer and is carried as one): the staged slope
+// (b - a)/D is split into hi + lo f32 halves (48 significant bits), and a pixel is
+//     fma(r, lo, fma(r, hi, a)).
+// The inner FMA rounds the exact a + r*hi once, at the magnitude of the result; the outer one adds the
+// 2^-24-relative remainder of the product and rounds again: <= 1 ulp of the result whatever |b - a| is (a
+// plain f32 slope would carry its 2^-24 relative error into r*(b - a), which can dwarf the result).  Measured
+// on gfx950 (tools/ubench): cvt_f64_i32 + fma_f64 + cvt_f32_f64 issue in ~6.6 f32-FMA slots, two f32 FMAs in 2.
+template <bool CLAMP, bool DOWN, bool OUT>
+__device__ inline void fast_walk32(const FastAx &fa, const float4 *__restrict__ row, int kf, int k, unsigned r, int npx,
+                                   float *__restrict__ o, size_t ostride, float *__restrict__ trow) {
+  const float rstep = (float)fa.rstep, Df = (float)fa.D;
+  float rf = (float)r;
+  float4 s = row[(CLAMP ? max(k, 0) : k) - kf];
+  float re = CLAMP ? (k < 0 ? 0.f : rf) : rf;
+#pragma unroll 2
+  for (int i = 0; i < npx; ++i) {
+    const float r2 = rf + rstep;
+    const bool c = r2 >= Df;
+    k += (int)fa.qstep + (c ? 1 : 0);
+    rf = c ? r2 - Df : r2;
+    const float4 sn = row[(CLAMP ? max(k, 0) : k) - kf];
+    const float v = fmaf(re, s.z, fmaf(re, s.y, s.x));
+    if (OUT) { if (!CLAMP || o) { *o = v; o += ostride; } }
+    if (DOWN) { *trow = v; trow += 65; }
+    s = sn;
+    re = CLAMP ? (k < 0 ? 0.f : rf) : rf;
+  }
+}
+
+// arithmetic of the tile kernel: the oracle's IEEE sequence, the FAST walk in f64, the FAST walk in f32
+enum { AR_EXACT = 0, AR_FAST64 = 1, AR_FAST32 = 2 };
+
+template <bool CPLX, int AR, bool DOWN>
 __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ in, size_t in_stride, TileParams q,
                                                      FastAx fa, float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
+  constexpr bool EXACT = AR == AR_EXACT, F32W = AR == AR_FAST32;
   extern __shared__ double lds_d[];
   const int Wp = q.W | 1;
-  // staged samples: EXACT [64][Wp] f32 ; FAST [64][Wp] {a, (b-a)/D} f64 pairs
+  // staged samples: EXACT [64][Wp] f32 ; FAST64 [64][Wp] {a, (b-a)/D} f64 pairs ; FAST32 [64][Wp] {a, hi, lo, -} f32
   float *smp = reinterpret_cast<float *>(lds_d);
   double2 *smp2 = reinterpret_cast<double2 *>(lds_d);
+  float4 *smp4 = reinterpret_cast<float4 *>(lds_d);
   char *after = reinterpret_cast<char *>(lds_d) + (size_t)64 * Wp * (EXACT ? 4 : 16);
   after += (16 - ((size_t)after & 15)) & 15;
   // candidate tables (DOWN): doubles first (alignment), then ints, then the raster tile
@@ -247,6 +282,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
           if (j < q.W) {
             const float a = CPLX ? abs_iq<EXACT>(re[u], im[u]) : re[u];
             if (EXACT) smp[r * Wp + j] = a;
+            else if (F32W) smp4[r * Wp + j].x = a;
             else smp2[r * Wp + j].x = (double)a;
           }
         }
@@ -258,8 +294,16 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
     for (int r = sub; r < 64; r += nsub)
-      for (int j = j0; j + 1 < q.W; j += lpl)
-        smp2[r * Wp + j].y = (smp2[r * Wp + j + 1].x - smp2[r * Wp + j].x) * fa.invDd;
+      for (int j = j0; j + 1 < q.W; j += lpl) {
+        if (F32W) {
+          const double sl = ((double)smp4[r * Wp + j + 1].x - (double)smp4[r * Wp + j].x) * fa.invDd;
+          const float hi = (float)sl;
+          smp4[r * Wp + j].y = hi;
+          smp4[r * Wp + j].z = (float)(sl - (double)hi);
+        } else {
+          smp2[r * Wp + j].y = (smp2[r * Wp + j + 1].x - smp2[r * Wp + j].x) * fa.invDd;
+        }
+      }
     __syncthreads();
   }
   {
@@ -286,14 +330,21 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
           if (DOWN) { *trow = v; trow += 65; }
         }
       } else {
-        const double2 *row = smp2 + lane * Wp;
         int k; unsigned r;
         fast_pos(fa, flat0, k, r);
         // x0 < 0 only for the very first pixels of a frame: a tile-uniform test picks the clamping walk
         const long long num0 = (long long)(2ull * ((unsigned long long)l0 * q.x_t + p0) + 1ull) * (long long)fa.S - (long long)fa.P;
-        if (num0 < 0) fast_walk<true, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-        else if (o) fast_walk<false, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-        else fast_walk<false, DOWN, false>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+        if (F32W) {
+          const float4 *row = smp4 + lane * Wp;
+          if (num0 < 0) fast_walk32<true, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+          else if (o) fast_walk32<false, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+          else fast_walk32<false, DOWN, false>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+        } else {
+          const double2 *row = smp2 + lane * Wp;
+          if (num0 < 0) fast_walk<true, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+          else if (o) fast_walk<false, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+          else fast_walk<false, DOWN, false>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
+        }
       }
     }
   }
@@ -320,6 +371,13 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
         const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
         const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
         v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
+      } else if (F32W) {
+        // non-negative taps: every step is a convex blend, so the f32 differences and FMAs each stay within an
+        // ulp of the running value (the f64 form below costs ~4x the issue slots on this SIMD)
+        const float dxf = (float)dx, dyf = (float)dy;
+        const float top = fmaf(dxf, R01 - R00, R00);
+        const float bot = fmaf(dxf, R11 - R10, R10);
+        v = fmaf(dyf, bot - top, top);
       } else {
         const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
         const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
@@ -327,6 +385,334 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       }
       dn[(size_t)c * q.h_out + r] = v;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_raster_fast: the FAST-mode tile kernel (same tiling, launch order and coordinate arithmetic as
+// k_raster_tile, which keeps the EXACT mode).  What is different, and why: counters on the C2 buffer show the
+// tile kernel issue-bound on VALU instructions (~550 per thread, only a third of them in the pixel walk) and
+// held to five workgroups per CU by LDS.  So here
+//   * the source position of a tile / line / wave segment is advanced from the frame origin with 32-bit
+//     multiply-adds and a float-reciprocal quotient (adv32) instead of two 64-bit/f64 floor divisions per thread;
+//   * a staging thread owns CONTIGUOUS samples of its line and forms the slopes in registers, so the staged
+//     {a, slope} records are written once -- no second pass over LDS and one barrier less;
+//   * the downgraded image is produced INSIDE the walk, from registers: a lane walks one raster line, so the four
+//     taps of an output pixel are this lane's previous and current pixel and the same two of the lane below
+//     (one ds_bpermute each).  Which pixel steps complete an output column is a wave-uniform bit mask; which
+//     lanes own an output row is a per-lane flag.  The 16.6 KiB raster tile in LDS, its store per pixel, the
+//     separate downgrade loop and its barrier are gone, and eight workgroups fit per CU.
+// The inverse maps (raster line -> output row, raster pixel -> output column) need source/destination ratios
+// strictly above 1 on both axes, so that a line (pixel) is the top-left tap of at most one row (column).
+// ------------------------------------------------------------------------------------------------------------
+struct FastInc {
+  unsigned qL, rL;    // advance of (k, r) per raster line       : 2*x_t*S       = qL*D + rL
+  unsigned qTL, rTL;  // per tile row (own_l lines)
+  unsigned qTP, rTP;  // per tile column (own_p pixels)
+  int k00;            // position of pixel 0 of a frame: floor((S - P)/D) ...
+  unsigned r00;       // ... and remainder
+  float invD;
+};
+
+static inline FastInc fast_inc(size_t S, size_t P, int x_t, int own_l, int own_p) {
+  FastInc n;
+  const long long D = 2 * (long long)P;
+  auto split = [&](long long delta, unsigned &q, unsigned &r) { q = (unsigned)(delta / D); r = (unsigned)(delta % D); };
+  split(2LL * x_t * (long long)S, n.qL, n.rL);
+  split(2LL * x_t * (long long)S * own_l, n.qTL, n.rTL);
+  split(2LL * (long long)S * own_p, n.qTP, n.rTP);
+  const long long num = (long long)S - (long long)P;
+  long long q = num / D;
+  if (num % D < 0) --q;
+  n.k00 = (int)q;
+  n.r00 = (unsigned)(num - q * D);
+  n.invD = 1.0f / (float)D;
+  return n;
+}
+
+// (k, r) += m*(q, rr) with r kept in [0, D); needs r + m*rr < 2^32 (host-checked) and D < 2^24
+__device__ inline void adv32(int &k, unsigned &r, unsigned m, unsigned q, unsigned rr, unsigned D, float invD) {
+  const unsigned t = r + m * rr;
+  unsigned c = (unsigned)((float)t * invD);  // floor(t/D) within +-1
+  int rem = (int)(t - c * D);
+  if (rem < 0) { rem += (int)D; --c; }
+  else if ((unsigned)rem >= D) { rem -= (int)D; ++c; }
+  k += (int)(m * q + c);
+  r = (unsigned)rem;
+}
+
+// output row/column whose top-left tap is source index l (-1: none); sf > 1 makes it unique.  The first guess is
+// the smallest c with sf*(c + 0.5) - 0.5 >= l; rs_pos decides, and a miss by rounding moves one step.
+__device__ inline int inv_tap(const RsAxis &a, double inv_sf, int l, int n_out, double &d) {
+  int c = (int)ceil(((double)l + 0.5) * inv_sf - 0.5);
+  c = min(max(c, 0), n_out - 1);
+  int k = (int)rs_pos(a, (double)(c + 1), d);
+  if (k == l) return c;
+  c += k > l ? -1 : 1;
+  if (c < 0 || c >= n_out) return -1;
+  k = (int)rs_pos(a, (double)(c + 1), d);
+  return k == l ? c : -1;
+}
+
+struct DownInfo {   // per-lane / per-wave state of the in-walk downgrade
+  unsigned long long colmask;  // bit j: the segment pixel j is the left tap of an output column
+  int ccol;                    // lane j: that column
+  float cdx; double cdxd;      // lane j: its weight (F32W / f64 walk)
+  int rrow;                    // this lane's output row (-1: none)
+  float rdy; double rdyd;
+  int below;                   // ds_bpermute address of the lane below
+  float *dn;                   // frame base of the (h_out, w_out) image
+  int h_out;
+};
+
+template <bool F32W>
+__device__ inline void down_event(const DownInfo &di, int j, float R00, float R01) {
+  const int c = __builtin_amdgcn_readlane(di.ccol, j);
+  const float R10 = __int_as_float(__builtin_amdgcn_ds_bpermute(di.below, __float_as_int(R00)));
+  const float R11 = __int_as_float(__builtin_amdgcn_ds_bpermute(di.below, __float_as_int(R01)));
+  float v;
+  if (F32W) {
+    // non-negative taps: every step is a convex blend, so the f32 differences and FMAs each stay within an ulp
+    const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(di.cdx), j));
+    const float top = fmaf(dx, R01 - R00, R00);
+    const float bot = fmaf(dx, R11 - R10, R10);
+    v = fmaf(di.rdy, bot - top, top);
+  } else {
+    const long long bits = __double_as_longlong(di.cdxd);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), j), hi = __builtin_amdgcn_readlane((int)(bits >> 32), j);
+    const double dx = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
+    const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
+    v = (float)fma(di.rdyd, bot - top, top);
+  }
+  if (di.rrow >= 0) di.dn[(size_t)c * di.h_out + di.rrow] = v;
+}
+
+// The common case of a lane's walk: a full segment of PW pixels in chunks of CH, each chunk unrolled -- the (k, r)
+// advance, the LDS read one pixel ahead, two FMAs and the store, with no branch and no register shuffling inside
+// a chunk.  The chunk's values stay in registers for the output columns whose left tap they are (the scan of
+// the wave-uniform column mask is a handful of scalar bit tests per chunk).  Chunking rather than unrolling the
+// whole segment keeps the kernel at 64 VGPRs, i.e. eight waves per SIMD.
+template <bool F32W, bool OUT, bool DOWNR, int PW>
+__device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, bool extra,
+                                      float *__restrict__ o, size_t ostride, const DownInfo &di) {
+  constexpr int CH = PW >= 4 ? 4 : PW;
+  const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
+  const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
+  const float rstepf = (float)fa.rstep, Df = (float)fa.D;
+  float rf = (float)r;
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  double2 s2 = make_double2(0.0, 0.0);
+  if (F32W) s4 = row4[kk]; else s2 = row2[kk];
+  float last = 0.f;  // last pixel of the previous chunk
+  for (int cb = 0; cb < PW; cb += CH) {
+    float v[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const float ref = rf;
+      const unsigned reu = r;
+      if (F32W) {
+        const float r2 = rf + rstepf;
+        const bool c = r2 >= Df;
+        kk += (int)fa.qstep + (c ? 1 : 0);
+        rf = c ? r2 - Df : r2;
+      } else {
+        const unsigned r2 = r + fa.rstep;
+        const bool c = r2 >= fa.D;
+        kk += (int)fa.qstep + (c ? 1 : 0);
+        r = c ? r2 - fa.D : r2;
+      }
+      float4 n4 = s4; double2 n2 = s2;
+      if (F32W) n4 = row4[kk]; else n2 = row2[kk];  // next pixel's record; in range by the W bound
+      v[i] = F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
+      if (OUT) { *o = v[i]; o += ostride; }
+      s4 = n4; s2 = n2;
+    }
+    if (DOWNR) {
+      const unsigned bits = (unsigned)(di.colmask >> (cb > 0 ? cb - 1 : 0)) << (cb > 0 ? 0 : 1);  // bit j: column cb-1+j
+      if (bits & 1u) down_event<F32W>(di, cb - 1, last, v[0]);
+#pragma unroll
+      for (int j = 1; j < CH; ++j)
+        if ((bits >> j) & 1u) down_event<F32W>(di, cb - 1 + j, v[j - 1], v[j]);
+      last = v[CH - 1];
+    }
+  }
+  if (DOWNR && extra && ((di.colmask >> (PW - 1)) & 1ull)) {
+    const float ve = F32W ? fmaf(rf, s4.z, fmaf(rf, s4.y, s4.x)) : (float)fma((double)r, s2.y, s2.x);
+    down_event<F32W>(di, PW - 1, last, ve);
+  }
+}
+
+// Edge cases (segment cut by the frame end, first pixels of a frame where x0 < 0): the same walk as a plain loop.
+// n_own pixels are stored; one more is evaluated (not stored) when `extra`.
+template <bool F32W, bool CLAMP, bool OUT, bool DOWNR>
+__device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, int n_own, bool extra,
+                                  float *__restrict__ o, size_t ostride, const DownInfo &di) {
+  const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
+  const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
+  const int n = n_own + (extra ? 1 : 0);
+  const float rstepf = (float)fa.rstep, Df = (float)fa.D;
+  float rf = (float)r;
+  float prev = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const int ks = CLAMP ? max(kk, 0) : kk;
+    const float ref = CLAMP ? (kk < 0 ? 0.f : rf) : rf;
+    const unsigned reu = CLAMP ? (kk < 0 ? 0u : r) : r;
+    float v;
+    if (F32W) { const float4 s4 = row4[ks]; v = fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)); }
+    else { const double2 s2 = row2[ks]; v = (float)fma((double)reu, s2.y, s2.x); }
+    if (OUT) { if (i < n_own && (!CLAMP || o)) { *o = v; o += ostride; } }
+    if (DOWNR) { if (i > 0 && ((di.colmask >> (i - 1)) & 1ull)) down_event<F32W>(di, i - 1, prev, v); }
+    prev = v;
+    if (F32W) {
+      const float r2 = rf + rstepf;
+      const bool c = r2 >= Df;
+      kk += (int)fa.qstep + (c ? 1 : 0);
+      rf = c ? r2 - Df : r2;
+    } else {
+      const unsigned r2 = r + fa.rstep;
+      const bool c = r2 >= fa.D;
+      kk += (int)fa.qstep + (c ? 1 : 0);
+      r = c ? r2 - fa.D : r2;
+    }
+  }
+}
+
+template <bool CPLX, bool F32W, bool DOWN, int PW>
+__global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict__ in, size_t in_stride, TileParams q,
+                                                     FastAx fa, FastInc fi, float *__restrict__ out, size_t out_stride,
+                                                     float *__restrict__ down, size_t down_stride) {
+  extern __shared__ double lds_d[];
+  const int Wp = q.W | 1;
+  float4 *smp4 = reinterpret_cast<float4 *>(lds_d);      // F32W : [64][Wp] {a, slope hi, slope lo, -}
+  double2 *smp2 = reinterpret_cast<double2 *>(lds_d);    // !F32W: [64][Wp] {a, slope} in f64
+  char *after = reinterpret_cast<char *>(lds_d) + (size_t)64 * Wp * 16;
+  double *rdyd = reinterpret_cast<double *>(after);      // DOWN: per-line row weight, per-pixel column weight
+  double *cdxd = rdyd + (DOWN ? 64 : 0);
+  int *rrow = reinterpret_cast<int *>(cdxd + (DOWN ? q.TP + 1 : 0));
+  int *ccol = rrow + (DOWN ? 64 : 0);
+
+  // (frame, strip, line tile) of this workgroup: same XCD-aware order as k_raster_tile
+  const unsigned xcd = blockIdx.x, ul = blockIdx.z;
+  const int tl = (int)blockIdx.y;
+  const unsigned U = (unsigned)(q.frames * q.tiles_p);
+  const unsigned gl = (unsigned)q.xcd_group_log;
+  const unsigned u = ((((ul >> gl) << 3) + xcd) << gl) + (ul & ((1u << gl) - 1u));
+  if (u >= U) return;
+  int f = (int)(((float)u + 0.5f) * q.inv_tiles_p);
+  int tp = (int)u - f * q.tiles_p;
+  if (tp < 0) { tp += q.tiles_p; --f; } else if (tp >= q.tiles_p) { tp -= q.tiles_p; ++f; }
+  const int l0 = tl * q.own_l, p0 = tp * q.own_p;
+  const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+
+  // position of (line l0, pixel p0); lines past the frame replicate the last one (same values, same addresses)
+  int kb = fi.k00; unsigned rb = fi.r00;
+  if (F32W) {
+    adv32(kb, rb, (unsigned)tl, fi.qTL, fi.rTL, fa.D, fi.invD);
+    adv32(kb, rb, (unsigned)tp, fi.qTP, fi.rTP, fa.D, fi.invD);
+  }
+  auto line_pos = [&](int line_in_tile, int &k, unsigned &r) {
+    const int l = min(l0 + line_in_tile, q.y_t - 1);
+    if (F32W) { k = kb; r = rb; adv32(k, r, (unsigned)(l - l0), fi.qL, fi.rL, fa.D, fi.invD); }
+    else fast_pos(fa, (unsigned)l * (unsigned)q.x_t + (unsigned)p0, k, r);
+  };
+
+  if (DOWN) {
+    // wave 0: output row of every line; waves 1..: output column of every pixel of the tile
+    if (wave == 0) {
+      const int l = l0 + lane;
+      const bool mine = lane < q.own_l || tl == q.tiles_l - 1;
+      double d = 0.0;
+      const int r = (mine && l < q.y_t) ? inv_tap(q.ay, q.inv_sfy, l, q.h_out, d) : -1;
+      rrow[lane] = r; rdyd[lane] = d;
+    } else {
+      for (int j = tid - 64; j <= q.TP; j += 192) {
+        const int p = p0 + j;
+        const bool mine = j < q.TP && (j < q.own_p || tp == q.tiles_p - 1);
+        double d = 0.0;
+        const int c = (mine && p < q.x_t) ? inv_tap(q.axx, q.inv_sfx, p, q.w_out, d) : -1;
+        ccol[j] = c; cdxd[j] = d;
+      }
+    }
+  }
+  {  // stage: 2^lpl_log lanes per line, each owning `cs` consecutive samples (cs <= 4) plus the one after them
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
+    const int cs = q.cs;
+    for (int r = sub; r < 64; r += nsub) {
+      int k; unsigned rr;
+      line_pos(r, k, rr);
+      const unsigned kf = (unsigned)max(k, 0);
+      const int jb = j0 * cs;
+      float re[5], im[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        re[t] = 0.f; im[t] = 0.f;
+        if (t <= cs) {
+          const unsigned ks = min(kf + (unsigned)min(jb + t, q.W - 1), q.S - 1u);
+          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[ks]; re[t] = z.x; im[t] = z.y; }
+          else re[t] = src[ks];
+        }
+      }
+      float a[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) a[t] = (CPLX && t <= cs) ? abs_iq<false>(re[t], im[t]) : re[t];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = jb + t;
+        if (t < cs && j < q.W) {
+          const double sl = ((double)a[t + 1] - (double)a[t]) * fa.invDd;
+          if (F32W) {
+            const float hi = (float)sl;
+            smp4[r * Wp + j] = make_float4(a[t], hi, (float)(sl - (double)hi), 0.f);
+          } else {
+            smp2[r * Wp + j] = make_double2((double)a[t], sl);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int pw = PW;  // = TP/4
+    const int pbeg = p0 + wave * pw;
+    const int n_own = min(pw, q.x_t - pbeg);
+    if (n_own <= 0) return;
+    // one pixel past the segment (evaluated, not stored) lets the last owned pixel be a left tap
+    const bool extra = DOWN && wave < 3 && pbeg + pw < q.x_t;
+    int k; unsigned r;
+    line_pos(lane, k, r);
+    const int kf = max(k, 0);
+    const long long num0 = (long long)(2ull * ((unsigned long long)l0 * q.x_t + p0) + 1ull) * (long long)fa.S - (long long)fa.P;
+    if (F32W) adv32(k, r, (unsigned)(wave * pw), fa.qstep, fa.rstep, fa.D, fi.invD);
+    else fast_pos(fa, (unsigned)min(l0 + lane, q.y_t - 1) * (unsigned)q.x_t + (unsigned)pbeg, k, r);
+    const int l = min(l0 + lane, q.y_t - 1);
+    float *o = out ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
+    DownInfo di{};
+    if (DOWN) {
+      const int cj = lane <= pw ? wave * pw + lane : q.TP;  // entry TP is never a column
+      di.ccol = ccol[cj];
+      di.cdxd = cdxd[cj];
+      di.cdx = (float)di.cdxd;
+      di.colmask = __ballot(lane < pw && di.ccol >= 0);
+      di.rrow = rrow[lane];
+      di.rdyd = rdyd[lane];
+      di.rdy = (float)di.rdyd;
+      di.below = ((lane + 1) & 63) << 2;
+      di.dn = down + (size_t)f * down_stride;
+      di.h_out = q.h_out;
+    }
+    const void *row = F32W ? (const void *)(smp4 + lane * Wp) : (const void *)(smp2 + lane * Wp);
+    const int kk = k - kf;
+    const bool full = n_own == PW && (!DOWN || extra || wave == 3);
+    if (num0 < 0) fast_walk2<F32W, true, true, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
+    else if (!full) {
+      if (o) fast_walk2<F32W, false, true, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
+      else fast_walk2<F32W, false, false, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
+    } else if (o) fast_walk_full<F32W, true, DOWN, PW>(fa, row, kk, r, extra, o, (size_t)q.y_t, di);
+    else fast_walk_full<F32W, false, DOWN, PW>(fa, row, kk, r, extra, o, (size_t)q.y_t, di);
   }
 }
 
@@ -566,7 +952,7 @@ static int check_geom(tsdr_ctx *ctx, size_t S, int y_t, int x_t) {
   return TSDR_OK;
 }
 
-template <bool CPLX, bool EXACT, bool DOWN>
+template <bool CPLX, int AR, bool DOWN>
 static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t in_stride, const TileParams &q,
                        const FastAx &fa, size_t lds, float *out, size_t out_stride, float *down, size_t down_stride) {
   const size_t units = (size_t)q.frames * q.tiles_p;
@@ -574,7 +960,7 @@ static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t 
   const size_t upx = ceil_div(units, 8 * G) * G;  // units per XCD slot
   if (upx > 65535 || (size_t)q.tiles_l > 65535 || units >= (size_t(1) << 20))
     return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
-  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, EXACT, DOWN>), dim3(8, (unsigned)q.tiles_l, (unsigned)upx), dim3(256), lds, in,
+  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, AR, DOWN>), dim3(8, (unsigned)q.tiles_l, (unsigned)upx), dim3(256), lds, in,
               in_stride, q, fa, out, out_stride, down, down_stride);
   return TSDR_OK;
 }
@@ -606,9 +992,9 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.inv_sfy = 1.0 / q.ay.sf; q.inv_sfx = 1.0 / q.axx.sf;
   }
   bool tiled = false;
-  // 64-pixel tiles when the downgrade is fused in: the raster tile kept in LDS then costs 16.6 KiB instead of
-  // 33 KiB, which doubles the resident workgroups per CU (measured: 0.18 ms vs 0.24 ms per C2 buffer)
-  int tp_max = want_down ? 64 : 128;
+  // EXACT with the downgrade fused in: 64-pixel tiles, because the raster tile kept in LDS then costs 16.6 KiB
+  // instead of 33 KiB, which doubles the resident workgroups per CU.  FAST keeps no raster tile (k_raster_fast).
+  int tp_max = (want_down && exact) ? 64 : 128;
   if (const char *e = getenv("TSDR_TILE_TP")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) tp_max = v; }
   // staged-sample budget per tile: EXACT 4 B/sample (<= 48 KiB), FAST 16 B/sample (<= 47 samples per line = 47 KiB;
   // only down-sampling ratios get near it, up-sampling tiles stage ~11-18 samples per line)
@@ -616,6 +1002,68 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   for (int TP = tp_max; TP >= 4; TP >>= 1) {
     const long W = (long)((double)(TP - 1) * sf) + 4;
     if (W <= w_cap) { tiled = true; q.TP = TP; q.W = (int)W; break; }
+  }
+  if (tiled && !exact) {  // FAST: k_raster_fast
+    // the in-walk downgrade needs ratios strictly above 1 (a line / pixel is then the top-left tap of at most one
+    // output row / column); otherwise the raster is produced here and the caller downgrades separately
+    const bool dn = want_down && q.TP >= 32 && y_t > h_out && x_t > w_out;
+    q.own_l = dn ? 63 : 64;
+    q.own_p = dn ? q.TP - 1 : q.TP;
+    q.tiles_l = dn ? (y_t - 2) / 63 + 1 : (int)ceil_div((size_t)y_t, 64);
+    q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
+    q.inv_tiles_p = 1.0f / (float)q.tiles_p;
+    if (!dn && !out) return TSDR_OK;  // nothing to do here; caller falls back to k_down_fused
+    // staging lanes per line: the power of two that wastes the fewest lane slots with <= 4 samples per lane
+    int best = -1; long best_slots = 1L << 60;
+    for (int lg = 2; lg <= 6; ++lg) {
+      const long lpl = 1L << lg, cs = (long)ceil_div((size_t)q.W, (size_t)lpl);
+      if (cs > 4) continue;
+      const long slots = cs * lpl;
+      if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
+    }
+    q.lpl_log = best;
+    q.cs = (int)ceil_div((size_t)q.W, (size_t)1 << best);
+    size_t lds = (size_t)64 * (size_t)(q.W | 1) * 16 + 16;
+    if (dn) {
+      q.h_out = h_out; q.w_out = w_out;
+      lds += (size_t)(64 + q.TP + 1) * 12 + 16;
+    }
+    if (const char *e = getenv("TSDR_LDS_PAD")) lds += (size_t)atoi(e);
+    const FastAx fa = fast_axis(S, P);
+    const FastInc fi = fast_inc(S, P, x_t, q.own_l, q.own_p);
+    // f32 walk and 32-bit position advance: D = 2P < 2^24 and few enough tiles that the advances stay below 2^32
+    const bool w32 = 2 * P < (size_t(1) << 24) && q.tiles_l <= 128 && q.tiles_p <= 128 && !getenv("TSDR_WALK64");
+    const size_t units = (size_t)q.frames * q.tiles_p;
+    const size_t G = (size_t)q.xcd_group;
+    const size_t upx = ceil_div(units, 8 * G) * G;  // units per XCD slot
+    if (upx > 65535 || (size_t)q.tiles_l > 65535 || units >= (size_t(1) << 20))
+      return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
+    const dim3 grid(8, (unsigned)q.tiles_l, (unsigned)upx);
+#define FASTK1(C, W32, D, PW, NAME)                                                                                   \
+  TSDR_LAUNCH(ctx, NAME, (k_raster_fast<C, W32, D, PW>), grid, dim3(256), lds, in, in_stride, q, fa, fi, out, out_stride, \
+              down, down_stride)
+#define FASTK(C, W32, D, NAME)                                                                                        \
+  do {                                                                                                                \
+    switch (q.TP) {                                                                                                   \
+      case 128: FASTK1(C, W32, D, 32, NAME); break;                                                                   \
+      case 64: FASTK1(C, W32, D, 16, NAME); break;                                                                    \
+      case 32: FASTK1(C, W32, D, 8, NAME); break;                                                                     \
+      case 16: FASTK1(C, W32, D, 4, NAME); break;                                                                     \
+      case 8: FASTK1(C, W32, D, 2, NAME); break;                                                                      \
+      default: FASTK1(C, W32, D, 1, NAME); break;                                                                     \
+    }                                                                                                                 \
+  } while (0)
+    if (dn) {
+      if (cplx) { if (w32) { FASTK(true, true, true, "raster_down_iq"); } else { FASTK(true, false, true, "raster_down_iq"); } }
+      else { if (w32) { FASTK(false, true, true, "raster_down_f32"); } else { FASTK(false, false, true, "raster_down_f32"); } }
+      if (did_down) *did_down = true;
+    } else {
+      if (cplx) { if (w32) { FASTK(true, true, false, "raster_iq"); } else { FASTK(true, false, false, "raster_iq"); } }
+      else { if (w32) { FASTK(false, true, false, "raster_f32"); } else { FASTK(false, false, false, "raster_f32"); } }
+    }
+#undef FASTK1
+#undef FASTK
+    return TSDR_OK;
   }
   if (tiled) {
     const bool dn = want_down && q.TP >= 32;
@@ -639,16 +1087,17 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       if (q.NR > 128 || q.NC > 192) return set_err(ctx, TSDR_EINVAL, "raster: candidate table overflow");
       lds += (size_t)q.TP * 65 * 4 + (size_t)(q.NR + q.NC + 4) * 4 + (size_t)(q.NR + q.NC) * 8;
     }
+    if (const char *e = getenv("TSDR_LDS_PAD")) lds += (size_t)atoi(e);
     const FastAx fa = fast_axis(S, P);
 #define TILE(C, E, D, NAME) launch_tile<C, E, D>(ctx, NAME, in, in_stride, q, fa, lds, out, out_stride, down, down_stride)
     if (dn) {
-      if (cplx) rc = exact ? TILE(true, true, true, "raster_down_iq_exact") : TILE(true, false, true, "raster_down_iq");
-      else rc = exact ? TILE(false, true, true, "raster_down_f32_exact") : TILE(false, false, true, "raster_down_f32");
+      if (cplx) rc = TILE(true, AR_EXACT, true, "raster_down_iq_exact");
+      else rc = TILE(false, AR_EXACT, true, "raster_down_f32_exact");
       if (!rc && did_down) *did_down = true;
     } else {
       if (!out) return TSDR_OK;  // nothing to do here; caller falls back to k_down_fused
-      if (cplx) rc = exact ? TILE(true, true, false, "raster_iq_exact") : TILE(true, false, false, "raster_iq");
-      else rc = exact ? TILE(false, true, false, "raster_f32_exact") : TILE(false, false, false, "raster_f32");
+      if (cplx) rc = TILE(true, AR_EXACT, false, "raster_iq_exact");
+      else rc = TILE(false, AR_EXACT, false, "raster_f32_exact");
     }
 #undef TILE
     return rc;

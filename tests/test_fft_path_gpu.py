@@ -59,6 +59,27 @@ def test_fft_any_length(ctx, n):
     assert relmax(O.fft(x), ref) < 1e-12
 
 
+# lengths 2^a 3^b 5^c go through the native mixed-radix passes: one pass (<= 256), two, three (2e6 = the packed
+# half of the 4e6-sample search window), ragged tiles (odd first radix), radix-3 stages, batches
+@pytest.mark.parametrize("n", [6, 10, 15, 25, 45, 120, 125, 200, 243, 250, 300, 625, 1000, 3000, 15625, 30000, 65610,
+                               100_000, 390_625, 1_000_000, 2_000_000, 2_400_000])
+def test_fft_mixed_radix(ctx, n):
+    x = crandn(n)
+    ref = np.fft.fft(x.astype(np.complex128))
+    e = relmax(ctx.fft(x), ref)
+    assert e < FFT_TOL, f"n={n}: {e:.3e}"
+    e = relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128)))
+    assert e < FFT_TOL, f"inverse n={n}: {e:.3e}"
+
+
+@pytest.mark.parametrize("n,batch", [(10, 777), (100, 41), (250, 300), (1000, 7), (6000, 5), (160_000, 2)])
+def test_fft_mixed_radix_batched(ctx, n, batch):
+    x = crandn(n * batch).reshape(batch, n)
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    assert relmax(ctx.fft(x), ref) < FFT_TOL
+    assert relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128), axis=1)) < FFT_TOL
+
+
 # ------------------------------------------------------------------ Autocorrelations.jl
 def test_autocorr_periodic_known_answer(ctx):
     """Exact period-T sequence: circular autocorrelation peaks at lag T, i.e. output index T
@@ -77,7 +98,9 @@ def test_autocorr_periodic_known_answer(ctx):
 
 
 @pytest.mark.parametrize("n,Fs,maxd,mind", [(3000, 30_000.0, 0.05, 0.0), (5000, 10_000.0, 0.1, 0.01), (4096, 4096.0, 0.5, 0.0),
-                                           (1500, 1000.0, 1.0, 0.0), (100_003, 1e6, 0.03, 0.0)])
+                                           (1500, 1000.0, 1.0, 0.0), (100_003, 1e6, 0.03, 0.0),
+                                           # n odd / n/2 with a factor 7: the zero-padded power-of-two route
+                                           (4001, 1000.0, 4.0, 0.0), (14_000, 1000.0, 7.0, 0.5)])
 def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind):
     x = (rng.random(n) ** 2).astype(np.float32) * 1e-5  # power-like, non-negative (GUI.jl:70)
     for scale in ("lin", "log"):
