@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtempest_hip.so")
+# TSDR_HIP_LIB: load another build of the same library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("TSDR_HIP_LIB") or os.path.join(HERE, "libtempest_hip.so")
 
 TSDR_OK, TSDR_EINVAL, TSDR_EBOUNDS, TSDR_ENOMEM, TSDR_EHIP, TSDR_ENODEV = 0, -1, -2, -3, -4, -5
 RENDER_H, RENDER_W = 600, 800

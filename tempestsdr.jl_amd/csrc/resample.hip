@@ -465,27 +465,36 @@ struct DownInfo {   // per-lane / per-wave state of the in-walk downgrade
   int h_out;
 };
 
+// dword store with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (the compiler keeps
+// emitting a 64-bit VGPR address, i.e. a 64-bit VALU add per store, for this pattern)
+__device__ inline void store_saddr(float *base_uniform, unsigned lane_off_bytes, float v) {
+  asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off_bytes), "v"(v), "s"(base_uniform) : "memory");
+}
+
+// One output column: this lane's line gives the upper blend along the pixel axis; the lower one is the same
+// quantity of the lane below (one ds_bpermute), so it is bit-identical to what that lane computes for itself.
 template <bool F32W>
 __device__ inline void down_event(const DownInfo &di, int j, float R00, float R01) {
   const int c = __builtin_amdgcn_readlane(di.ccol, j);
-  const float R10 = __int_as_float(__builtin_amdgcn_ds_bpermute(di.below, __float_as_int(R00)));
-  const float R11 = __int_as_float(__builtin_amdgcn_ds_bpermute(di.below, __float_as_int(R01)));
   float v;
   if (F32W) {
     // non-negative taps: every step is a convex blend, so the f32 differences and FMAs each stay within an ulp
     const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(di.cdx), j));
     const float top = fmaf(dx, R01 - R00, R00);
-    const float bot = fmaf(dx, R11 - R10, R10);
+    const float bot = __int_as_float(__builtin_amdgcn_ds_bpermute(di.below, __float_as_int(top)));
     v = fmaf(di.rdy, bot - top, top);
   } else {
     const long long bits = __double_as_longlong(di.cdxd);
     const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), j), hi = __builtin_amdgcn_readlane((int)(bits >> 32), j);
     const double dx = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
     const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
-    const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
+    const long long tb = __double_as_longlong(top);
+    const int blo = __builtin_amdgcn_ds_bpermute(di.below, (int)(tb & 0xffffffffLL));
+    const int bhi = __builtin_amdgcn_ds_bpermute(di.below, (int)(tb >> 32));
+    const double bot = __longlong_as_double(((long long)bhi << 32) | (unsigned)blo);
     v = (float)fma(di.rdyd, bot - top, top);
   }
-  if (di.rrow >= 0) di.dn[(size_t)c * di.h_out + di.rrow] = v;
+  if (di.rrow >= 0) store_saddr(di.dn + (size_t)c * di.h_out, (unsigned)di.rrow * 4u, v);
 }
 
 // The common case of a lane's walk: a full segment of PW pixels in chunks of CH, each chunk unrolled -- the (k, r)
@@ -495,7 +504,9 @@ __device__ inline void down_event(const DownInfo &di, int j, float R00, float R0
 // whole segment keeps the kernel at 64 VGPRs, i.e. eight waves per SIMD.
 template <bool F32W, bool OUT, bool DOWNR, int PW>
 __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, bool extra,
-                                      float *__restrict__ o, size_t ostride, const DownInfo &di) {
+                                      float *__restrict__ ob, int loff, size_t ostride, const DownInfo &di) {
+  // ob is wave-uniform (first pixel of the segment, line 0 of the frame), loff the lane's line: the store then
+  // takes a scalar base advanced by scalar adds and a fixed VGPR offset -- no per-pixel VALU address math
   constexpr int CH = PW >= 4 ? 4 : PW;
   const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
   const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
@@ -525,7 +536,7 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
       float4 n4 = s4; double2 n2 = s2;
       if (F32W) n4 = row4[kk]; else n2 = row2[kk];  // next pixel's record; in range by the W bound
       v[i] = F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
-      if (OUT) { *o = v[i]; o += ostride; }
+      if (OUT) { store_saddr(ob, (unsigned)loff * 4u, v[i]); ob += ostride; }
       s4 = n4; s2 = n2;
     }
     if (DOWNR) {
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
   const int l0 = tl * q.own_l, p0 = tp * q.own_p;
   const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
   // position of (line l0, pixel p0); lines past the frame replicate the last one (same values, same addresses)
   int kb = fi.k00; unsigned rb = fi.r00;
@@ -711,8 +722,11 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
     else if (!full) {
       if (o) fast_walk2<F32W, false, true, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
       else fast_walk2<F32W, false, false, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
-    } else if (o) fast_walk_full<F32W, true, DOWN, PW>(fa, row, kk, r, extra, o, (size_t)q.y_t, di);
-    else fast_walk_full<F32W, false, DOWN, PW>(fa, row, kk, r, extra, o, (size_t)q.y_t, di);
+    } else {
+      float *ob = out ? out + (size_t)f * out_stride + (size_t)pbeg * q.y_t : nullptr;
+      if (ob) fast_walk_full<F32W, true, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
+      else fast_walk_full<F32W, false, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
+    }
   }
 }
 

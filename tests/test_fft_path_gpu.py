@@ -101,7 +101,13 @@ def test_autocorr_periodic_known_answer(ctx):
                                            (1500, 1000.0, 1.0, 0.0), (100_003, 1e6, 0.03, 0.0),
                                            # n odd / n/2 with a factor 7: the zero-padded power-of-two route
                                            (4001, 1000.0, 4.0, 0.0), (14_000, 1000.0, 7.0, 0.5)])
-def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind, mixed, monkeypatch):
+    # TSDR_AC_MIXED=1 routes n = 2 * (2^a 3^b 5^c) through the native mixed-radix transform (no padding, no fold)
+    if mixed:
+        monkeypatch.setenv("TSDR_AC_MIXED", "1")
+    else:
+        monkeypatch.delenv("TSDR_AC_MIXED", raising=False)
     x = (rng.random(n) ** 2).astype(np.float32) * 1e-5  # power-like, non-negative (GUI.jl:70)
     for scale in ("lin", "log"):
         g, _ = ctx.calculate_autocorrelation(x, Fs, mind, maxd, scale)
