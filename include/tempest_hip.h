@@ -205,6 +205,18 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
                   float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                   int *sync_idx, int *n_frames);
 
+/* The same per-buffer body as a two-stage pipeline for callers that stream successive buffers (the GUI loop of
+ * GUI.jl:150-178 does: one buffer after the other from the SDR): the raster stage of buffer k+1 runs while the
+ * vsync/shift/IIR stage of buffer k is still in flight.  submit only enqueues (on two internal streams, ordered
+ * after everything already enqueued on the context's stream); the outputs of every submitted buffer are complete,
+ * in stream order, after tsdr_frames_flush (or tsdr_synchronize).  Results are identical to calling tsdr_frames_d
+ * once per buffer.  Until the flush, the caller must not touch iq, the state or the output buffers of submitted
+ * work, and each in-flight buffer needs its own frames_out / raster_out / sync_idx. */
+int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
+                         float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
+                         int *sync_idx, int *n_frames);
+int tsdr_frames_flush(tsdr_ctx *ctx);
+
 /* ---- the same loop in two stages, for sharding ONE buffer's frames across GPUs ----
  * Stage 1 is independent per frame (shard frames across ranks, no collective): IQ -> 600x800 image
  * per frame (+ optional raster) and, if do_align, two opaque 64-bit vsync argmax keys per frame

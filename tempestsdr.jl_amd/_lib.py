@@ -106,6 +106,8 @@ _SIGS = {
     # frame loop
     "tsdr_frames": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
+    "tsdr_frames_submit_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
+    "tsdr_frames_flush": (C.c_int, [vp]),
     "tsdr_frames_scan_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, c_i]),
     "tsdr_frames_combine_d": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
 }

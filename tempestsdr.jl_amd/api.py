@@ -315,6 +315,22 @@ def frames_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, frames_ou
     return n.value
 
 
+def frames_submit_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, frames_out=None, raster_out=None,
+                    sync_idx=None):
+    """frames_d as a two-stage pipeline across successive buffers: only enqueues; the raster stage of this
+    buffer overlaps the vsync/IIR stage of the previous one.  Outputs are complete after frames_flush(ctx)."""
+    n = C.c_int(0)
+    ctx.call("tsdr_frames_submit_d", C.c_void_p(sync.h if sync is not None else 0), _ptr(iq), int(nEch), int(S), int(y_t),
+             int(x_t), C.c_float(alpha), int(bool(do_align)), _ptr(state), _ptr(frames_out), _ptr(raster_out),
+             _ptr(sync_idx), C.byref(n))
+    return n.value
+
+
+def frames_flush(ctx):
+    """Order the context's stream after every buffer submitted with frames_submit_d."""
+    ctx.call("tsdr_frames_flush")
+
+
 class SyncXY:
     """SyncXY{Float32} state (FrameSynchronisation.jl:25-48) living on the device."""
 

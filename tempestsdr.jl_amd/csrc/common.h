@@ -70,6 +70,10 @@ struct tsdr_ctx {
   float2 *tw_small = nullptr;  // W_4096^e, e < 4096
   std::map<int, tsdr::TwTable> tw;
   std::map<size_t, tsdr::BluesteinPlan> blu;
+  // two-stage frame pipeline (tsdr_frames_submit_d): raster stage and vsync/IIR stage on their own streams
+  hipStream_t pipe_r = nullptr, pipe_s = nullptr;
+  hipEvent_t pipe_in = nullptr, pipe_er[2] = {nullptr, nullptr}, pipe_es[2] = {nullptr, nullptr};
+  unsigned long long pipe_n = 0;  // submissions since the last flush point
 
   void *scratch(int slot, size_t bytes);  // nullptr on failure (err set)
 };

@@ -69,6 +69,8 @@ void *tsdr_ctx::scratch(int slot, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.cap >= bytes) return b.p;
   if (b.p) {
+    if (pipe_r) (void)hipStreamSynchronize(pipe_r);
+    if (pipe_s) (void)hipStreamSynchronize(pipe_s);
     (void)hipStreamSynchronize(stream);
     (void)hipFree(b.p);
     b.p = nullptr;
@@ -127,6 +129,10 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->pipe_r) { (void)hipStreamSynchronize(ctx->pipe_r); (void)hipStreamDestroy(ctx->pipe_r); }
+  if (ctx->pipe_s) { (void)hipStreamSynchronize(ctx->pipe_s); (void)hipStreamDestroy(ctx->pipe_s); }
+  for (hipEvent_t e : {ctx->pipe_in, ctx->pipe_er[0], ctx->pipe_er[1], ctx->pipe_es[0], ctx->pipe_es[1]})
+    if (e) (void)hipEventDestroy(e);
   for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
   for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -164,6 +170,8 @@ int tsdr_get_precision(tsdr_ctx *ctx) { return ctx ? ctx->precision : TSDR_EINVA
 
 int tsdr_synchronize(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;
+  if (ctx->pipe_r) TSDR_HIP(ctx, hipStreamSynchronize(ctx->pipe_r));
+  if (ctx->pipe_s) TSDR_HIP(ctx, hipStreamSynchronize(ctx->pipe_s));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TSDR_OK;
 }

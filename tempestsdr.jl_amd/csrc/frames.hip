@@ -93,6 +93,79 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
   return tsdr_frames_combine_d(ctx, sync, img, keys, nf, alpha, do_align, imageOut_state, frames_out, sync_idx);
 }
 
+// ---- the same body as a two-stage pipeline across successive buffers ------------------------------------------
+// Stage R (raster + 600x800 images) of buffer k+1 has no dependence on stage S (vsync statistics, shift, IIR) of
+// buffer k, and the two are bound by different things: R is a full-chip streaming kernel, S is three short
+// launches that are latency-bound and leave most CUs idle.  submit enqueues R on one internal stream and S on
+// another; S(k) waits for R(k), S stages run in order (they carry the SyncXY and imageOut state), and R(k+2) waits
+// for S(k) because the two alternate between two image slots.  Nothing waits on the host.
+static int pipe_init(tsdr_ctx *ctx) {
+  if (ctx->pipe_r) return TSDR_OK;
+  // the S stage is three short dependent launches: it gets the higher priority, so that its workgroups are placed
+  // as soon as raster workgroups retire instead of queueing behind the rest of the raster grid
+  int prio_lo = 0, prio_hi = 0;
+  TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->pipe_r, hipStreamNonBlocking, prio_lo));
+  TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->pipe_s, hipStreamNonBlocking, prio_hi));
+  TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_in, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_er[i], hipEventDisableTiming));
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_es[i], hipEventDisableTiming));
+  }
+  return TSDR_OK;
+}
+
+int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
+                         float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
+                         int *sync_idx, int *n_frames) {
+  if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
+  if (nEch && !iq) return TSDR_EINVAL;
+  int rc = frames_check(ctx, sync, do_align);
+  if (rc) return rc;
+  const size_t nb = nEch / S;
+  if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
+  if (n_frames) *n_frames = (int)nb;
+  if (nb == 0) return TSDR_OK;
+  rc = pipe_init(ctx);
+  if (rc) return rc;
+  const int F = (int)nb;
+  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
+  const unsigned slot = (unsigned)(ctx->pipe_n & 1ull);
+  float *img2 = (float *)ctx->scratch(WS_IMG, 2 * nb * npx * 4);  // a growing buffer drains the pipeline first
+  unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, nb * 2 * 8);
+  if (!img2 || !keys) return TSDR_ENOMEM;
+  float *img = img2 + (size_t)slot * nb * npx;
+  // whatever produced iq / the state on the caller's stream comes first
+  TSDR_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));
+  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_in, 0));
+  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_in, 0));
+  if (ctx->pipe_n >= 2) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_es[slot], 0));  // image slot free again
+  ctx->launch_stream = ctx->pipe_r;
+  rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx);
+  if (!rc) {
+    TSDR_HIP(ctx, hipEventRecord(ctx->pipe_er[slot], ctx->pipe_r));
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_er[slot], 0));
+    ctx->launch_stream = ctx->pipe_s;
+    if (do_align) rc = sync_scan_d(sync, img, npx, F, &keys, 0);
+    if (!rc)
+      rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
+                       do_align ? sync_idx : nullptr);
+    if (!rc) TSDR_HIP(ctx, hipEventRecord(ctx->pipe_es[slot], ctx->pipe_s));
+  }
+  ctx->launch_stream = ctx->stream;
+  if (!rc) ++ctx->pipe_n;
+  return rc;
+}
+
+int tsdr_frames_flush(tsdr_ctx *ctx) {
+  if (!ctx) return TSDR_EINVAL;
+  if (ctx->pipe_n == 0) return TSDR_OK;
+  // stage S of the last submission is the last thing enqueued: the caller's stream continues after it
+  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_es[(ctx->pipe_n - 1) & 1ull], 0));
+  ctx->pipe_n = 0;
+  return TSDR_OK;
+}
+
 int tsdr_frames(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,
                 int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx, int *n_frames) {
   if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;

@@ -102,3 +102,41 @@ def test_frames_many_frames(ctx, tsdr, synth, precision):
             assert relerr(g["raster"][f], o["raster"][f]) < RTOL and relerr(g["frames"][f], o["frames"][f]) < RTOL
     if precision == "exact":
         assert np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
+
+
+def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
+    """tsdr_frames_submit_d / tsdr_frames_flush (raster stage of buffer k+1 in flight with the vsync/IIR stage of
+    buffer k) must return, bit for bit, what one tsdr_frames_d call per buffer returns: same kernels, same
+    order per stage, and the SyncXY / imageOut state threaded through the buffers."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y_t, fv, nfr, nbuf = 2.0e6, 1056, 628, 60.0, 4, 5
+    S = synth.samples_per_frame(Fs, fv)
+    P, npx = x_t * y_t, 600 * 800
+    bufs = [synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 7, n0=b * (S * nfr + 7)) for b in range(nbuf)]
+
+    def run(pipelined):
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
+        d_fr = [ctx.dev_alloc(nfr * npx * 4) for _ in bufs]
+        d_ra = [ctx.dev_alloc(nfr * P * 4) for _ in bufs]
+        d_ix = [ctx.dev_alloc(nfr * 8) for _ in bufs]
+        try:
+            for b in range(nbuf):
+                f = api.frames_submit_d if pipelined else api.frames_d
+                n = f(ctx, sync, d_iq[b], bufs[b].size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr[b], d_ra[b], d_ix[b])
+                assert n == nfr
+            if pipelined:
+                api.frames_flush(ctx)
+            ctx.synchronize()
+            return ([ctx.download(p, (nfr * npx,), np.uint32) for p in d_fr], [ctx.download(p, (nfr * P,), np.uint32) for p in d_ra],
+                    [ctx.download(p, (nfr * 2,), np.int32) for p in d_ix], ctx.download(d_state, (npx,), np.uint32))
+        finally:
+            for p in [d_state] + d_iq + d_fr + d_ra + d_ix:
+                ctx.dev_free(p)
+
+    a, b = run(False), run(True)
+    for k in range(3):
+        for x, y in zip(a[k], b[k]):
+            assert np.array_equal(x, y)
+    assert np.array_equal(a[3], b[3])
