@@ -152,7 +152,7 @@ __device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int
 
 // ---- fold partials + FIR + Sigma + beta scan + argmax.  One workgroup = 64 blank-band centres.
 // Phase 1 (wave 0, one lane per centre): the reference's sequential running sum _Sigma(w), every value parked
-// in LDS.  Phase 2 (all 256 threads): the (centre, w) pairs are independent now -- thread t owns centre t & 63
+// in LDS; the centres' circular neighbourhood is first unwrapped into a linear LDS window.  Phase 2 (all 256 threads): the (centre, w) pairs are independent now -- thread t owns centre t & 63
 // and widths w_min + (t >> 6) + 4i.  grid.x = ceil(x_t/64) + ceil(y_t/64), grid.y = frames.
 // write_frame: frame whose beta matrices are stored.
 __global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, SyncGeom g,
@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, Sy
   float *cv = sh + n;                                       // [n]
   float2 *rtab = reinterpret_cast<float2 *>(sh + 2 * n);    // [W] {RN(1/(2(n-w))), RN(1/(2w))}
   float *sw = sh + 2 * n + 2 * W;                           // [64][Wp] running sums
+  const int NU = 64 + 2 * w_max;
+  float *cu = sw + 64 * Wp;                                 // [NU] cv[(cbase - w_max + j) mod n]: the circular
+                                                            // neighbourhood of the 64 centres, laid out linearly
   __shared__ float Ssh;
   const float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
   const int nrb = (g.y_t + 63) >> 6;
@@ -180,6 +183,13 @@ __global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, Sy
     const int cnt = axis == 0 ? nrb : 8;
     float tot = q[0];
     int j = 1;
+    for (; j + 8 <= cnt; j += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(j + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot = __fadd_rn(tot, v[u]);
+    }
     for (; j + 4 <= cnt; j += 4) {
       const float v0 = q[(size_t)j * st], v1 = q[(size_t)(j + 1) * st], v2 = q[(size_t)(j + 2) * st], v3 = q[(size_t)(j + 3) * st];
       tot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(tot, v0), v1), v2), v3);
@@ -202,31 +212,61 @@ __global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, Sy
   }
   __syncthreads();
   const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64;
+  {
+    int k0 = (cbase - w_max) % n; if (k0 < 0) k0 += n;
+    for (int j = tid; j < NU; j += 256) cu[j] = cv[(k0 + j) % n];
+  }
   if (tid < 64) {
     // Sigma in sum64 order
     float a = 0.0f;
     for (int i = tid; i < n; i += 64) a = __fadd_rn(a, cv[i]);
     a = wave_tree64(a);
     if (tid == 0) Ssh = a;
-    // phase 1: running sum of centre cbase + tid (FrameSynchronisation.jl:101-107), sequential
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // phase 1: running sum of centre cbase + tid (FrameSynchronisation.jl:101-107), sequential.  In the unwrapped
+    // window the walk is plain ascending / descending addresses: no wrap test per step, immediate LDS offsets.
     const int c0 = cbase + tid;
     if (c0 < n) {
+      const float *ctr = cu + w_max + tid;
       float acc = 0.0f;
-      int k = (c0 - (w_min - 1)) % n; if (k < 0) k += n;
-#pragma unroll 8
-      for (int t = 0; t < 2 * (w_min - 1) + 1; ++t) { acc = __fadd_rn(acc, cv[k]); if (++k == n) k = 0; }
+      {
+        const float *pk = ctr - (w_min - 1);
+        const int np = 2 * (w_min - 1) + 1;
+        int t = 0;
+        for (; t + 8 <= np; t += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = pk[t + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
+        }
+        for (; t < np; ++t) acc = __fadd_rn(acc, pk[t]);
+      }
       float s = __fmul_rn(2.0f, acc);
-      int lo = (c0 - w_min) % n; if (lo < 0) lo += n;
-      int hi = (c0 + w_min) % n;
+      const float *plo = ctr - w_min, *phi = ctr + w_min;
       float *dst = sw + tid * Wp;
-      // the LDS reads do not depend on s: unrolling lets them run ahead of the two-add dependency chain
-#pragma unroll 8
-      for (int i = 0; i < W; ++i) {
-        s = __fadd_rn(s, __fmul_rn(2.0f, cv[lo]));
-        s = __fadd_rn(s, __fmul_rn(2.0f, cv[hi]));
+      // blocks of 8 widths: the 16 reads first (they do not depend on s, but the compiler will not move them across
+      // the LDS stores of the previous block on its own), then the serial adds, then the 8 stores
+      int i = 0;
+      for (; i + 8 <= W; i += 8) {
+        float lo[8], hi[8], out[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { lo[u] = plo[-(i + u)]; hi[u] = phi[i + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s = __fadd_rn(s, __fmul_rn(2.0f, lo[u]));
+          s = __fadd_rn(s, __fmul_rn(2.0f, hi[u]));
+          out[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[i + u] = out[u];
+      }
+      for (; i < W; ++i) {
+        s = __fadd_rn(s, __fmul_rn(2.0f, plo[-i]));
+        s = __fadd_rn(s, __fmul_rn(2.0f, phi[i]));
         dst[i] = s;
-        if (--lo < 0) lo = n - 1;
-        if (++hi == n) hi = 0;
       }
     }
   }
@@ -368,7 +408,8 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   const size_t nmax = (size_t)(x > y ? x : y);
   const size_t wmax = (size_t)std::max(1 + s->wmax_x - s->wmin_x, 1 + s->wmax_y - s->wmin_y);
   const unsigned nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nbb, (unsigned)frames), dim3(256), (2 * nmax + 2 * wmax + 64 * (wmax | 1)) * 4,
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nbb, (unsigned)frames), dim3(256),
+              (2 * nmax + 2 * wmax + 64 * (wmax | 1) + 64 + 2 * (size_t)std::max(s->wmax_x, s->wmax_y)) * 4,
               (const float *)proj, g, keys, frames - 1, s->beta_x, s->beta_y);
   *keys_out = keys;
   return TSDR_OK;
