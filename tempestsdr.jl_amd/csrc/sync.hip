@@ -62,9 +62,13 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 // and fold the tile's 64 rows in order (-> colpart[block][column]).  grid = (8 * nrb, frames).
 __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
                                              float *__restrict__ proj, unsigned long long *__restrict__ keys) {
-  extern __shared__ float tile[];  // [64][chunk | 1]
+  // The chunk goes through LDS in sub-tiles of SUB columns: [64][SUB + 1] floats = 8.4 KiB, so that every workgroup
+  // of the launch is resident at once (the whole-chunk tile, 26 KiB at 800 columns, held a CU to six single-wave
+  // workgroups and the 2400 of a C2 buffer ran in two rounds).
+  constexpr int SUB = 32, PITCH = SUB + 1;
+  __shared__ float tile[64 * PITCH];
   const int f = blockIdx.y;
-  const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3, pitch = chunk | 1;
+  const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3;
   const int rb = blockIdx.x % nrb, j = blockIdx.x / nrb;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride(y_t, x_t);
@@ -73,26 +77,39 @@ __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size
   const int r = rb * 64 + lane;
   const bool rv = r < y_t;
   const int c0 = j * chunk, c1 = min(c0 + chunk, x_t);
+  const int nval = min(64, y_t - rb * 64);
   const float *p = im + (rv ? r : 0) + (size_t)c0 * y_t;
   float a = 0.0f;
-  int c = c0;
-  for (; c + 16 <= c1; c += 16) {  // 16 independent coalesced loads in flight, folded in order
-    float v[16];
+  for (int cs = c0; cs < c1; cs += SUB) {
+    const int nc = min(SUB, c1 - cs);
+    if (nc == SUB) {  // SUB independent coalesced loads in flight, folded in column order
+      float v[SUB];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = p[(size_t)u * y_t];
+      for (int u = 0; u < SUB; ++u) v[u] = p[(size_t)u * y_t];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { a = __fadd_rn(a, v[u]); tile[lane * pitch + (c - c0) + u] = v[u]; }
-    p += (size_t)16 * y_t;
+      for (int u = 0; u < SUB; ++u) { a = __fadd_rn(a, v[u]); tile[lane * PITCH + u] = v[u]; }
+    } else {
+      for (int u = 0; u < nc; ++u) { const float v = p[(size_t)u * y_t]; a = __fadd_rn(a, v); tile[lane * PITCH + u] = v; }
+    }
+    p += (size_t)SUB * y_t;
+    __syncthreads();
+    if (lane < nc) {  // lanes become columns: the 64 rows of the block in row order
+      float t = 0.0f;
+      const float *col = tile + lane;
+      int rr = 0;
+      for (; rr + 16 <= nval; rr += 16) {  // reads first, then the adds
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = col[(rr + u) * PITCH];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t = __fadd_rn(t, v[u]);
+      }
+      for (; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
+      pr[(size_t)rb * x_t + cs + lane] = t;
+    }
+    __syncthreads();
   }
-  for (; c < c1; ++c) { const float v = *p; a = __fadd_rn(a, v); tile[lane * pitch + (c - c0)] = v; p += y_t; }
   if (rv) pr[(size_t)nrb * x_t + (size_t)j * y_t + r] = a;
-  __syncthreads();
-  const int nval = min(64, y_t - rb * 64);
-  for (int cl = lane; cl < c1 - c0; cl += 64) {
-    float t = 0.0f;
-    for (int rr = 0; rr < nval; ++rr) t = __fadd_rn(t, tile[rr * pitch + cl]);
-    pr[(size_t)rb * x_t + c0 + cl] = t;
-  }
 }
 
 __device__ inline unsigned long long pack_key(float v, int c) {
@@ -402,8 +419,7 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   if (!proj || !keys) return TSDR_ENOMEM;
   const SyncGeom g = geom_of(s);
   const unsigned nrb = (unsigned)ceil_div((size_t)y, 64);
-  const size_t chunk = ceil_div((size_t)x, 8);
-  TSDR_LAUNCH(ctx, "sync_proj", k_proj, dim3(8 * nrb, (unsigned)frames), dim3(64), 64 * (chunk | 1) * 4, img, img_stride, y,
+  TSDR_LAUNCH(ctx, "sync_proj", k_proj, dim3(8 * nrb, (unsigned)frames), dim3(64), 0, img, img_stride, y,
               x, proj, keys);
   const size_t nmax = (size_t)(x > y ? x : y);
   const size_t wmax = (size_t)std::max(1 + s->wmax_x - s->wmin_x, 1 + s->wmax_y - s->wmin_y);
