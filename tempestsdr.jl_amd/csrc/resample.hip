@@ -630,34 +630,17 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
     else fast_pos(fa, (unsigned)l * (unsigned)q.x_t + (unsigned)p0, k, r);
   };
 
-  if (DOWN) {
-    // wave 0: output row of every line; waves 1..: output column of every pixel of the tile
-    if (wave == 0) {
-      const int l = l0 + lane;
-      const bool mine = lane < q.own_l || tl == q.tiles_l - 1;
-      double d = 0.0;
-      const int r = (mine && l < q.y_t) ? inv_tap(q.ay, q.inv_sfy, l, q.h_out, d) : -1;
-      rrow[lane] = r; rdyd[lane] = d;
-    } else {
-      for (int j = tid - 64; j <= q.TP; j += 192) {
-        const int p = p0 + j;
-        const bool mine = j < q.TP && (j < q.own_p || tp == q.tiles_p - 1);
-        double d = 0.0;
-        const int c = (mine && p < q.x_t) ? inv_tap(q.axx, q.inv_sfx, p, q.w_out, d) : -1;
-        ccol[j] = c; cdxd[j] = d;
-      }
-    }
-  }
-  {  // stage: 2^lpl_log lanes per line, each owning `cs` consecutive samples (cs <= 4) plus the one after them
+  {  // stage: 2^lpl_log lanes per line, each owning `cs` consecutive samples (cs <= 4) plus the one after them.
+     // The loads of a thread's first line are issued before the output row/column tables are worked out (f64
+     // arithmetic that needs no memory), so their latency is covered.
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
     const int cs = q.cs;
-    for (int r = sub; r < 64; r += nsub) {
+    const int jb = j0 * cs;
+    auto issue = [&](int r, float (&re)[5], float (&im)[5]) {
       int k; unsigned rr;
       line_pos(r, k, rr);
       const unsigned kf = (unsigned)max(k, 0);
-      const int jb = j0 * cs;
-      float re[5], im[5];
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         re[t] = 0.f; im[t] = 0.f;
@@ -667,6 +650,8 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
           else re[t] = src[ks];
         }
       }
+    };
+    auto consume = [&](int r, const float (&re)[5], const float (&im)[5]) {
       float a[5];
 #pragma unroll
       for (int t = 0; t < 5; ++t) a[t] = (CPLX && t <= cs) ? abs_iq<false>(re[t], im[t]) : re[t];
@@ -683,6 +668,31 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
           }
         }
       }
+    };
+    float re[5], im[5];
+    issue(sub, re, im);
+    if (DOWN) {
+      // wave 0: output row of every line; waves 1..: output column of every pixel of the tile
+      if (wave == 0) {
+        const int l = l0 + lane;
+        const bool mine = lane < q.own_l || tl == q.tiles_l - 1;
+        double d = 0.0;
+        const int r = (mine && l < q.y_t) ? inv_tap(q.ay, q.inv_sfy, l, q.h_out, d) : -1;
+        rrow[lane] = r; rdyd[lane] = d;
+      } else {
+        for (int j = tid - 64; j <= q.TP; j += 192) {
+          const int p = p0 + j;
+          const bool mine = j < q.TP && (j < q.own_p || tp == q.tiles_p - 1);
+          double d = 0.0;
+          const int c = (mine && p < q.x_t) ? inv_tap(q.axx, q.inv_sfx, p, q.w_out, d) : -1;
+          ccol[j] = c; cdxd[j] = d;
+        }
+      }
+    }
+    consume(sub, re, im);
+    for (int r = sub + nsub; r < 64; r += nsub) {
+      issue(r, re, im);
+      consume(r, re, im);
     }
   }
   __syncthreads();

@@ -345,16 +345,30 @@ __global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img
   const int i = (int)(idx % (size_t)h), j = (int)(idx / (size_t)h);
   float acc = state[idx];
   const float oma = __fsub_rn(1.0f, alpha);
-  for (int f = 0; f < frames; ++f) {
-    size_t src = idx;
-    if (do_align) {
-      const int sy = f == 0 ? pend_in[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
-      const int sx = key_col1(keys[(size_t)f * 2 + 0]);
-      int si = i + sy; si %= h;
-      int sj = j + sx; sj %= w;
-      src = (size_t)sj * h + si;
+  auto src_of = [&](int f) -> size_t {
+    if (!do_align) return idx;
+    const int sy = f == 0 ? pend_in[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
+    const int sx = key_col1(keys[(size_t)f * 2 + 0]);
+    int si = i + sy; if (si >= h) si %= h;   // 1 <= s <= n: one conditional subtraction almost always
+    int sj = j + sx; if (sj >= w) sj %= w;
+    return (size_t)sj * h + si;
+  };
+  // The gathered pixels of FB frames are requested together (their addresses do not depend on acc); the
+  // recurrence then runs over them in frame order.  One load in flight per lane made this kernel latency-bound.
+  constexpr int FB = 6;
+  int f = 0;
+  for (; f + FB <= frames; f += FB) {
+    float v[FB];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) v[u] = img[(size_t)(f + u) * img_stride + src_of(f + u)];
+#pragma unroll
+    for (int u = 0; u < FB; ++u) {
+      acc = __fadd_rn(__fmul_rn(alpha, acc), __fmul_rn(oma, v[u]));
+      if (frames_out) frames_out[(size_t)(f + u) * npx + idx] = acc;
     }
-    const float v = img[(size_t)f * img_stride + src];
+  }
+  for (; f < frames; ++f) {
+    const float v = img[(size_t)f * img_stride + src_of(f)];
     acc = __fadd_rn(__fmul_rn(alpha, acc), __fmul_rn(oma, v));
     if (frames_out) frames_out[(size_t)f * npx + idx] = acc;
   }
