@@ -1230,7 +1230,9 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
 // raster (optional) + (h_out,w_out) image for every frame with as few passes over IQ as possible
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride) {
-  if (raster) {
+  // FAST without a raster to write: the tile kernel still wins (its walk produces the raster values in registers and
+  // downgrades them on the spot; k_down_fused re-derives four taps per output pixel), so it runs with out == null
+  if (raster || (ctx->precision == TSDR_FAST && !getenv("TSDR_OLD_FUSED"))) {
     bool did = false;
     int rc = raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, raster, raster_stride, down, down_stride, h_out,
                              w_out, &did);
