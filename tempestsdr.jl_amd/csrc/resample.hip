@@ -589,7 +589,9 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
   }
 }
 
-template <bool CPLX, bool F32W, bool DOWN, int PW>
+// OUT: the raster is written (out != null); a template parameter so that the raster-free launch is a different
+// kernel symbol and the two show up separately in profiler statistics
+template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT>
 __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict__ in, size_t in_stride, TileParams q,
                                                      FastAx fa, FastInc fi, float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
     if (F32W) adv32(k, r, (unsigned)(wave * pw), fa.qstep, fa.rstep, fa.D, fi.invD);
     else fast_pos(fa, (unsigned)min(l0 + lane, q.y_t - 1) * (unsigned)q.x_t + (unsigned)pbeg, k, r);
     const int l = min(l0 + lane, q.y_t - 1);
-    float *o = out ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
+    float *o = OUT ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
     DownInfo di{};
     if (DOWN) {
       const int cj = lane <= pw ? wave * pw + lane : q.TP;  // entry TP is never a column
@@ -728,14 +730,11 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
     const void *row = F32W ? (const void *)(smp4 + lane * Wp) : (const void *)(smp2 + lane * Wp);
     const int kk = k - kf;
     const bool full = n_own == PW && (!DOWN || extra || wave == 3);
-    if (num0 < 0) fast_walk2<F32W, true, true, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
-    else if (!full) {
-      if (o) fast_walk2<F32W, false, true, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
-      else fast_walk2<F32W, false, false, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
-    } else {
-      float *ob = out ? out + (size_t)f * out_stride + (size_t)pbeg * q.y_t : nullptr;
-      if (ob) fast_walk_full<F32W, true, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
-      else fast_walk_full<F32W, false, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
+    if (num0 < 0) fast_walk2<F32W, true, OUT, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
+    else if (!full) fast_walk2<F32W, false, OUT, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
+    else {
+      float *ob = OUT ? out + (size_t)f * out_stride + (size_t)pbeg * q.y_t : nullptr;
+      fast_walk_full<F32W, OUT, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
     }
   }
 }
@@ -1064,8 +1063,15 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
     const dim3 grid(8, (unsigned)q.tiles_l, (unsigned)upx);
 #define FASTK1(C, W32, D, PW, NAME)                                                                                   \
-  TSDR_LAUNCH(ctx, NAME, (k_raster_fast<C, W32, D, PW>), grid, dim3(256), lds, in, in_stride, q, fa, fi, out, out_stride, \
-              down, down_stride)
+  do {                                                                                                                \
+    if (out) {                                                                                                        \
+      TSDR_LAUNCH(ctx, NAME, (k_raster_fast<C, W32, D, PW, true>), grid, dim3(256), lds, in, in_stride, q, fa, fi, out,    \
+                  out_stride, down, down_stride);                                                                      \
+    } else {                                                                                                          \
+      TSDR_LAUNCH(ctx, (C ? "down_walk_iq" : "down_walk_f32"), (k_raster_fast<C, W32, D, PW, false>), grid, dim3(256), lds, in, in_stride, q, fa, \
+                  fi, out, out_stride, down, down_stride);                                                             \
+    }                                                                                                                 \
+  } while (0)
 #define FASTK(C, W32, D, NAME)                                                                                        \
   do {                                                                                                                \
     switch (q.TP) {                                                                                                   \
