@@ -37,7 +37,12 @@ def test_sig_to_image_fast(ctx, S, y_t, x_t):
     dict(Fs=2.0e6, x_t=1056, y_t=628, fv=60.0, nfr=3),    # fused raster+downgrade launch
     dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, nfr=3),    # C2
     dict(Fs=200e6, x_t=2576, y_t=1125, fv=60.0, nfr=2),   # C3 (downsampling)
-    dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, nfr=2),    # C5 (4K60 total raster)
+    dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, nfr=2),    # C5 (4K60 total raster): 2P >= 2^24, f64 walk
+    dict(Fs=4.0e6, x_t=1000, y_t=600, fv=60.0, nfr=2),    # y_t == 600: no in-walk downgrade (ratio 1 on one axis)
+    dict(Fs=4.0e6, x_t=800, y_t=700, fv=60.0, nfr=2),     # x_t == 800
+    dict(Fs=3.0e6, x_t=801, y_t=601, fv=50.0, nfr=2),     # ratios barely above 1: nearly every line/pixel owns a row/column
+    dict(Fs=6.0e6, x_t=300, y_t=9000, fv=50.0, nfr=1),    # 143 line tiles: 32-bit position advance not applicable
+    dict(Fs=1.0e6, x_t=2000, y_t=130, fv=50.0, nfr=2),    # two line tiles, ragged last one
 ])
 @pytest.mark.parametrize("want_raster", [True, False])
 def test_frames_fast(ctx, tsdr, synth, case, want_raster):
