@@ -591,19 +591,26 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
 
 // OUT: the raster is written (out != null); a template parameter so that the raster-free launch is a different
 // kernel symbol and the two show up separately in profiler statistics
-template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT>
-__global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict__ in, size_t in_stride, TileParams q,
+// VW: wavefronts stacked vertically in one workgroup (256*VW threads: VW x 4 wavefronts of 64 lines x PW pixels,
+// neighbours sharing one line with DOWN).  A wave's 256-byte column segment starts wherever (p*y_t + line)*4 falls,
+// so its first and last 128-byte lines are shared with the segments above and below; when those belong to other
+// workgroups the halves reach L2 ~20 us apart, longer than a line survives there under this write stream, and are
+// written back as partial lines twice.  Stacking VW waves makes VW-1 of every VW seams internal to a workgroup.
+template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT, int VW>
+__global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__restrict__ in, size_t in_stride, TileParams q,
                                                      FastAx fa, FastInc fi, float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
   extern __shared__ double lds_d[];
   const int Wp = q.W | 1;
-  float4 *smp4 = reinterpret_cast<float4 *>(lds_d);      // F32W : [64][Wp] {a, slope hi, slope lo, -}
-  double2 *smp2 = reinterpret_cast<double2 *>(lds_d);    // !F32W: [64][Wp] {a, slope} in f64
-  char *after = reinterpret_cast<char *>(lds_d) + (size_t)64 * Wp * 16;
+  float4 *smp4 = reinterpret_cast<float4 *>(lds_d);      // F32W : [NL][Wp] {a, slope hi, slope lo, -}
+  double2 *smp2 = reinterpret_cast<double2 *>(lds_d);    // !F32W: [NL][Wp] {a, slope} in f64
+  constexpr int LSTEP = DOWN ? 63 : 64;              // line pitch of vertically stacked waves
+  constexpr int NL = LSTEP * (VW - 1) + 64;            // lines of the tile
+  char *after = reinterpret_cast<char *>(lds_d) + (size_t)NL * Wp * 16;
   double *rdyd = reinterpret_cast<double *>(after);      // DOWN: per-line row weight, per-pixel column weight
-  double *cdxd = rdyd + (DOWN ? 64 : 0);
+  double *cdxd = rdyd + (DOWN ? NL : 0);
   int *rrow = reinterpret_cast<int *>(cdxd + (DOWN ? q.TP + 1 : 0));
-  int *ccol = rrow + (DOWN ? 64 : 0);
+  int *ccol = rrow + (DOWN ? NL : 0);
 
   // (frame, strip, line tile) of this workgroup: same XCD-aware order as k_raster_tile
   const unsigned xcd = blockIdx.x, ul = blockIdx.z;
@@ -618,7 +625,9 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
   const int l0 = tl * q.own_l, p0 = tp * q.own_p;
   const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
   const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wave = wave_id & 3, wv = wave_id >> 2;  // horizontal segment, vertical position
+  const int lbase = wv * LSTEP;                       // first line of this wave in the tile
 
   // position of (line l0, pixel p0); lines past the frame replicate the last one (same values, same addresses)
   int kb = fi.k00; unsigned rb = fi.r00;
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
      // The loads of a thread's first line are issued before the output row/column tables are worked out (f64
      // arithmetic that needs no memory), so their latency is covered.
     const int lpl = 1 << q.lpl_log;
-    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = (256 * VW) >> q.lpl_log;
     const int cs = q.cs;
     const int jb = j0 * cs;
     auto issue = [&](int r, float (&re)[5], float (&im)[5]) {
@@ -672,17 +681,17 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
       }
     };
     float re[5], im[5];
-    issue(sub, re, im);
+    if (sub < NL) issue(sub, re, im);
     if (DOWN) {
-      // wave 0: output row of every line; waves 1..: output column of every pixel of the tile
-      if (wave == 0) {
-        const int l = l0 + lane;
-        const bool mine = lane < q.own_l || tl == q.tiles_l - 1;
+      // first NL threads: output row of every line; the rest: output column of every pixel of the tile
+      if (tid < NL) {
+        const int l = l0 + tid;
+        const bool mine = tid < q.own_l || tl == q.tiles_l - 1;
         double d = 0.0;
         const int r = (mine && l < q.y_t) ? inv_tap(q.ay, q.inv_sfy, l, q.h_out, d) : -1;
-        rrow[lane] = r; rdyd[lane] = d;
+        rrow[tid] = r; rdyd[tid] = d;
       } else {
-        for (int j = tid - 64; j <= q.TP; j += 192) {
+        for (int j = tid - NL; j <= q.TP; j += 256 * VW - NL) {
           const int p = p0 + j;
           const bool mine = j < q.TP && (j < q.own_p || tp == q.tiles_p - 1);
           double d = 0.0;
@@ -691,8 +700,8 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
         }
       }
     }
-    consume(sub, re, im);
-    for (int r = sub + nsub; r < 64; r += nsub) {
+    if (sub < NL) consume(sub, re, im);
+    for (int r = sub + nsub; r < NL; r += nsub) {
       issue(r, re, im);
       consume(r, re, im);
     }
@@ -706,12 +715,12 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
     // one pixel past the segment (evaluated, not stored) lets the last owned pixel be a left tap
     const bool extra = DOWN && wave < 3 && pbeg + pw < q.x_t;
     int k; unsigned r;
-    line_pos(lane, k, r);
+    line_pos(lbase + lane, k, r);
     const int kf = max(k, 0);
     const long long num0 = (long long)(2ull * ((unsigned long long)l0 * q.x_t + p0) + 1ull) * (long long)fa.S - (long long)fa.P;
     if (F32W) adv32(k, r, (unsigned)(wave * pw), fa.qstep, fa.rstep, fa.D, fi.invD);
-    else fast_pos(fa, (unsigned)min(l0 + lane, q.y_t - 1) * (unsigned)q.x_t + (unsigned)pbeg, k, r);
-    const int l = min(l0 + lane, q.y_t - 1);
+    else fast_pos(fa, (unsigned)min(l0 + lbase + lane, q.y_t - 1) * (unsigned)q.x_t + (unsigned)pbeg, k, r);
+    const int l = min(l0 + lbase + lane, q.y_t - 1);
     float *o = OUT ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
     DownInfo di{};
     if (DOWN) {
@@ -720,14 +729,15 @@ __global__ __launch_bounds__(256, 8) void k_raster_fast(const float *__restrict_
       di.cdxd = cdxd[cj];
       di.cdx = (float)di.cdxd;
       di.colmask = __ballot(lane < pw && di.ccol >= 0);
-      di.rrow = rrow[lane];
-      di.rdyd = rdyd[lane];
+      // lane 63 is the next wave's lane 0 unless this is the bottom wave of the tile
+      di.rrow = (lane < 63 || wv == VW - 1) ? rrow[lbase + lane] : -1;
+      di.rdyd = rdyd[lbase + lane];
       di.rdy = (float)di.rdyd;
       di.below = ((lane + 1) & 63) << 2;
       di.dn = down + (size_t)f * down_stride;
       di.h_out = q.h_out;
     }
-    const void *row = F32W ? (const void *)(smp4 + lane * Wp) : (const void *)(smp2 + lane * Wp);
+    const void *row = F32W ? (const void *)(smp4 + (lbase + lane) * Wp) : (const void *)(smp2 + (lbase + lane) * Wp);
     const int kk = k - kf;
     const bool full = n_own == PW && (!DOWN || extra || wave == 3);
     if (num0 < 0) fast_walk2<F32W, true, OUT, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
@@ -1030,9 +1040,14 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     // the in-walk downgrade needs ratios strictly above 1 (a line / pixel is then the top-left tap of at most one
     // output row / column); otherwise the raster is produced here and the caller downgrades separately
     const bool dn = want_down && q.TP >= 32 && y_t > h_out && x_t > w_out;
-    q.own_l = dn ? 63 : 64;
+    // wavefronts stacked vertically per workgroup (see k_raster_fast).  Measured on C2: 1 -> 0.121 ms, 2 -> 0.118 ms,
+    // 4 (1024 threads, 77 KiB LDS) -> 0.131 ms
+    int VW = y_t >= 2 * 64 ? 2 : 1;
+    if (const char *e = getenv("TSDR_VW")) { const int v = atoi(e); if (v == 1 || v == 2) VW = v; }
+    const int lstep = dn ? 63 : 64, NL = lstep * (VW - 1) + 64;
+    q.own_l = lstep * VW;
     q.own_p = dn ? q.TP - 1 : q.TP;
-    q.tiles_l = dn ? (y_t - 2) / 63 + 1 : (int)ceil_div((size_t)y_t, 64);
+    q.tiles_l = dn ? (y_t - 2) / q.own_l + 1 : (int)ceil_div((size_t)y_t, (size_t)q.own_l);
     q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
     q.inv_tiles_p = 1.0f / (float)q.tiles_p;
     if (!dn && !out) return TSDR_OK;  // nothing to do here; caller falls back to k_down_fused
@@ -1046,10 +1061,10 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     }
     q.lpl_log = best;
     q.cs = (int)ceil_div((size_t)q.W, (size_t)1 << best);
-    size_t lds = (size_t)64 * (size_t)(q.W | 1) * 16 + 16;
+    size_t lds = (size_t)NL * (size_t)(q.W | 1) * 16 + 16;
     if (dn) {
       q.h_out = h_out; q.w_out = w_out;
-      lds += (size_t)(64 + q.TP + 1) * 12 + 16;
+      lds += (size_t)(NL + q.TP + 1) * 12 + 16;
     }
     if (const char *e = getenv("TSDR_LDS_PAD")) lds += (size_t)atoi(e);
     const FastAx fa = fast_axis(S, P);
@@ -1062,15 +1077,20 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     if (upx > 65535 || (size_t)q.tiles_l > 65535 || units >= (size_t(1) << 20))
       return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
     const dim3 grid(8, (unsigned)q.tiles_l, (unsigned)upx);
-#define FASTK1(C, W32, D, PW, NAME)                                                                                   \
+#define FASTK2(C, W32, D, PW, VWK, NAME)                                                                              \
   do {                                                                                                                \
     if (out) {                                                                                                        \
-      TSDR_LAUNCH(ctx, NAME, (k_raster_fast<C, W32, D, PW, true>), grid, dim3(256), lds, in, in_stride, q, fa, fi, out,    \
-                  out_stride, down, down_stride);                                                                      \
-    } else {                                                                                                          \
-      TSDR_LAUNCH(ctx, (C ? "down_walk_iq" : "down_walk_f32"), (k_raster_fast<C, W32, D, PW, false>), grid, dim3(256), lds, in, in_stride, q, fa, \
+      TSDR_LAUNCH(ctx, NAME, (k_raster_fast<C, W32, D, PW, true, VWK>), grid, dim3(256 * VWK), lds, in, in_stride, q, fa,   \
                   fi, out, out_stride, down, down_stride);                                                             \
+    } else {                                                                                                          \
+      TSDR_LAUNCH(ctx, (C ? "down_walk_iq" : "down_walk_f32"), (k_raster_fast<C, W32, D, PW, false, VWK>), grid,          \
+                  dim3(256 * VWK), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);                   \
     }                                                                                                                 \
+  } while (0)
+#define FASTK1(C, W32, D, PW, NAME)                                                                                   \
+  do {                                                                                                                \
+    if (VW == 2) FASTK2(C, W32, D, PW, 2, NAME);                                                                 \
+    else FASTK2(C, W32, D, PW, 1, NAME);                                                                              \
   } while (0)
 #define FASTK(C, W32, D, NAME)                                                                                        \
   do {                                                                                                                \
@@ -1092,6 +1112,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       else { if (w32) { FASTK(false, true, false, "raster_f32"); } else { FASTK(false, false, false, "raster_f32"); } }
     }
 #undef FASTK1
+#undef FASTK2
 #undef FASTK
     return TSDR_OK;
   }
