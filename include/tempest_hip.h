@@ -217,6 +217,29 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
                          int *sync_idx, int *n_frames);
 int tsdr_frames_flush(tsdr_ctx *ctx);
 
+/* ---- host -> device staging ring ---------------------------------------
+ * The consumer side of AtomicCircularBuffer (AtomicAbstractSDRs.jl:64-190): `depth` slots of nEch samples in
+ * PINNED host memory.  Producer (the SDR thread): tsdr_ring_put = circ_put! (:161-173) -- never waits for the
+ * consumer, overwrites the oldest unread buffer when the ring is full (counted as overflow) -- or, zero-copy,
+ * tsdr_ring_write_ptr + tsdr_ring_commit.  Consumer: tsdr_ring_take_d = circ_take! / recv! (:177-190, :320-322)
+ * except that the buffer lands on the device: the H2D DMA runs on the ring's own stream, and the DMA of the next
+ * committed slot is started when a buffer is handed out, so it overlaps the kernels of the current one.
+ * fmt 0: ComplexF32 slots (what recv! returns); fmt 1: interleaved int16 I/Q as SDR hardware delivers it (half
+ * the PCIe bytes), expanded on the device to ComplexF32 * scale.  Counters as print_summary (:333-341). */
+typedef struct tsdr_ring tsdr_ring;
+int tsdr_ring_create(tsdr_ctx *ctx, size_t nEch, int depth, int fmt, float scale, tsdr_ring **out);
+void tsdr_ring_free(tsdr_ring *r);
+int tsdr_ring_put(tsdr_ring *r, const void *data);
+void *tsdr_ring_write_ptr(tsdr_ring *r);
+int tsdr_ring_commit(tsdr_ring *r);
+/* blocks up to timeout_ms (< 0: forever); TSDR_EBOUNDS on timeout or after tsdr_ring_stop with nothing left.
+ * *dev_iq: nEch ComplexF32 on the device, valid until the second next take; the context's stream is ordered after
+ * the transfer. */
+int tsdr_ring_take_d(tsdr_ring *r, int timeout_ms, float **dev_iq);
+int tsdr_ring_stop(tsdr_ring *r);
+int tsdr_ring_stats(tsdr_ring *r, unsigned long long *produced, unsigned long long *consumed,
+                    unsigned long long *overflow, double *producer_msps, double *consumer_msps);
+
 /* ---- the same loop in two stages, for sharding ONE buffer's frames across GPUs ----
  * Stage 1 is independent per frame (shard frames across ranks, no collective): IQ -> 600x800 image
  * per frame (+ optional raster) and, if do_align, two opaque 64-bit vsync argmax keys per frame

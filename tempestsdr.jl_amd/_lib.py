@@ -108,6 +108,15 @@ _SIGS = {
     "tsdr_frames_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_submit_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_flush": (C.c_int, [vp]),
+    "tsdr_ring_create": (C.c_int, [vp, c_sz, C.c_int, C.c_int, C.c_float, C.POINTER(vp)]),
+    "tsdr_ring_free": (None, [vp]),
+    "tsdr_ring_put": (C.c_int, [vp, vp]),
+    "tsdr_ring_write_ptr": (vp, [vp]),
+    "tsdr_ring_commit": (C.c_int, [vp]),
+    "tsdr_ring_take_d": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "tsdr_ring_stop": (C.c_int, [vp]),
+    "tsdr_ring_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tsdr_frames_scan_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, c_i]),
     "tsdr_frames_combine_d": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
 }

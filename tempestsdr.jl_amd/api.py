@@ -331,6 +331,67 @@ def frames_flush(ctx):
     ctx.call("tsdr_frames_flush")
 
 
+class StagingRing:
+    """Pinned-host staging ring: the consumer side of AtomicCircularBuffer / recv!(buffer, csdr)
+    (AtomicAbstractSDRs.jl:64-190, 320-322) with the buffer landing on the device.
+    fmt "cf32": ComplexF32 slots; "sc16": interleaved int16 I/Q, expanded on the device to ComplexF32 * scale."""
+
+    def __init__(self, ctx, nEch, depth=16, fmt="cf32", scale=1.0):
+        self.ctx, self.nEch, self.depth, self.fmt = ctx, int(nEch), int(depth), fmt
+        h = C.c_void_p(0)
+        ctx.call("tsdr_ring_create", self.nEch, self.depth, {"cf32": 0, "sc16": 1}[fmt], C.c_float(scale), C.byref(h))
+        self.h = h.value
+
+    def _chk(self, rc, what):
+        check(self.ctx.h, rc, what)
+
+    def put(self, buf):
+        """circ_put!: copy one buffer (complex64[nEch] or int16[2*nEch]) into the ring; never waits for the consumer."""
+        a = np.ascontiguousarray(buf)
+        want = self.nEch * (8 if self.fmt == "cf32" else 4)
+        if a.nbytes != want:
+            raise AssertionError(f"ring slot is {want} bytes, got {a.nbytes}")
+        self._chk(self.ctx.lib.tsdr_ring_put(self.h, _ptr(a)), "tsdr_ring_put")
+
+    def write_view(self):
+        """Zero-copy producer: a numpy view of the pinned slot to fill; publish it with commit()."""
+        p = self.ctx.lib.tsdr_ring_write_ptr(self.h)
+        n = self.nEch * 2
+        ctype = C.c_float if self.fmt == "cf32" else C.c_int16
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,))
+
+    def commit(self):
+        self._chk(self.ctx.lib.tsdr_ring_commit(self.h), "tsdr_ring_commit")
+
+    def take_d(self, timeout_ms=-1):
+        """circ_take! / recv!: device address of the next buffer (nEch ComplexF32); IndexError on timeout/stop."""
+        p = C.c_void_p(0)
+        self._chk(self.ctx.lib.tsdr_ring_take_d(self.h, int(timeout_ms), C.byref(p)), "tsdr_ring_take_d")
+        return p.value
+
+    def stop(self):
+        self._chk(self.ctx.lib.tsdr_ring_stop(self.h), "tsdr_ring_stop")
+
+    def stats(self):
+        a, b, c = C.c_ulonglong(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        rp, rc_ = C.c_double(0), C.c_double(0)
+        self._chk(self.ctx.lib.tsdr_ring_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(rp), C.byref(rc_)),
+                  "tsdr_ring_stats")
+        return {"produced": a.value, "consumed": b.value, "overflow": c.value, "producer_msps": rp.value,
+                "consumer_msps": rc_.value}
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.tsdr_ring_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SyncXY:
     """SyncXY{Float32} state (FrameSynchronisation.jl:25-48) living on the device."""
 

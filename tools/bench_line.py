@@ -7,3 +7,4 @@ for line in sys.stdin:
     print("     ", r["kernels_ms_per_step"])
     if d.get("search"): print("      search", d["search"])
     if d.get("fused"): print("      fused", d["fused"])
+    if d.get("host_ingest"): print("      ingest", d["host_ingest"])
