@@ -75,3 +75,47 @@ def bench_ingest(ctx, tsdr, iq_host, S, y_t, x_t, seconds=1.0, depth=4, fmt="cf3
     return {"fmt": fmt, "frames_per_s": round(n_done / dt, 1), "msps": round(n_done / nb * nEch / dt / 1e6, 1),
             "pcie_GBs": round(n_done / nb * bytes_per_buf / dt / 1e9, 2), "buffers": n_done // nb, "seconds": round(dt, 3),
             "overflow": st["overflow"], "depth": depth}
+
+
+# ---- the small host-side pieces of the runtime loop -----------------------------------------------
+class FrameChannel:
+    """Drop-oldest bounded channel of GUI.jl:111-118 (`non_blocking_put!`): the producer never blocks; when the
+    channel is full the oldest frame is taken out to make room."""
+
+    def __init__(self, sz_max):
+        import collections
+        if sz_max < 1:
+            raise ValueError("channel size must be >= 1")
+        self._q = collections.deque()
+        self.sz_max = int(sz_max)
+        self._cv = threading.Condition()
+        self.dropped = 0
+
+    def put(self, image):
+        with self._cv:
+            if len(self._q) == self.sz_max:  # "This is full": take!(channelImage)
+                self._q.popleft()
+                self.dropped += 1
+            self._q.append(image)
+            self._cv.notify()
+
+    def take(self, timeout=None):
+        with self._cv:
+            if not self._cv.wait_for(lambda: len(self._q) > 0, timeout):
+                raise IndexError("FrameChannel.take: timed out")
+            return self._q.popleft()
+
+    def __len__(self):
+        with self._cv:
+            return len(self._q)
+
+
+def record_buffers(take_host_buffer, nb_buffer, nEch, path, fmt="single"):
+    """The record task of GUI.jl:181-190: nbBuffer consecutive recv! results concatenated and written with
+    writeComplexBinary (DatBinaryFiles.jl:15-31).  `take_host_buffer()` returns one complex64[nEch] buffer."""
+    from .dat_files import writeComplexBinary
+    rec = np.empty(nb_buffer * nEch, np.complex64)
+    for n in range(nb_buffer):
+        rec[n * nEch:(n + 1) * nEch] = take_host_buffer()
+    writeComplexBinary(rec, path, fmt)
+    return rec.size

@@ -233,3 +233,36 @@ def test_search_flow_on_oracle(tsdr):
     assert vcm.allVideoConfigurations[got["name"]].refresh == 60.0
     with pytest.raises(IndexError):  # capture shorter than the 0.1 s window
         search.extract_configuration(OracleCtx, iq[:1000], Fs)
+
+
+# ---- runtime-loop extras: drop-oldest frame channel, record task --------------------------------
+def test_frame_channel_drops_oldest():
+    """GUI.jl:111-118: when the channel is full the oldest image is removed before the new one goes in."""
+    import importlib
+    from tempest_loader import load_package
+    load_package()
+    ing = importlib.import_module("tempestsdr_jl_amd.ingest")
+    ch = ing.FrameChannel(3)
+    for k in range(5):
+        ch.put(k)
+    assert len(ch) == 3 and ch.dropped == 2
+    assert [ch.take(0.1) for _ in range(3)] == [2, 3, 4]
+    with pytest.raises(IndexError):
+        ch.take(0.01)
+
+
+def test_record_buffers_round_trip(tmp_path):
+    """GUI.jl:181-190: nbBuffer recv! results concatenated and written as a .dat; read back identical (:single)."""
+    import importlib
+    from tempest_loader import load_package
+    load_package()
+    ing = importlib.import_module("tempestsdr_jl_amd.ingest")
+    dat = importlib.import_module("tempestsdr_jl_amd.dat_files")
+    rng = np.random.default_rng(3)
+    nEch, nb = 1000, 4
+    bufs = [(rng.standard_normal(nEch) + 1j * rng.standard_normal(nEch)).astype(np.complex64) for _ in range(nb)]
+    it = iter(bufs)
+    path = str(tmp_path / "dumpIQ_0.dat")
+    assert ing.record_buffers(lambda: next(it), nb, nEch, path) == nb * nEch
+    back = dat.readComplexBinary(path, "single")
+    assert np.array_equal(np.asarray(back, np.complex64), np.concatenate(bufs))
