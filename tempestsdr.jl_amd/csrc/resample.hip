@@ -1,8 +1,8 @@
 // resample.hip -- Resampler.jl on gfx950.
 //
-//   sig_to_image (Resampler.jl:117-122)     k_raster_tile   IQ/|IQ| -> column-major (y_t,x_t) raster
-//   ... |> downgradeImage (:124-126)        k_raster_tile<DOWN>: the same launch also emits the 600x800 image
-//   sig_to_image |> downgradeImage          k_down_fused    IQ/|IQ| -> (h_out,w_out), no raster in HBM
+//   sig_to_image (Resampler.jl:117-122)     k_raster_fast (FAST) / k_raster_tile (EXACT)   IQ/|IQ| -> column-major (y_t,x_t) raster
+//   ... |> downgradeImage (:124-126)        <DOWN> of either: the same launch also emits the 600x800 image
+//   sig_to_image |> downgradeImage          k_raster_fast with out == null (FAST) / k_down_fused: no raster in HBM
 //   downgradeImage / imresize(image,size)   k_resize2d
 //   imresize(sig,n)                         k_resize1d
 //   naiveResampler (:103-110)               k_naive
@@ -12,9 +12,9 @@
 //          oracle/tempest_oracle.c: f64 source coordinate sf*i+off (two roundings), f64 weights, one rounding
 //          to f32 per value.  Bit-identical to the oracle.
 //   FAST   evaluates the SAME coordinate exactly as a rational, x0(i) = ((2i+1)S - P) / 2P (0-based), carried
-//          along a line with integer adds (quotient k, remainder r); the weight is r/2P in f64 and the blend is
-//          one f64 FMA rounded once to f32.  Within 1 ulp of EXACT (the two differ only in how the last bits of
-//          the f64 intermediate round), ~2.5x fewer VALU cycles: the EXACT loop is f64-issue bound, not HBM bound.
+//          along a line with integer adds (quotient k, remainder r).  The blend is a + r*slope with the slope
+//          (b - a)/2P staged per sample: as hi + lo f32 halves and two f32 FMAs when 2P < 2^24 (r is then an exact
+//          f32 integer), else in f64 with one f64 FMA.  Within 1 ulp of EXACT either way.
 //
 // Layout: the raster is column-major (y_t,x_t): element (line l, pixel p) at p*y_t + l, so a wavefront owns 64
 // consecutive LINES of one pixel column and its store is one contiguous 256-byte segment.  Source samples of a
@@ -79,10 +79,6 @@ __device__ inline void fast_pos(const FastAx &f, unsigned flat, int &k, unsigned
   r = (unsigned)rem;
 }
 
-__device__ inline void fast_step(const FastAx &f, int &k, unsigned &r) {
-  k += (int)f.qstep;
-  r += f.rstep;
-  if (r >= f.D) { r -= f.D; k += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -108,73 +104,14 @@ struct TileParams {
   double inv_sfy, inv_sfx;
 };
 
-// FAST pixel walk of one lane along its line: (k, r) advance by integer adds; every staged sample holds
-// {a, (b - a)/D} in f64, so a pixel is cvt(r) -> fma -> cvt.  CLAMP handles x0 < 0 (first pixels of a frame).
-template <bool CLAMP, bool DOWN, bool OUT>
-__device__ inline void fast_walk(const FastAx &fa, const double2 *__restrict__ row, int kf, int k, unsigned r, int npx,
-                                 float *__restrict__ o, size_t ostride, float *__restrict__ trow) {
-  // software pipeline: the LDS read of pixel i+1 is issued before pixel i is blended and stored
-  double2 s = row[(CLAMP ? max(k, 0) : k) - kf];
-  unsigned re = CLAMP ? (k < 0 ? 0u : r) : r;
-#pragma unroll 2
-  for (int i = 0; i < npx; ++i) {
-    const unsigned r2 = r + fa.rstep;
-    const bool c = r2 >= fa.D;
-    k += (int)fa.qstep + (c ? 1 : 0);
-    r = c ? r2 - fa.D : r2;
-    const double2 sn = row[(CLAMP ? max(k, 0) : k) - kf];   // next pixel's {a, slope}; in range by the W bound
-    const float v = (float)fma((double)re, s.y, s.x);
-    if (OUT) { if (!CLAMP || o) { *o = v; o += ostride; } }
-    if (DOWN) { *trow = v; trow += 65; }
-    s = sn;
-    re = CLAMP ? (k < 0 ? 0u : r) : r;
-  }
-}
-
-// The same walk in f32 (D < 2^24, so r is an exact f32 integer and is carried as one): the staged slope
-// (b - a)/D is split into hi + lo f32 halves (48 significant bits), and a pixel is
-//     fma(r, lo, fma(r, hi, a)).
-// The inner FMA rounds the exact a + r*hi once, at the magnitude of the result; the outer one adds the
-// 2^-24-relative remainder of the product and rounds again: <= 1 ulp of the result whatever |b - a| is (a
-// plain f32 slope would carry its 2^-24 relative error into r*(b - a), which can dwarf the result).  Measured
-// on gfx950 (tools/ubench): cvt_f64_i32 + fma_f64 + cvt_f32_f64 issue in ~6.6 f32-FMA slots, two f32 FMAs in 2.
-template <bool CLAMP, bool DOWN, bool OUT>
-__device__ inline void fast_walk32(const FastAx &fa, const float4 *__restrict__ row, int kf, int k, unsigned r, int npx,
-                                   float *__restrict__ o, size_t ostride, float *__restrict__ trow) {
-  const float rstep = (float)fa.rstep, Df = (float)fa.D;
-  float rf = (float)r;
-  float4 s = row[(CLAMP ? max(k, 0) : k) - kf];
-  float re = CLAMP ? (k < 0 ? 0.f : rf) : rf;
-#pragma unroll 2
-  for (int i = 0; i < npx; ++i) {
-    const float r2 = rf + rstep;
-    const bool c = r2 >= Df;
-    k += (int)fa.qstep + (c ? 1 : 0);
-    rf = c ? r2 - Df : r2;
-    const float4 sn = row[(CLAMP ? max(k, 0) : k) - kf];
-    const float v = fmaf(re, s.z, fmaf(re, s.y, s.x));
-    if (OUT) { if (!CLAMP || o) { *o = v; o += ostride; } }
-    if (DOWN) { *trow = v; trow += 65; }
-    s = sn;
-    re = CLAMP ? (k < 0 ? 0.f : rf) : rf;
-  }
-}
-
-// arithmetic of the tile kernel: the oracle's IEEE sequence, the FAST walk in f64, the FAST walk in f32
-enum { AR_EXACT = 0, AR_FAST64 = 1, AR_FAST32 = 2 };
-
-template <bool CPLX, int AR, bool DOWN>
+template <bool CPLX, bool DOWN>
 __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ in, size_t in_stride, TileParams q,
-                                                     FastAx fa, float *__restrict__ out, size_t out_stride,
+                                                     float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
-  constexpr bool EXACT = AR == AR_EXACT, F32W = AR == AR_FAST32;
   extern __shared__ double lds_d[];
   const int Wp = q.W | 1;
-  // staged samples: EXACT [64][Wp] f32 ; FAST64 [64][Wp] {a, (b-a)/D} f64 pairs ; FAST32 [64][Wp] {a, hi, lo, -} f32
-  float *smp = reinterpret_cast<float *>(lds_d);
-  double2 *smp2 = reinterpret_cast<double2 *>(lds_d);
-  float4 *smp4 = reinterpret_cast<float4 *>(lds_d);
-  char *after = reinterpret_cast<char *>(lds_d) + (size_t)64 * Wp * (EXACT ? 4 : 16);
+  float *smp = reinterpret_cast<float *>(lds_d);  // staged samples [64][Wp] f32
+  char *after = reinterpret_cast<char *>(lds_d) + (size_t)64 * Wp * 4;
   after += (16 - ((size_t)after & 15)) & 15;
   // candidate tables (DOWN): doubles first (alignment), then ints, then the raster tile
   double *rd = reinterpret_cast<double *>(after);
@@ -261,9 +198,8 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       {
         const int l = min(l0 + r, q.y_t - 1);
         const unsigned flat = (unsigned)l * (unsigned)q.x_t + (unsigned)p0;
-        int k;
-        if (EXACT) { double d; k = (int)rs_pos(ax, (double)(flat + 1u), d); }
-        else { unsigned rr; fast_pos(fa, flat, k, rr); k = max(k, 0); }
+        double d;
+        const int k = (int)rs_pos(ax, (double)(flat + 1u), d);
         kf = (unsigned)k;
         if (j0 == 0) kfirst[r] = k;
       }
@@ -280,32 +216,13 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
         for (int u = 0; u < 4; ++u) {
           const int j = jb + u * lpl;
           if (j < q.W) {
-            const float a = CPLX ? abs_iq<EXACT>(re[u], im[u]) : re[u];
-            if (EXACT) smp[r * Wp + j] = a;
-            else if (F32W) smp4[r * Wp + j].x = a;
-            else smp2[r * Wp + j].x = (double)a;
+            smp[r * Wp + j] = CPLX ? abs_iq<true>(re[u], im[u]) : re[u];
           }
         }
       }
     }
   }
   __syncthreads();
-  if (!EXACT) {  // second pass: slope towards the next sample, pre-divided by D
-    const int lpl = 1 << q.lpl_log;
-    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = 256 >> q.lpl_log;
-    for (int r = sub; r < 64; r += nsub)
-      for (int j = j0; j + 1 < q.W; j += lpl) {
-        if (F32W) {
-          const double sl = ((double)smp4[r * Wp + j + 1].x - (double)smp4[r * Wp + j].x) * fa.invDd;
-          const float hi = (float)sl;
-          smp4[r * Wp + j].y = hi;
-          smp4[r * Wp + j].z = (float)(sl - (double)hi);
-        } else {
-          smp2[r * Wp + j].y = (smp2[r * Wp + j + 1].x - smp2[r * Wp + j].x) * fa.invDd;
-        }
-      }
-    __syncthreads();
-  }
   {
     const int wave = tid >> 6, lane = tid & 63;
     const int l = l0 + lane;
@@ -319,32 +236,14 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       float *o = out ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
       float *trow = DOWN ? tile + (pbeg - p0) * 65 + lane : nullptr;
       const unsigned flat0 = (unsigned)l * (unsigned)q.x_t + (unsigned)pbeg;
-      if (EXACT) {
-        const float *row = smp + lane * Wp;
-        for (int p = pbeg; p < pend; ++p) {
-          double d;
-          const int j = (int)rs_pos(ax, (double)(flat0 + (unsigned)(p - pbeg) + 1u), d) - kf;
-          const float a = row[j], bb = row[j + 1];
-          const float v = same ? (d == 1.0 ? bb : a) : rs_blend(a, bb, d);
-          if (o) { *o = v; o += q.y_t; }
-          if (DOWN) { *trow = v; trow += 65; }
-        }
-      } else {
-        int k; unsigned r;
-        fast_pos(fa, flat0, k, r);
-        // x0 < 0 only for the very first pixels of a frame: a tile-uniform test picks the clamping walk
-        const long long num0 = (long long)(2ull * ((unsigned long long)l0 * q.x_t + p0) + 1ull) * (long long)fa.S - (long long)fa.P;
-        if (F32W) {
-          const float4 *row = smp4 + lane * Wp;
-          if (num0 < 0) fast_walk32<true, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-          else if (o) fast_walk32<false, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-          else fast_walk32<false, DOWN, false>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-        } else {
-          const double2 *row = smp2 + lane * Wp;
-          if (num0 < 0) fast_walk<true, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-          else if (o) fast_walk<false, DOWN, true>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-          else fast_walk<false, DOWN, false>(fa, row, kf, k, r, pend - pbeg, o, (size_t)q.y_t, trow);
-        }
+      const float *row = smp + lane * Wp;
+      for (int p = pbeg; p < pend; ++p) {
+        double d;
+        const int j = (int)rs_pos(ax, (double)(flat0 + (unsigned)(p - pbeg) + 1u), d) - kf;
+        const float a = row[j], bb = row[j + 1];
+        const float v = same ? (d == 1.0 ? bb : a) : rs_blend(a, bb, d);
+        if (o) { *o = v; o += q.y_t; }
+        if (DOWN) { *trow = v; trow += 65; }
       }
     }
   }
@@ -365,24 +264,10 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       const double dy = rd[rfirst + ri], dx = cd[cfirst + ci];
       const float *t0 = tile + lx * 65 + ly;
       const float R00 = t0[0], R10 = t0[1], R01 = t0[65], R11 = t0[66];
-      float v;
-      if (EXACT) {
-        const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
-        const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
-        const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
-        v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
-      } else if (F32W) {
-        // non-negative taps: every step is a convex blend, so the f32 differences and FMAs each stay within an
-        // ulp of the running value (the f64 form below costs ~4x the issue slots on this SIMD)
-        const float dxf = (float)dx, dyf = (float)dy;
-        const float top = fmaf(dxf, R01 - R00, R00);
-        const float bot = fmaf(dxf, R11 - R10, R10);
-        v = fmaf(dyf, bot - top, top);
-      } else {
-        const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
-        const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
-        v = (float)fma(dy, bot - top, top);
-      }
+      const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
+      const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
+      const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
+      const float v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
       dn[(size_t)c * q.h_out + r] = v;
     }
   }
@@ -985,16 +870,16 @@ static int check_geom(tsdr_ctx *ctx, size_t S, int y_t, int x_t) {
   return TSDR_OK;
 }
 
-template <bool CPLX, int AR, bool DOWN>
+template <bool CPLX, bool DOWN>
 static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t in_stride, const TileParams &q,
-                       const FastAx &fa, size_t lds, float *out, size_t out_stride, float *down, size_t down_stride) {
+                       size_t lds, float *out, size_t out_stride, float *down, size_t down_stride) {
   const size_t units = (size_t)q.frames * q.tiles_p;
   const size_t G = (size_t)q.xcd_group;
   const size_t upx = ceil_div(units, 8 * G) * G;  // units per XCD slot
   if (upx > 65535 || (size_t)q.tiles_l > 65535 || units >= (size_t(1) << 20))
     return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
-  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, AR, DOWN>), dim3(8, (unsigned)q.tiles_l, (unsigned)upx), dim3(256), lds, in,
-              in_stride, q, fa, out, out_stride, down, down_stride);
+  TSDR_LAUNCH(ctx, name, (k_raster_tile<CPLX, DOWN>), dim3(8, (unsigned)q.tiles_l, (unsigned)upx), dim3(256), lds, in,
+              in_stride, q, out, out_stride, down, down_stride);
   return TSDR_OK;
 }
 
@@ -1012,12 +897,11 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   const double sf = (double)S / (double)P;
   const bool exact = ctx->precision == TSDR_EXACT || P >= (size_t(1) << 30);
   // fused downgrade in the raster launch: only when both axes shrink (<= 66 x 130 candidates per tile)
-  const bool want_down = down && !getenv("TSDR_NO_FUSED_DOWN") && !(y_t == h_out && x_t == w_out) && y_t >= 2 * 64 && x_t >= 2 * 128 &&
+  const bool want_down = down && !(y_t == h_out && x_t == w_out) && y_t >= 2 * 64 && x_t >= 2 * 128 &&
                          (double)y_t / h_out >= 1.0 && (double)x_t / w_out >= 1.0;
   TileParams q{};
   q.S = (unsigned)S; q.y_t = y_t; q.x_t = x_t; q.frames = frames;
   q.xcd_group_log = 2;  // groups of 4 strips; measured on C2: G=1 0.138 ms, G=4 0.132 ms, G=41 0.146 ms
-  if (const char *e = getenv("TSDR_XCD_GROUP_LOG")) { const int v = atoi(e); if (v >= 0 && v <= 12) q.xcd_group_log = v; }
   q.xcd_group = 1 << q.xcd_group_log;
   q.ax = rs_axis(S, (size_t)y_t * x_t);
   if (h_out > 0 && w_out > 0) {
@@ -1028,7 +912,6 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   // EXACT with the downgrade fused in: 64-pixel tiles, because the raster tile kept in LDS then costs 16.6 KiB
   // instead of 33 KiB, which doubles the resident workgroups per CU.  FAST keeps no raster tile (k_raster_fast).
   int tp_max = (want_down && exact) ? 64 : 128;
-  if (const char *e = getenv("TSDR_TILE_TP")) { const int v = atoi(e); if (v == 32 || v == 64 || v == 128) tp_max = v; }
   // staged-sample budget per tile: EXACT 4 B/sample (<= 48 KiB), FAST 16 B/sample (<= 47 samples per line = 47 KiB;
   // only down-sampling ratios get near it, up-sampling tiles stage ~11-18 samples per line)
   const long w_cap = exact ? 191 : 47;
@@ -1043,7 +926,6 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     // wavefronts stacked vertically per workgroup (see k_raster_fast).  Measured on C2: 1 -> 0.121 ms, 2 -> 0.118 ms,
     // 4 (1024 threads, 77 KiB LDS) -> 0.131 ms
     int VW = y_t >= 2 * 64 ? 2 : 1;
-    if (const char *e = getenv("TSDR_VW")) { const int v = atoi(e); if (v == 1 || v == 2) VW = v; }
     const int lstep = dn ? 63 : 64, NL = lstep * (VW - 1) + 64;
     q.own_l = lstep * VW;
     q.own_p = dn ? q.TP - 1 : q.TP;
@@ -1066,11 +948,10 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       q.h_out = h_out; q.w_out = w_out;
       lds += (size_t)(NL + q.TP + 1) * 12 + 16;
     }
-    if (const char *e = getenv("TSDR_LDS_PAD")) lds += (size_t)atoi(e);
     const FastAx fa = fast_axis(S, P);
     const FastInc fi = fast_inc(S, P, x_t, q.own_l, q.own_p);
     // f32 walk and 32-bit position advance: D = 2P < 2^24 and few enough tiles that the advances stay below 2^32
-    const bool w32 = 2 * P < (size_t(1) << 24) && q.tiles_l <= 128 && q.tiles_p <= 128 && !getenv("TSDR_WALK64");
+    const bool w32 = 2 * P < (size_t(1) << 24) && q.tiles_l <= 128 && q.tiles_p <= 128;
     const size_t units = (size_t)q.frames * q.tiles_p;
     const size_t G = (size_t)q.xcd_group;
     const size_t upx = ceil_div(units, 8 * G) * G;  // units per XCD slot
@@ -1130,7 +1011,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
     }
     q.lpl_log = best;
-    size_t lds = (size_t)64 * (size_t)(q.W | 1) * (exact ? 4 : 16) + 16 + 64 * 4 + 16;
+    size_t lds = (size_t)64 * (size_t)(q.W | 1) * 4 + 16 + 64 * 4 + 16;
     if (dn) {
       q.h_out = h_out; q.w_out = w_out;
       q.NR = (int)ceil(64.0 / ((double)y_t / h_out)) + 5;
@@ -1138,17 +1019,15 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       if (q.NR > 128 || q.NC > 192) return set_err(ctx, TSDR_EINVAL, "raster: candidate table overflow");
       lds += (size_t)q.TP * 65 * 4 + (size_t)(q.NR + q.NC + 4) * 4 + (size_t)(q.NR + q.NC) * 8;
     }
-    if (const char *e = getenv("TSDR_LDS_PAD")) lds += (size_t)atoi(e);
-    const FastAx fa = fast_axis(S, P);
-#define TILE(C, E, D, NAME) launch_tile<C, E, D>(ctx, NAME, in, in_stride, q, fa, lds, out, out_stride, down, down_stride)
+#define TILE(C, D, NAME) launch_tile<C, D>(ctx, NAME, in, in_stride, q, lds, out, out_stride, down, down_stride)
     if (dn) {
-      if (cplx) rc = TILE(true, AR_EXACT, true, "raster_down_iq_exact");
-      else rc = TILE(false, AR_EXACT, true, "raster_down_f32_exact");
+      if (cplx) rc = TILE(true, true, "raster_down_iq_exact");
+      else rc = TILE(false, true, "raster_down_f32_exact");
       if (!rc && did_down) *did_down = true;
     } else {
       if (!out) return TSDR_OK;  // nothing to do here; caller falls back to k_down_fused
-      if (cplx) rc = TILE(true, AR_EXACT, false, "raster_iq_exact");
-      else rc = TILE(false, AR_EXACT, false, "raster_f32_exact");
+      if (cplx) rc = TILE(true, false, "raster_iq_exact");
+      else rc = TILE(false, false, "raster_f32_exact");
     }
 #undef TILE
     return rc;
@@ -1259,7 +1138,7 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride) {
   // FAST without a raster to write: the tile kernel still wins (its walk produces the raster values in registers and
   // downgrades them on the spot; k_down_fused re-derives four taps per output pixel), so it runs with out == null
-  if (raster || (ctx->precision == TSDR_FAST && !getenv("TSDR_OLD_FUSED"))) {
+  if (raster || ctx->precision == TSDR_FAST) {
     bool did = false;
     int rc = raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, raster, raster_stride, down, down_stride, h_out,
                              w_out, &did);
