@@ -79,10 +79,8 @@ __device__ inline void fast_pos(const FastAx &f, unsigned flat, int &k, unsigned
   r = (unsigned)rem;
 }
 
-}
-
 // ------------------------------------------------------------------------------------------------------------
-// k_raster_tile: one tile of 64 lines x TP pixels per workgroup (TP = 128 whenever the staged span fits).
+// k_raster_tile (EXACT mode): one tile of 64 lines x TP pixels per workgroup (TP = 128 whenever the staged span fits).
 // DOWN: tiles overlap by one line / one pixel (63 x TP-1 owned); the tile's raster values are kept in LDS and
 // the 600x800 output pixels whose top-left tap falls in the owned area are produced by the same workgroup.
 // ------------------------------------------------------------------------------------------------------------
