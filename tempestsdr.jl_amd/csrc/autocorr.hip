@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "fft_dev.h"
 
@@ -140,7 +141,11 @@ __device__ inline unsigned long long argmax_key(float v, unsigned idx) {
   return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
 
-__global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, size_t n, unsigned long long *__restrict__ key) {
+// `key` must be zero on entry; `clear` (the slot the next launch will use) is zeroed here, so no memset launch
+// separates two searches
+__global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, size_t n, unsigned long long *__restrict__ key,
+                                                unsigned long long *__restrict__ clear) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0ull;
   unsigned long long best = 0ull;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const unsigned long long k = argmax_key(v[i], (unsigned)i);
@@ -313,18 +318,25 @@ int tsdr_zoom_bounds(size_t N, double Fs, double rate_min, double rate_max, size
 int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *val) {
   if (!ctx || !v || !idx || n == 0) return TSDR_EINVAL;  // findmax of an empty collection throws
   if (n >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "argmax: vector too long");
-  unsigned long long *key = (unsigned long long *)ctx->scratch(WS_MISC, 16);
-  if (!key) return TSDR_ENOMEM;
-  TSDR_HIP(ctx, hipMemsetAsync(key, 0, 8, ctx->stream));
+  if (!ctx->amax_keys) {
+    TSDR_HIP(ctx, hipMalloc((void **)&ctx->amax_keys, 16));
+    TSDR_HIP(ctx, hipMemset(ctx->amax_keys, 0, 16));
+    TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->amax_host, 64, hipHostMallocDefault));
+    ctx->amax_slot = 0;
+  }
+  unsigned long long *key = ctx->amax_keys + ctx->amax_slot, *other = ctx->amax_keys + (ctx->amax_slot ^ 1);
+  ctx->amax_slot ^= 1;
   const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
-  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key);
-  unsigned long long h = 0;
-  TSDR_HIP(ctx, hipMemcpyAsync(&h, key, 8, hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key, other);
+  // one pinned-memory DMA and one synchronisation; the value rides in the key's upper half (NaN canonicalised)
+  TSDR_HIP(ctx, hipMemcpyAsync(ctx->amax_host, key, 8, hipMemcpyDeviceToHost, ctx->stream));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const unsigned long long h = *ctx->amax_host;
   *idx = (size_t)(0xFFFFFFFFu - (unsigned)(h & 0xFFFFFFFFull));
   if (val) {
-    TSDR_HIP(ctx, hipMemcpyAsync(val, v + *idx, 4, hipMemcpyDeviceToHost, ctx->stream));
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned u = (unsigned)(h >> 32);
+    const unsigned bits = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;  // inverse of argmax_key's order-preserving map
+    std::memcpy(val, &bits, 4);
   }
   return TSDR_OK;
 }

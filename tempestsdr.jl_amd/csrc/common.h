@@ -70,6 +70,9 @@ struct tsdr_ctx {
   float2 *tw_small = nullptr;  // W_4096^e, e < 4096
   std::map<int, tsdr::TwTable> tw;
   std::map<size_t, tsdr::BluesteinPlan> blu;
+  // tsdr_argmax_d: two device key slots (each launch clears the other one) and a pinned host word for the readback
+  unsigned long long *amax_keys = nullptr, *amax_host = nullptr;
+  int amax_slot = 0;
   // two-stage frame pipeline (tsdr_frames_submit_d): raster stage and vsync/IIR stage on their own streams
   hipStream_t pipe_r = nullptr, pipe_s = nullptr;
   hipEvent_t pipe_in = nullptr, pipe_er[2] = {nullptr, nullptr}, pipe_es[2] = {nullptr, nullptr};

@@ -138,6 +138,8 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->amax_keys) (void)hipFree(ctx->amax_keys);
+  if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
   for (auto &kv : ctx->blu) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.bfft); }

@@ -25,3 +25,12 @@ for k, v in sorted(ctx.profile_results().items()):
     cnt, ms = v["launches"], v["total_ms"]
     print(f"{k:16s} n={cnt:4d} avg={ms/cnt*1e3:8.2f} us  per-search={ms/10*1e3:8.2f} us"); tot += ms / 10
 print("total per search", round(tot * 1e3, 2), "us")
+# back-to-back searches without per-kernel events or host readback: GPU-side time per search incl. launch gaps
+import time
+ctx.profile(False)
+for _ in range(3): once()
+ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): once()
+ctx.synchronize()
+print("back-to-back, no readback:", round((time.perf_counter() - t0) / 50 * 1e6, 1), "us per search")
