@@ -216,10 +216,16 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
     rc = fft_pow2(ctx, z, Z, logM - 1, 1, -1, 1.0f, SRC_C2C, 0, 0);
   }
   if (rc) return rc;
-  TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)tw->lo,
-              (const float2 *)tw->hi, tw->h, 0.0);
-  // only lags < n are ever folded: the last inverse pass stores a[0 .. n] = n/2 + 1 complex values
-  rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc), SRC_C2C, 0, n / 2 + 1);
+  // only lags < n are ever folded: the last inverse pass stores a[0 .. n] = n/2 + 1 complex values.  With more
+  // than one pass the power spectrum is formed by the first pass's loader (SRC_POWER); the in-place kernel remains
+  // for single-pass lengths.
+  if (logM - 1 > 8) {
+    rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc), SRC_POWER, Mc, n / 2 + 1);
+  } else {
+    TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)tw->lo,
+                (const float2 *)tw->hi, tw->h, 0.0);
+    rc = fft_pow2(ctx, Z, z, logM - 1, 1, +1, (float)(0.5 / (double)Mc), SRC_C2C, 0, n / 2 + 1);
+  }
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "ac_fold", k_ac_fold, dim3(stream_grid(ctx, cnt)), dim3(256), 0, reinterpret_cast<const float *>(z), n, k0,
               cnt, log_scale, out);

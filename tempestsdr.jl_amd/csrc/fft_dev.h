@@ -110,10 +110,27 @@ __device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000
 //   SRC_C2C   in[g]
 //   SRC_REAL  (x[2g], x[2g+1])            real f32 sequence of src_n samples packed two per complex, zero beyond
 //   SRC_IQPOW (|iq[2g]|^2, |iq[2g+1]|^2)  the same with x = abs2.(iq) formed on the fly (GUI.jl:70)
-enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2 };
+//   SRC_POWER Y[g] of the autocorrelation: `in` = Z, the length-src_n (a power of two) transform of a packed real
+//             sequence; Y is the packed spectrum whose inverse transform (times 1/2) is the real sequence with
+//             spectrum |X|^2 (see k_ac_power, which this loader replaces: one launch and a 2 x 8*Mc-byte round
+//             trip less)
+enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2, SRC_POWER = 3 };
 
 __device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g) {
   if (src_mode == SRC_C2C) return in[g];
+  if (src_mode == SRC_POWER) {
+    const size_t Mc = (size_t)src_n;
+    const float2 a = in[g], b = in[g ? Mc - g : 0];
+    const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+    const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (Z[g] - conj Z[Mc-g]) / 2
+    const float2 O = make_float2(D.y, -D.x);                                // -i*D
+    const float2 W = tw_unit((unsigned)g, 64 - __clzll((unsigned long long)Mc));  // W_M^g, M = 2*Mc
+    const float2 WO = cmul(W, O);
+    const float2 X0 = make_float2(E.x + WO.x, E.y + WO.y), X1 = make_float2(E.x - WO.x, E.y - WO.y);
+    const float P0 = X0.x * X0.x + X0.y * X0.y, P1 = X1.x * X1.x + X1.y * X1.y;
+    const float sum = P0 + P1, dif = P0 - P1;
+    return make_float2(sum + dif * W.y, dif * W.x);  // (P + P') + i conj(W) (P - P')
+  }
   const unsigned long long i0 = 2ull * g;
   if (i0 >= src_n) return make_float2(0.f, 0.f);  // zero padding is never read
   if (src_mode == SRC_REAL) {
@@ -124,9 +141,9 @@ __device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, u
   return make_float2(z.x * z.x + z.y * z.y, i0 + 1 < src_n ? z.z * z.z + z.w * z.w : 0.f);
 }
 
-// exp(-2*pi*i*e/N) for any N: inv_n = 1/N in f64, 0 <= e < N.  The phase e/N is formed in f64 (relative
-// error 2^-52), so the octant split is exact to ~1e-16 of a turn.
-__device__ inline float2 tw_frac(unsigned e, double inv_n8) {  // inv_n8 = 8/N
+// exp(-2*pi*i*e/N) for any N: inv_n8 = 8/N in f64, 0 <= e < N.  The phase e/N is formed in f64 (relative error
+// 2^-52), so the octant split is exact to ~1e-16 of a turn.
+__device__ inline float2 tw_frac(unsigned e, double inv_n8) {
   const double ph = (double)e * inv_n8;
   const unsigned o = (unsigned)ph;
   const double f = ph - (double)o;
