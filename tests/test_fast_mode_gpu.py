@@ -32,6 +32,18 @@ def test_sig_to_image_fast(ctx, S, y_t, x_t):
     assert relerr(got, want) < RTOL, relerr(got, want)
 
 
+@pytest.mark.parametrize("S,y_t,x_t", [(26001, 125, 161), (333333, 1125, 2576), (3333333, 1125, 2576), (833333, 2250, 4400)])
+def test_sig_to_image_fast_signed_input(ctx, S, y_t, x_t):
+    """sig_to_image also serves real signals that change sign (e.g. an FM-demodulated trace).  Next to a zero
+    crossing the pixel is a difference of two O(1) terms, and FAST (exact rational coordinate) and the oracle (f64
+    coordinate sf*i+off, rounded twice: ~1e-9 absolute at 3e6-sample frames) legitimately differ by that much of
+    the neighbouring samples there; so the bar is 4e-7 of max(|pixel|, 0.02 sigma) with unit-variance input."""
+    sig = rng.standard_normal(S).astype(np.float32)
+    got, want = ctx.sig_to_image(sig, y_t, x_t).astype(np.float64), O.sig_to_image(sig, y_t, x_t).astype(np.float64)
+    err = np.abs(got - want) / np.maximum(np.abs(want), 0.02)
+    assert err.max() < RTOL, err.max()
+
+
 @pytest.mark.parametrize("case", [
     dict(Fs=1.0e6, x_t=160, y_t=125, fv=50.0, nfr=3),     # S == P copy path, upscale to 600x800 (separate kernels)
     dict(Fs=2.0e6, x_t=1056, y_t=628, fv=60.0, nfr=3),    # fused raster+downgrade launch
