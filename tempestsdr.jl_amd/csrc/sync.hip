@@ -69,7 +69,10 @@ __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size
   __shared__ float tile[64 * PITCH];
   const int f = blockIdx.y;
   const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3;
-  const int rb = blockIdx.x % nrb, j = blockIdx.x / nrb;
+  // workgroups are dealt round-robin over the 8 XCDs and there are 8 column chunks: chunk = id mod 8 keeps all row
+  // blocks of a chunk on one XCD, so the 128-byte lines straddling two row blocks (600 rows * 4 B is not a multiple
+  // of 128) are fetched into one L2 once instead of into two
+  const int j = blockIdx.x & 7, rb = blockIdx.x >> 3;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride(y_t, x_t);
   const int lane = threadIdx.x;
