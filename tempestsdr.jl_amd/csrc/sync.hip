@@ -201,20 +201,26 @@ __global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, Sy
     const float *q = axis == 0 ? pr + i : pr + (size_t)nrb * g.x_t + i;
     const size_t st = axis == 0 ? (size_t)g.x_t : (size_t)g.y_t;
     const int cnt = axis == 0 ? nrb : 8;
-    float tot = q[0];
-    int j = 1;
-    for (; j + 8 <= cnt; j += 8) {
-      float v[8];
+    float tot;
+    if (cnt <= 16) {  // all partials of this element requested together, added in their defined order
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(j + u) * st];
+      for (int u = 0; u < 16; ++u) v[u] = u < cnt ? q[(size_t)u * st] : 0.0f;
+      tot = v[0];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) tot = __fadd_rn(tot, v[u]);
+      for (int u = 1; u < 16; ++u) if (u < cnt) tot = __fadd_rn(tot, v[u]);
+    } else {
+      tot = q[0];
+      int j = 1;
+      for (; j + 8 <= cnt; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(j + u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot = __fadd_rn(tot, v[u]);
+      }
+      for (; j < cnt; ++j) tot = __fadd_rn(tot, q[(size_t)j * st]);
     }
-    for (; j + 4 <= cnt; j += 4) {
-      const float v0 = q[(size_t)j * st], v1 = q[(size_t)(j + 1) * st], v2 = q[(size_t)(j + 2) * st], v3 = q[(size_t)(j + 3) * st];
-      tot = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(tot, v0), v1), v2), v3);
-    }
-    for (; j < cnt; ++j) tot = __fadd_rn(tot, q[(size_t)j * st]);
     raw[i] = tot;
   }
   for (int i = tid; i < W; i += 256) {
