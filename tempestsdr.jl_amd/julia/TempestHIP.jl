@@ -187,4 +187,37 @@ function hip_frames!(imageOut::Matrix{Float32}, sigId::Vector{ComplexF32}, sync:
     return frames, idx
 end
 
+# ---- streaming ingest: the staging ring (AtomicAbstractSDRs.jl:64-190 on pinned memory) ----------
+"""
+    HipRing(c, nEch; depth=16, sc16=false, scale=1f0)
+
+Pinned-host staging ring with the put/take/overflow semantics of `AtomicCircularBuffer`.  The producer task fills
+`write_slot(ring)` in place (e.g. `recv!(write_slot(ring), sdr)`) and calls `commit!(ring)`; the consumer calls
+`take_d!(ring)` in place of `recv!(buffer, csdr)` and gets a device pointer to hand to `tsdr_frames_d`.
+"""
+mutable struct HipRing
+    c::HipContext
+    h::Ptr{Cvoid}
+    nEch::Int
+    sc16::Bool
+end
+function HipRing(c::HipContext, nEch::Integer; depth = 16, sc16 = false, scale = 1f0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(c, ccall((:tsdr_ring_create, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Cint, Cfloat, Ptr{Ptr{Cvoid}}),
+                   c.h, nEch, depth, sc16 ? 1 : 0, scale, h), "HipRing")
+    r = HipRing(c, h[], nEch, sc16)
+    finalizer(x -> ccall((:tsdr_ring_free, LIB), Cvoid, (Ptr{Cvoid},), x.h), r)
+    return r
+end
+write_slot(r::HipRing) = r.sc16 ?
+    unsafe_wrap(Array, Ptr{Int16}(ccall((:tsdr_ring_write_ptr, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), r.h)), 2 * r.nEch) :
+    unsafe_wrap(Array, Ptr{ComplexF32}(ccall((:tsdr_ring_write_ptr, LIB), Ptr{Cvoid}, (Ptr{Cvoid},), r.h)), r.nEch)
+commit!(r::HipRing) = check(r.c, ccall((:tsdr_ring_commit, LIB), Cint, (Ptr{Cvoid},), r.h), "commit!")
+circ_put!(r::HipRing, data) = check(r.c, ccall((:tsdr_ring_put, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), r.h, data), "circ_put!")
+function take_d!(r::HipRing; timeout_ms = -1)
+    d = Ref{Ptr{Cfloat}}(C_NULL)
+    check(r.c, ccall((:tsdr_ring_take_d, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Ptr{Cfloat}}), r.h, timeout_ms, d), "take_d!")
+    return d[]
+end
+
 end # module
