@@ -189,19 +189,19 @@ end
 
 # ---- streaming ingest: the staging ring (AtomicAbstractSDRs.jl:64-190 on pinned memory) ----------
 """
-    HipRing(c, nEch; depth=16, sc16=false, scale=1f0)
+    HipRing(c::Ctx, nEch; depth=16, sc16=false, scale=1f0)
 
 Pinned-host staging ring with the put/take/overflow semantics of `AtomicCircularBuffer`.  The producer task fills
 `write_slot(ring)` in place (e.g. `recv!(write_slot(ring), sdr)`) and calls `commit!(ring)`; the consumer calls
 `take_d!(ring)` in place of `recv!(buffer, csdr)` and gets a device pointer to hand to `tsdr_frames_d`.
 """
 mutable struct HipRing
-    c::HipContext
+    c::Ctx
     h::Ptr{Cvoid}
     nEch::Int
     sc16::Bool
 end
-function HipRing(c::HipContext, nEch::Integer; depth = 16, sc16 = false, scale = 1f0)
+function HipRing(c::Ctx, nEch::Integer; depth = 16, sc16 = false, scale = 1f0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(c, ccall((:tsdr_ring_create, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Cint, Cfloat, Ptr{Ptr{Cvoid}}),
                    c.h, nEch, depth, sc16 ? 1 : 0, scale, h), "HipRing")
