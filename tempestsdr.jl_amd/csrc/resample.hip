@@ -399,6 +399,7 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
   double2 s2 = make_double2(0.0, 0.0);
   if (F32W) s4 = row4[kk]; else s2 = row2[kk];
   float last = 0.f;  // last pixel of the previous chunk
+  unsigned long long mm = di.colmask << 1;  // column mask aligned to the chunks: bit j+1 = column j (wave-uniform)
   for (int cb = 0; cb < PW; cb += CH) {
     float v[CH];
 #pragma unroll
@@ -423,7 +424,8 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
       s4 = n4; s2 = n2;
     }
     if (DOWNR) {
-      const unsigned bits = (unsigned)(di.colmask >> (cb > 0 ? cb - 1 : 0)) << (cb > 0 ? 0 : 1);  // bit j: column cb-1+j
+      const unsigned bits = (unsigned)mm;  // bit j: column cb-1+j is completed by pixel cb+j
+      mm >>= CH;
       if (bits & 1u) down_event<F32W>(di, cb - 1, last, v[0]);
 #pragma unroll
       for (int j = 1; j < CH; ++j)
