@@ -18,6 +18,7 @@
 // of 16 elements and the T-wide runs of a tile stay 128-byte aligned.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "fft_dev.h"
@@ -326,6 +327,192 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
   }
 }
 
+// ---- two register steps per pass (the structure of fft.hip's k_fft_pass with general radices) --------------------
+// R = RA * RB, both taken from the register DFT sizes: with n = j0 + RB*m and k = ka + RA*kb
+//   X[ka + RA*kb] = sum_j0 W_RB^(j0*kb) * ( W_R^(j0*ka) * sum_m W_RA^(m*ka) x[j0 + RB*m] ).
+// Step 1: RA-point DFTs over m in registers (slot = (column t, residue j0)), twiddle, ONE exchange through LDS;
+// step 2: RB-point DFTs over j0 in registers (slot = (column t, frequency ka)), stores straight from registers.
+// The generic kernel above walks the tile through LDS once per stage and twice more for loading and storing.
+// STRIDED loads go global -> registers; LAST stages its rows (contiguous over the DFT index) through LDS first.
+template <int RA, int RB>
+struct Mix2Geom {
+  static constexpr int R = RA * RB;
+  static constexpr int tmax() { int t = 1; while (2 * t * R <= 4096 && 2 * t <= 256) t *= 2; return t; }
+  static constexpr int TM = tmax();                       // widest tile (columns, a power of two)
+  static constexpr int CA = (RB * TM + 255) / 256;        // step-1 slots per thread
+  static constexpr int CB = (RA * TM + 255) / 256;        // step-2 slots per thread
+};
+
+template <int RA, int RB, int MODE>
+__global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in, float2 *__restrict__ out, MixDesc d) {
+  using G = Mix2Geom<RA, RB>;
+  constexpr int R = G::R, CA = G::CA, CB = G::CB;
+  extern __shared__ float2 sm[];
+  const int logT = d.logT, T = 1 << logT, TP = T + 1;
+  const int SA = (RB << logT) + (T < 32 ? T : 0);  // pitch of one ka plane of the exchange buffer
+  float2 *buf = sm;                                // staging tile [j][TP] (LAST) and exchange buffer [ka][SA], aliased
+  float2 *twR = sm + (R * TP > RA * SA ? R * TP : RA * SA);
+  const int tid = threadIdx.x;
+  const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
+  if (RB > 1)
+    for (int e = tid; e < R; e += 256) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
+  const unsigned bid = blockIdx.x;
+  const int n1 = RB << logT, n2 = RA << logT;  // DFT slots of step 1 / step 2
+
+  float2 v[CA * RA > CB * RB ? CA * RA : CB * RB];
+  float2 tw[MODE == FFT_STRIDED ? CB * RB : 1];
+  size_t base = 0, tbase = 0;
+  unsigned col0 = 0, a = 0, kt = 0, arest = 0;
+  if (MODE == FFT_STRIDED) {
+    const unsigned tile = bid % d.tiles;
+    a = (bid / d.tiles) % d.A;
+    const unsigned b = bid / (d.tiles * d.A);
+    col0 = tile << logT;
+    base = (size_t)b * d.N + (size_t)a * R * d.B + col0;
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1), j0 = s >> logT;
+      const bool ok = s < n1 && col0 + (unsigned)t < d.B;
+#pragma unroll
+      for (int m = 0; m < RA; ++m)
+        v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
+                           : make_float2(0.f, 0.f);
+    }
+    // inter-pass twiddles of this thread's outputs, evaluated under the latency of the loads just issued
+    const unsigned Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const int s = min(tid + 256 * q, n2 - 1);
+      const unsigned col = col0 + (unsigned)(s & (T - 1));
+      const unsigned nnext = col / d.Bnext;
+      const unsigned ka = (unsigned)(s >> logT);
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        tw[q * RB + i] = tw_q32(phase_q32(nnext * (Ka + (ka + RA * i) * d.Pprev), d.ntw_hi, d.ntw_lo));
+    }
+  } else {
+    kt = bid % d.k1tiles;
+    arest = (bid / d.k1tiles) % d.Aprime;
+    tbase = (size_t)(bid / (d.k1tiles * d.Aprime)) * d.N;
+    const int work = R << logT;
+    const float invR = 1.0f / (float)R;
+    constexpr int NL = (R * G::TM + 255) / 256;  // staged elements per thread
+    float2 w[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = min(tid + 256 * u, work - 1);
+      const int t = (int)(((float)e + 0.5f) * invR), j = e - t * R;  // e < 2^13: exact
+      const unsigned k1 = (kt << logT) + (unsigned)t;
+      w[u] = k1 < d.R1 ? in[tbase + ((size_t)k1 * d.Aprime + arest) * R + j] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + 256 * u;
+      if (e < work) {
+        const int t = (int)(((float)e + 0.5f) * invR), j = e - t * R;
+        buf[j * TP + t] = conj_if(w[u], smask);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = min(tid + 256 * q, n1 - 1);
+      const int t = s & (T - 1), j0 = s >> logT;
+#pragma unroll
+      for (int m = 0; m < RA; ++m) v[q * RA + m] = buf[(j0 + RB * m) * TP + t];
+    }
+  }
+  __syncthreads();  // twR visible; staging tile fully read before the exchange buffer overwrites it
+
+  // ---- step 1: RA-point DFTs over m, twiddle, exchange ----
+#pragma unroll
+  for (int q = 0; q < CA; ++q) dft_nat<RA>(v + q * RA);
+  if (RB > 1) {
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = tid + 256 * q;
+      const int j0 = s >> logT;
+      if (s < n1) {
+#pragma unroll
+        for (int ka = 0; ka < RA; ++ka) {
+          float2 x = v[q * RA + ka];
+          if (ka) x = cmul(x, twR[j0 * ka]);
+          buf[ka * SA + s] = x;  // (j0, t) is the slot number itself
+        }
+      }
+    }
+    __syncthreads();
+    // ---- step 2: RB-point DFTs over j0 ----
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const int s = min(tid + 256 * q, n2 - 1);
+      const int t = s & (T - 1), ka = s >> logT;
+#pragma unroll
+      for (int j0 = 0; j0 < RB; ++j0) v[q * RB + j0] = buf[ka * SA + (j0 << logT) + t];
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) dft_nat<RB>(v + q * RB);
+  }
+  // register i of output slot q now holds X[ka + RA*i] (RB > 1) or X[i] of column slot q (RB == 1)
+  constexpr int CO = RB > 1 ? CB : CA, RO = RB > 1 ? RB : RA;
+  const int no = RB > 1 ? n2 : n1;
+  if (MODE == FFT_STRIDED) {
+#pragma unroll
+    for (int q = 0; q < CO; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1);
+      if (s < no && col0 + (unsigned)t < d.B) {
+#pragma unroll
+        for (int i = 0; i < RO; ++i) {
+          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+          out[base + (size_t)k * d.B + t] = conj_if(cmul(v[q * RO + i], tw[RB > 1 ? q * RB + i : 0]), smask);
+        }
+      }
+    }
+  } else {
+    const unsigned Kp = digit_swap_g(arest, d.nprev - 1, d.Rprev + 1, d.Wprev + 1);
+#pragma unroll
+    for (int q = 0; q < CO; ++q) {
+      const int s = tid + 256 * q;
+      const int t = s & (T - 1);
+      const unsigned k1 = (kt << logT) + (unsigned)t;
+      if (s < no && k1 < d.R1) {
+        const size_t orel = (size_t)k1 + Kp;
+#pragma unroll
+        for (int i = 0; i < RO; ++i) {
+          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+          const size_t o = orel + (size_t)k * d.Pprev;
+          const float2 x = v[q * RO + i];
+          if (o < d.keep) out[tbase + o] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+        }
+      }
+    }
+  }
+}
+
+typedef void (*mix2_fn)(const float2 *, float2 *, MixDesc);
+struct Mix2Entry { unsigned R, RA; int tm; mix2_fn strided, last; };
+#define MIX2(RA_, RB_)                                                                                     \
+  { RA_ * RB_, RA_, Mix2Geom<RA_, RB_>::TM, k_fft_mix2<RA_, RB_, FFT_STRIDED>, k_fft_mix2<RA_, RB_, FFT_LAST> }
+// the factor sizes that have a two-step kernel (RB > 1 everywhere: the twiddle array is indexed per output)
+static const Mix2Entry kMix2[] = {
+    MIX2(16, 16), MIX2(16, 10), MIX2(16, 9), MIX2(16, 8), MIX2(16, 5), MIX2(25, 10), MIX2(25, 9), MIX2(25, 8),
+    MIX2(25, 5),  MIX2(25, 4),  MIX2(25, 3), MIX2(25, 2), MIX2(10, 9), MIX2(9, 9),   MIX2(9, 8),  MIX2(9, 5),
+    MIX2(8, 8),   MIX2(8, 5),   MIX2(5, 5),
+};
+#undef MIX2
+static const Mix2Entry *mix2_lookup(unsigned R) {
+  for (const Mix2Entry &e : kMix2)
+    if (e.R == R) return &e;
+  return nullptr;
+}
+static size_t mix2_lds(unsigned R, unsigned RA, int logT) {
+  const size_t T = (size_t)1 << logT, RB = R / RA;
+  const size_t SA = (RB << logT) + (T < 32 ? T : 0);
+  return (std::max((size_t)R * (T + 1), (size_t)RA * SA) + R) * sizeof(float2);
+}
+
 // ---- planning --------------------------------------------------------------------------------
 struct MixPlan {
   int p = 0;
@@ -461,7 +648,10 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     d.mode = FFT_STRIDED;
     d.src_mode = i == 0 ? src_mode : SRC_C2C;
     d.src_n = src_n;
-    d.logT = pick_logT(std::min({8, floor_log2(4096u / d.R), ceil_log2((unsigned)B)}), 4, batch * P, B);
+    const Mix2Entry *m2 = getenv("TSDR_FFT_NO_MIX2") ? nullptr : mix2_lookup(d.R);
+    // (the two-step kernels keep their full tile: a narrower one leaves most threads without a step-1 DFT)
+    d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2((unsigned)B)}),
+                       m2 ? 8 : 4, batch * P, B);
     d.scale = 1.0f;
     d.A = (unsigned)P;
     d.B = (unsigned)B;
@@ -478,7 +668,11 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     for (int j = 0; j < i; ++j) { d.Rprev[j] = pl.R[j]; d.Wprev[j] = (unsigned)wgt; wgt *= pl.R[j]; }
     const size_t grid = batch * d.A * d.tiles;
     if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
-    TSDR_LAUNCH(ctx, kStridedName[i], k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), src, work, d);
+    if (m2) {
+      TSDR_LAUNCH(ctx, kStridedName[i], m2->strided, dim3((unsigned)grid), dim3(256), mix2_lds(d.R, m2->RA, d.logT), src, work, d);
+    } else {
+      TSDR_LAUNCH(ctx, kStridedName[i], k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), src, work, d);
+    }
     src = work;
     P *= d.R;
   }
@@ -486,7 +680,9 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   d.mode = FFT_LAST;
   d.src_mode = SRC_C2C;
   d.R1 = pl.R[0];
-  d.logT = pick_logT(std::min({8, floor_log2(4096u / d.R), ceil_log2(d.R1)}), 4, batch * (P / pl.R[0]), d.R1);
+  const Mix2Entry *m2 = getenv("TSDR_FFT_NO_MIX2") ? nullptr : mix2_lookup(d.R);
+  d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2(d.R1)}), m2 ? 8 : 4,
+                     batch * (P / pl.R[0]), d.R1);
   d.scale = scale;
   d.Pprev = (unsigned)P;
   d.nprev = p - 1;
@@ -498,7 +694,11 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   d.k1tiles = (unsigned)ceil_div((size_t)d.R1, (size_t)1 << d.logT);
   const size_t grid = batch * d.Aprime * d.k1tiles;
   if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
-  TSDR_LAUNCH(ctx, "fftm_last", k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), (const float2 *)work, out, d);
+  if (m2) {
+    TSDR_LAUNCH(ctx, "fftm_last", m2->last, dim3((unsigned)grid), dim3(256), mix2_lds(d.R, m2->RA, d.logT), (const float2 *)work, out, d);
+  } else {
+    TSDR_LAUNCH(ctx, "fftm_last", k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), (const float2 *)work, out, d);
+  }
   return TSDR_OK;
 }
 

@@ -62,7 +62,7 @@ def test_fft_any_length(ctx, n):
 # lengths 2^a 3^b 5^c go through the native mixed-radix passes: one pass (<= 256), two, three (2e6 = the packed
 # half of the 4e6-sample search window), ragged tiles (odd first radix), radix-3 stages, batches
 @pytest.mark.parametrize("n", [6, 10, 15, 25, 45, 120, 125, 200, 243, 250, 300, 625, 1000, 3000, 15625, 30000, 65610,
-                               100_000, 390_625, 1_000_000, 2_000_000, 2_400_000])
+                               100_000, 390_625, 1_000_000, 2_000_000, 2_400_000, 60 * 150 * 120, 3_600_000])
 def test_fft_mixed_radix(ctx, n):
     x = crandn(n)
     ref = np.fft.fft(x.astype(np.complex128))
@@ -70,6 +70,16 @@ def test_fft_mixed_radix(ctx, n):
     assert e < FFT_TOL, f"n={n}: {e:.3e}"
     e = relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128)))
     assert e < FFT_TOL, f"inverse n={n}: {e:.3e}"
+
+
+@pytest.mark.parametrize("n", [1000, 30000, 390_625, 2_000_000, 2_400_000])
+def test_fft_mixed_radix_lds_stage_kernel(ctx, n, monkeypatch):
+    """Factor sizes without a two-register-step kernel (e.g. 60, 120, 150) go through the generic LDS-stage kernel;
+    TSDR_FFT_NO_MIX2 sends every factor there so that it stays covered on the common sizes too."""
+    monkeypatch.setenv("TSDR_FFT_NO_MIX2", "1")
+    x = crandn(n)
+    assert relmax(ctx.fft(x), np.fft.fft(x.astype(np.complex128))) < FFT_TOL
+    assert relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128))) < FFT_TOL
 
 
 @pytest.mark.parametrize("n,batch", [(10, 777), (100, 41), (250, 300), (1000, 7), (6000, 5), (160_000, 2)])
