@@ -85,6 +85,8 @@ __global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in,
   const int SA = (RB << logT) + (T < 32 ? T : 0);  // pitch of one ka plane of the exchange buffer
   float2 *buf = sm;                                // staging tile [j][TP] and exchange buffer [ka][SA] (aliased)
   float2 *twR = sm + 4096 + 256 + 16;
+  float2 *twK = twR + 256;  // STRIDED: per-frequency inter-pass twiddles when they are uniform over the tile
+  bool tw_shared = false;
   const int tid = threadIdx.x;
   const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
   if (RB > 1)
@@ -116,17 +118,25 @@ __global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in,
                                : make_float2(0.f, 0.f);
     }
     // inter-pass twiddles of this thread's 16 outputs: independent of the data, so they are evaluated here,
-    // under the latency of the loads just issued
+    // under the latency of the loads just issued.  When the whole tile lies inside one n_{i+1} (always in the
+    // first of three or more passes) the twiddle depends on the output frequency only: the workgroup evaluates
+    // its R values once into LDS (twK) instead of 16 per thread, and the threads pick theirs up after the barrier.
     const unsigned Ka = digit_swap(a, d.nprev, d.logRprev);
     const unsigned mask = (d.logNtw >= 32) ? 0xFFFFFFFFu : ((1u << d.logNtw) - 1u);
+    tw_shared = d.logBnext >= logT;
+    if (tw_shared) {
+      const unsigned nnext = (tile * T) >> d.logBnext;
+      for (int k = tid; k < R; k += 256) twK[k] = tw_unit((nnext * (Ka + ((unsigned)k << d.logPprev))) & mask, d.logNtw);
+    } else {
 #pragma unroll
-    for (int q = 0; q < CO; ++q) {
-      const int s = min(tid + 256 * q, no - 1);
-      const unsigned nnext = (tile * T + (unsigned)(s & (T - 1))) >> d.logBnext;
+      for (int q = 0; q < CO; ++q) {
+        const int s = min(tid + 256 * q, no - 1);
+        const unsigned nnext = (tile * T + (unsigned)(s & (T - 1))) >> d.logBnext;
 #pragma unroll
-      for (int i = 0; i < RO; ++i) {
-        const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
-        tw[q * RO + i] = tw_unit((nnext * (Ka + ((unsigned)k << d.logPprev))) & mask, d.logNtw);
+        for (int i = 0; i < RO; ++i) {
+          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+          tw[q * RO + i] = tw_unit((nnext * (Ka + ((unsigned)k << d.logPprev))) & mask, d.logNtw);
+        }
       }
     }
   } else {
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in,
         for (int i = 0; i < RO; ++i) {
           const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
           const float2 x = RB > 1 ? v[q * RB + brev<RB>(i)] : v[q * RA + i];
-          out[base + (size_t)k * d.B + t] = conj_if(cmul(x, tw[q * RO + i]), smask);
+          out[base + (size_t)k * d.B + t] = conj_if(cmul(x, tw_shared ? twK[k] : tw[q * RO + i]), smask);
         }
       }
     }
@@ -281,7 +291,7 @@ static fft_pass_fn pass_fn(int logR) {
     default: return k_fft_pass<8, MODE>;
   }
 }
-static const size_t kPassLds = (4096 + 256 + 16 + 256) * sizeof(float2);
+static const size_t kPassLds = (4096 + 256 + 16 + 256 + 256) * sizeof(float2);
 
 // ---- twiddle tables ------------------------------------------------------------------------
 static int ensure_tw_small(tsdr_ctx *ctx) {
