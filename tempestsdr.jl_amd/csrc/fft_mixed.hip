@@ -352,6 +352,8 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
   const int SA = (RB << logT) + (T < 32 ? T : 0);  // pitch of one ka plane of the exchange buffer
   float2 *buf = sm;                                // staging tile [j][TP] (LAST) and exchange buffer [ka][SA], aliased
   float2 *twR = sm + (R * TP > RA * SA ? R * TP : RA * SA);
+  float2 *twK = twR + R;  // STRIDED: per-frequency inter-pass twiddles when uniform over the tile
+  bool tw_shared = false;
   const int tid = threadIdx.x;
   const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
   if (RB > 1)
@@ -379,17 +381,25 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
         v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
                            : make_float2(0.f, 0.f);
     }
-    // inter-pass twiddles of this thread's outputs, evaluated under the latency of the loads just issued
+    // inter-pass twiddles of this thread's outputs, evaluated under the latency of the loads just issued; when the
+    // whole tile lies inside one n_{i+1} they depend on the output frequency only and the workgroup evaluates its
+    // R values once into LDS
     const unsigned Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
+    tw_shared = (d.Bnext & (unsigned)(T - 1)) == 0;  // T divides Bnext: tiles never straddle
+    if (tw_shared) {
+      const unsigned nnext = col0 / d.Bnext;
+      for (int k = tid; k < R; k += 256) twK[k] = tw_q32(phase_q32(nnext * (Ka + (unsigned)k * d.Pprev), d.ntw_hi, d.ntw_lo));
+    } else {
 #pragma unroll
-    for (int q = 0; q < CB; ++q) {
-      const int s = min(tid + 256 * q, n2 - 1);
-      const unsigned col = col0 + (unsigned)(s & (T - 1));
-      const unsigned nnext = col / d.Bnext;
-      const unsigned ka = (unsigned)(s >> logT);
+      for (int q = 0; q < CB; ++q) {
+        const int s = min(tid + 256 * q, n2 - 1);
+        const unsigned col = col0 + (unsigned)(s & (T - 1));
+        const unsigned nnext = col / d.Bnext;
+        const unsigned ka = (unsigned)(s >> logT);
 #pragma unroll
-      for (int i = 0; i < RB; ++i)
-        tw[q * RB + i] = tw_q32(phase_q32(nnext * (Ka + (ka + RA * i) * d.Pprev), d.ntw_hi, d.ntw_lo));
+        for (int i = 0; i < RB; ++i)
+          tw[q * RB + i] = tw_q32(phase_q32(nnext * (Ka + (ka + RA * i) * d.Pprev), d.ntw_hi, d.ntw_lo));
+      }
     }
   } else {
     kt = bid % d.k1tiles;
@@ -466,7 +476,7 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
 #pragma unroll
         for (int i = 0; i < RO; ++i) {
           const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
-          out[base + (size_t)k * d.B + t] = conj_if(cmul(v[q * RO + i], tw[RB > 1 ? q * RB + i : 0]), smask);
+          out[base + (size_t)k * d.B + t] = conj_if(cmul(v[q * RO + i], tw_shared ? twK[k] : tw[RB > 1 ? q * RB + i : 0]), smask);
         }
       }
     }
@@ -510,7 +520,7 @@ static const Mix2Entry *mix2_lookup(unsigned R) {
 static size_t mix2_lds(unsigned R, unsigned RA, int logT) {
   const size_t T = (size_t)1 << logT, RB = R / RA;
   const size_t SA = (RB << logT) + (T < 32 ? T : 0);
-  return (std::max((size_t)R * (T + 1), (size_t)RA * SA) + R) * sizeof(float2);
+  return (std::max((size_t)R * (T + 1), (size_t)RA * SA) + 2 * (size_t)R) * sizeof(float2);
 }
 
 // ---- planning --------------------------------------------------------------------------------
