@@ -157,3 +157,23 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
         for x, y in zip(a[k], b[k]):
             assert np.array_equal(x, y)
     assert np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_frames_fast_random_geometries(ctx, tsdr, seed):
+    """Random raster sizes and sampling ratios (0.08 .. 1.6 samples per pixel), white-noise IQ -- the hardest input
+    for the blends, neighbouring taps differing by their own size: sync indices identical, frames and rasters within
+    the bar.  (tools/fuzz_raster.py runs the same loop over many more cases.)"""
+    r = np.random.default_rng(seed)
+    for _ in range(5):
+        y_t, x_t, nfr = int(r.integers(130, 1300)), int(r.integers(260, 2800)), int(r.integers(1, 4))
+        S = max(2, int(y_t * x_t * float(np.exp(r.uniform(np.log(0.08), np.log(1.6))))))
+        iq = ((r.standard_normal(S * nfr + 3) + 1j * r.standard_normal(S * nfr + 3)) * 1e-3).astype(np.complex64)
+        gs = np.zeros((600, 800), np.float32, order="F")
+        os_ = np.zeros((600, 800), np.float32, order="F")
+        g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), gs, want_raster=True)
+        o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), os_, want_raster=True)
+        assert np.array_equal(g["sync_idx"], o["sync_idx"]), (S, y_t, x_t)
+        for f in range(nfr):
+            assert relerr(g["frames"][f], o["frames"][f]) < RTOL, (S, y_t, x_t, f)
+            assert relerr(g["raster"][f], o["raster"][f]) < RTOL, (S, y_t, x_t, f)
