@@ -39,3 +39,20 @@ for it in range(16):
                 e = relerr(g["raster"][f], o["raster"][f]); worst = max(worst, e)
                 assert e < 4e-7, (S, y_t, x_t, f, e)
 print("frames: 16 geometries x 2 ok, worst", worst)
+
+# EXACT mode: bit-identical rasters, frames, state and indices on random geometries
+ctx.set_precision("exact")
+beq = lambda a, b: np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+for it in range(10):
+    y_t = int(rng.integers(20, 1300)); x_t = int(rng.integers(30, 2800)); nfr = int(rng.integers(1, 3))
+    ratio = float(np.exp(rng.uniform(np.log(0.08), np.log(1.6))))
+    S = max(2, int(y_t * x_t * ratio))
+    iq = ((rng.standard_normal(S * nfr + 3) + 1j * rng.standard_normal(S * nfr + 3)) * 1e-3).astype(np.complex64)
+    gs = np.zeros((600, 800), np.float32, order="F"); os_ = np.zeros((600, 800), np.float32, order="F")
+    g = ctx.frames(T.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), gs, want_raster=True)
+    o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), os_, want_raster=True)
+    assert np.array_equal(g["sync_idx"], o["sync_idx"]) and beq(gs, os_), (S, y_t, x_t)
+    for f in range(nfr):
+        assert beq(g["frames"][f], o["frames"][f]) and beq(g["raster"][f], o["raster"][f]), (S, y_t, x_t, f)
+print("exact frames: 10 geometries bit-identical")
+ctx.set_precision("fast")
