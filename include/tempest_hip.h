@@ -62,17 +62,26 @@ int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream);
 int tsdr_synchronize(tsdr_ctx *ctx);
 int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_t *hbm_bytes);
 
-/* Arithmetic of the resize/raster kernels (sig_to_image, the frame loop):
+/* Arithmetic of the steady-state frame loop (tsdr_frames*, i.e. IQ -> raster -> 600x800 image):
  *   TSDR_EXACT: the reference's evaluation order -- f64 source coordinate sf*i+off and f64 weights,
  *               one rounding to f32 per value; bit-identical to the CPU oracle.
  *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend (within
  *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp): pixels within ~3 ulp
- *               (4e-7 relative) of TSDR_EXACT; ~2.5x fewer VALU cycles.  Default.
- * Both are parity-tested; everything downstream of the 600x800 image (vsync, circshift, IIR) is
- * evaluated identically in the two modes. */
+ *               (4e-7 relative) of TSDR_EXACT; ~2.5x fewer VALU cycles.  Default.  The images' projection
+ *               sums are then formed inside the raster kernel (per-tile partial sums, added in tile order)
+ *               instead of by a second pass over the images in the reference's row order.
+ * The mode applies ONLY to tsdr_frames / _d / _submit_d / _scan_d.  The per-function entry points
+ * (tsdr_sig_to_image, tsdr_resize1d/2d, tsdr_downgrade, tsdr_vsync, ... and their _d forms) always run
+ * the TSDR_EXACT operation sequence.  Shift + IIR are evaluated identically in both modes. */
 enum tsdr_precision { TSDR_EXACT = 0, TSDR_FAST = 1 };
 int tsdr_set_precision(tsdr_ctx *ctx, int mode);
 int tsdr_get_precision(tsdr_ctx *ctx);
+/* Development switches (A/B timing, test coverage); results are parity-tested either way.
+ *   "ac_mixed"    1 (default): calculate_autocorrelation of n = 2*(2^a 3^b 5^c) samples runs the native length-n/2
+ *                 mixed-radix transform; 0: zero-padded power-of-two transform + fold.
+ *   "fft_no_mix2" 1: every mixed-radix factor goes through the generic LDS-stage kernel.  Default 0.
+ * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 preset them, read once in tsdr_create. */
+int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
 
 /* resident buffers for callers without their own device allocator */
 void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes);
@@ -239,6 +248,8 @@ int tsdr_ring_take_d(tsdr_ring *r, int timeout_ms, float **dev_iq);
 int tsdr_ring_stop(tsdr_ring *r);
 int tsdr_ring_stats(tsdr_ring *r, unsigned long long *produced, unsigned long long *consumed,
                     unsigned long long *overflow, double *producer_msps, double *consumer_msps);
+/* takes whose buffer had already been sent ahead (H2D under the previous buffer's kernels) / staged at take time */
+int tsdr_ring_prefetch_stats(tsdr_ring *r, unsigned long long *hits, unsigned long long *misses);
 
 /* ---- the same loop in two stages, for sharding ONE buffer's frames across GPUs ----
  * Stage 1 is independent per frame (shard frames across ranks, no collective): IQ -> 600x800 image

@@ -530,17 +530,32 @@ const float *orc_sync_beta_y(const orc_sync *s) { return s->beta_y; }
 
 /* ---- summation orders ---------------------------------------------------------------
  * The reference calls sum(image;dims=1), sum(image;dims=2) and sum(c_v) (FrameSynchronisation.jl
- * :61,:71,:96).  Julia evaluates these with @simd / pairwise reductions whose association order
- * depends on the machine's vector width, so no order is "the" reference order; any fixed order is
- * an equally faithful restatement (they differ at the 1e-7 relative level).  The orders below are
- * fixed once, documented, and reproduced operation for operation by the GPU kernels:
- *   sum64(x,n): lane m (0..63) accumulates x[m], x[m+64], ... in ascending order starting from
- *               0.0f; the 64 partials are folded by the tree v[i] += v[i+off], off = 32,16,..,1.
- *               Used for Sigma = sum(c_v).
- *   columns:    rows are cut into blocks of 64; each block is accumulated in ascending order
- *               from 0.0f and the block sums are added top to bottom (first block first).
- *   rows:       the n columns are cut into 8 chunks of ceil(n/8); each chunk is accumulated in
- *               ascending order from 0.0f and the chunks are added left to right. */
+ * :61,:71,:96).  Which Base code path each takes, and what that fixes [RECALLED: Base reducedim.jl /
+ * reduce.jl as of Julia 1.6-1.11; their source is not under /root/reference]:
+ *
+ *   sum(image;dims=2)  -> Base._mapreducedim!, the branch taken when the FIRST dimension is kept
+ *                         (`reducedim1(R, A)` false): R is initialised with zero(T) + zero(T), then
+ *                             for j in 1:x_t;  @simd for i in 1:y_t;  R[i] = R[i] + A[i,j]
+ *                         -- the @simd runs over i (independent accumulators), so every row's sum is
+ *                         STRICTLY LEFT TO RIGHT, starting from 0.0f: a deterministic order.
+ *                         => sum_rows() below, and the GPU reproduces it operation for operation.
+ *                         (Compile with -DORC_ROWSUM_CHUNK8 for the round-1 order -- 8 column chunks
+ *                         accumulated in order and added left to right -- kept only so that the
+ *                         effect of the choice can be measured; build flag of the same name in
+ *                         tempestsdr.jl_amd/build.py selects the matching GPU order.)
+ *   sum(image;dims=1)  -> the `reducedim1` branch: per column, `@simd for i; r = r + A[i,j]`.  Here
+ *                         @simd licenses re-association of the single accumulator, so the order
+ *                         depends on the vector width LLVM picks for the host CPU: no order is "the"
+ *                         reference order.  Fixed here as: rows cut into blocks of 64, each block
+ *                         accumulated in ascending order from 0.0f, block sums added top to bottom.
+ *   sum(c_v)           -> Base.mapreduce_impl on a Vector shorter than the pairwise block size
+ *                         (1024): `v = a[1] + a[2]; @simd for i = 3:n; v += a[i]` -- again @simd on
+ *                         one accumulator, machine-dependent association.  Fixed here as sum64():
+ *                         lane m (0..63) accumulates x[m], x[m+64], ... in ascending order from
+ *                         0.0f; the 64 partials are folded by the tree v[i] += v[i+off],
+ *                         off = 32,16,..,1.
+ * The two open orders differ from any other at the 1e-7 relative level and only matter for
+ * near-tied argmaxes; tests print the top-2 beta margin so that a tie would be visible. */
 static float tree64(float *v) {
   for (int off = 32; off > 0; off >>= 1)
     for (int i = 0; i < off; i++) v[i] = v[i] + v[i + off];
@@ -555,8 +570,8 @@ static float sum64(const float *x, int n) {
   }
   return tree64(p);
 }
-/* c_v[c] = sum of column c (y rows) ; c_h[r] = sum of row r (x columns); image column-major */
-static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
+/* c_v[c] = sum(image;dims=1)[c]: sum of column c over the y rows (image column-major) */
+static void sum_cols(const float *img, int y, int x, float *cv) {
   for (int c = 0; c < x; c++) {
     const float *col = img + (size_t)c * y;
     float tot = 0.0f;
@@ -567,6 +582,10 @@ static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
     }
     cv[c] = tot;
   }
+}
+/* c_h[r] = sum(image;dims=2)[r]: sum of row r over the x columns -- FrameSynchronisation.jl:71 */
+static void sum_rows(const float *img, int y, int x, float *ch) {
+#ifdef ORC_ROWSUM_CHUNK8
   const int chunk = (x + 7) / 8;
   for (int r = 0; r < y; r++) {
     float tot = 0.0f;
@@ -577,16 +596,40 @@ static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
     }
     ch[r] = tot;
   }
+#else
+  for (int r = 0; r < y; r++) ch[r] = 0.0f + 0.0f;          /* reducedim_init: zero(T) + zero(T) */
+  for (int c = 0; c < x; c++) {                              /* columns outermost, as Base walks A */
+    const float *col = img + (size_t)c * y;
+    for (int r = 0; r < y; r++) ch[r] = ch[r] + col[r];
+  }
+#endif
+}
+static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
+  sum_cols(img, y, x, cv);
+  sum_rows(img, y, x, ch);
 }
 
-/* DSP.filt(h,x) [RECALLED]: causal FIR, zero initial state, same length;
- * transposed direct form, plain f32 multiply-add. */
+/* DSP.filt(h,x) for a short FIR [RECALLED: DSP.jl >= 0.7 filt.jl -- filt(b::AbstractVector, x) with
+ * length(b) below the small-filter cutoff goes to the @generated _filt_fir!/_small_filt_fir!, a
+ * transposed-direct-form loop written with muladd:
+ *     val  = muladd(x_i, b[1], si_1)
+ *     si_j = muladd(x_i, b[j+1], si_{j+1})     j = 1 .. N-2
+ *     si_{N-1} = b[N] * x_i
+ * with zero initial state and length(out) == length(x)].  muladd on Float32 lowers to a fused
+ * multiply-add on every CPU Julia supports with FMA hardware (x86-64 Haswell+, AArch64), so the
+ * chain is restated with fmaf.  -DORC_FIR_NOFMA gives the unfused form (DSP.jl <= 0.6, or a
+ * machine without FMA); the build flag of the same name selects the matching GPU code. */
 static void fir_filt(const float *h, int nh, const float *x, int n, float *y) {
   float si[8] = {0};
   for (int i = 0; i < n; i++) {
     float xi = x[i];
+#ifdef ORC_FIR_NOFMA
     float val = si[0] + h[0] * xi;
     for (int j = 0; j < nh - 2; j++) si[j] = si[j + 1] + h[j + 1] * xi;
+#else
+    float val = fmaf(xi, h[0], si[0]);
+    for (int j = 0; j < nh - 2; j++) si[j] = fmaf(xi, h[j + 1], si[j + 1]);
+#endif
     si[nh - 2] = h[nh - 1] * xi;
     y[i] = val;
   }

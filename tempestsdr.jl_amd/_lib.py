@@ -40,6 +40,7 @@ _SIGS = {
     "tsdr_synchronize": (C.c_int, [vp]),
     "tsdr_set_precision": (C.c_int, [vp, C.c_int]),
     "tsdr_get_precision": (C.c_int, [vp]),
+    "tsdr_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "tsdr_device_info": (C.c_int, [vp, C.c_char_p, c_sz, c_i, c_szp]),
     "tsdr_dev_alloc": (vp, [vp, c_sz]),
     "tsdr_dev_free": (C.c_int, [vp, vp]),
@@ -117,6 +118,7 @@ _SIGS = {
     "tsdr_ring_stop": (C.c_int, [vp]),
     "tsdr_ring_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tsdr_ring_prefetch_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "tsdr_frames_scan_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, c_i]),
     "tsdr_frames_combine_d": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
 }

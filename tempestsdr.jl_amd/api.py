@@ -79,6 +79,10 @@ class Context:
     def precision(self):
         return "exact" if self.lib.tsdr_get_precision(self.h) == _lib.EXACT else "fast"
 
+    def set_option(self, name, value):
+        """development switches ("ac_mixed", "fft_no_mix2") -- tsdr_set_option"""
+        self.call("tsdr_set_option", name.encode(), int(value))
+
     def set_stream(self, stream_ptr):
         self.call("tsdr_set_stream", C.c_void_p(stream_ptr or 0))
 
@@ -377,8 +381,10 @@ class StagingRing:
         rp, rc_ = C.c_double(0), C.c_double(0)
         self._chk(self.ctx.lib.tsdr_ring_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(rp), C.byref(rc_)),
                   "tsdr_ring_stats")
+        h, m = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._chk(self.ctx.lib.tsdr_ring_prefetch_stats(self.h, C.byref(h), C.byref(m)), "tsdr_ring_prefetch_stats")
         return {"produced": a.value, "consumed": b.value, "overflow": c.value, "producer_msps": rp.value,
-                "consumer_msps": rc_.value}
+                "consumer_msps": rc_.value, "prefetch_hits": h.value, "prefetch_misses": m.value}
 
     def close(self):
         if self.h:

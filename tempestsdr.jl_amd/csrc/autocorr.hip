@@ -175,8 +175,7 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
   // correlation of length n is transformed natively -- no zero padding, no fold, half the bytes (or less) of the
   // padded route below, which remains for every other n.
   const bool half_pow2 = (n & 1) == 0 && is_pow2(n / 2);
-  // (the mixed-radix passes are not yet faster per search than the padded power-of-two route: opt-in for now)
-  const bool mixed_on = getenv("TSDR_AC_MIXED") != nullptr;
+  const bool mixed_on = ctx->opt_ac_mixed != 0;
   if ((n & 1) == 0 && n > 1024 && (half_pow2 || (mixed_on && fft_mixed_ok(n / 2))) &&
       (!is_iq || (reinterpret_cast<uintptr_t>(x) & 15u) == 0)) {
     const size_t Mc = n / 2;

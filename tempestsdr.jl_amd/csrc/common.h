@@ -23,6 +23,7 @@ enum Slot {
   WS_IMG,         // per-frame 600x800 images of one buffer
   WS_PROJ,        // raw + filtered projections, sums
   WS_KEYS,        // packed argmax keys per frame
+  WS_CV,          // filtered projections + their sums per frame
   WS_FFT_A,       // FFT ping
   WS_FFT_B,       // FFT pong
   WS_FFT_C,       // Bluestein / correlation scratch
@@ -58,6 +59,9 @@ struct tsdr_ctx {
   std::string err;
   int cu_count = 0;
   int precision = TSDR_FAST;  // tsdr_precision
+  // development switches (tsdr_set_option; environment variables of the same upper-case names are read ONCE, in tsdr_create)
+  int opt_ac_mixed = 1;     // autocorrelation of n = 2*(2^a3^b5^c) samples: native mixed-radix route (0: zero-padded power of two)
+  int opt_fft_no_mix2 = 0;  // 1: every mixed-radix factor through the generic LDS-stage kernel
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];
   // profiling
   bool prof_on = false;
@@ -77,6 +81,7 @@ struct tsdr_ctx {
   hipStream_t pipe_r = nullptr, pipe_s = nullptr;
   hipEvent_t pipe_in = nullptr, pipe_er[2] = {nullptr, nullptr}, pipe_es[2] = {nullptr, nullptr};
   unsigned long long pipe_n = 0;  // submissions since the last flush point
+  size_t pipe_nb = 0;             // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
 
   void *scratch(int slot, size_t bytes);  // nullptr on failure (err set)
 };

@@ -1,5 +1,6 @@
 // ctx.hip -- context lifetime, workspace, error reporting, HIP-event measurement.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -122,6 +123,9 @@ tsdr_ctx *tsdr_create(int device) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
   (void)hipEventCreate(&ctx->t0);
   (void)hipEventCreate(&ctx->t1);
+  // development switches: the environment is consulted here and nowhere else
+  if (const char *e = getenv("TSDR_AC_MIXED")) ctx->opt_ac_mixed = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_FFT_NO_MIX2")) ctx->opt_fft_no_mix2 = atoi(e) != 0;
   return ctx;
 }
 
@@ -169,6 +173,14 @@ int tsdr_set_precision(tsdr_ctx *ctx, int mode) {
 }
 
 int tsdr_get_precision(tsdr_ctx *ctx) { return ctx ? ctx->precision : TSDR_EINVAL; }
+
+int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
+  if (!ctx || !name) return TSDR_EINVAL;
+  if (!strcmp(name, "ac_mixed")) ctx->opt_ac_mixed = value != 0;
+  else if (!strcmp(name, "fft_no_mix2")) ctx->opt_fft_no_mix2 = value != 0;
+  else return tsdr::set_err(ctx, TSDR_EINVAL, "unknown option '%s'", name);
+  return TSDR_OK;
+}
 
 int tsdr_synchronize(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;

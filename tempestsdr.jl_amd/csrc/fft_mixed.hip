@@ -658,7 +658,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     d.mode = FFT_STRIDED;
     d.src_mode = i == 0 ? src_mode : SRC_C2C;
     d.src_n = src_n;
-    const Mix2Entry *m2 = getenv("TSDR_FFT_NO_MIX2") ? nullptr : mix2_lookup(d.R);
+    const Mix2Entry *m2 = ctx->opt_fft_no_mix2 ? nullptr : mix2_lookup(d.R);
     // (the two-step kernels keep their full tile: a narrower one leaves most threads without a step-1 DFT)
     d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2((unsigned)B)}),
                        m2 ? 8 : 4, batch * P, B);
@@ -690,7 +690,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   d.mode = FFT_LAST;
   d.src_mode = SRC_C2C;
   d.R1 = pl.R[0];
-  const Mix2Entry *m2 = getenv("TSDR_FFT_NO_MIX2") ? nullptr : mix2_lookup(d.R);
+  const Mix2Entry *m2 = ctx->opt_fft_no_mix2 ? nullptr : mix2_lookup(d.R);
   d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2(d.R1)}), m2 ? 8 : 4,
                      batch * (P / pl.R[0]), d.R1);
   d.scale = scale;

@@ -10,14 +10,21 @@
 // recurrence -- are resolved inside shift_iir/sync_publish, so everything upstream is parallel
 // over frames.  No host synchronisation happens in the _d entry point.
 #include "common.h"
+#include "sync_layout.h"
 
 struct tsdr_sync;
 
 namespace tsdr {
+// proj != nullptr: the kernel may also leave the projection partial sums of every (h_out, w_out) image there
+// (TSDR_FAST in-walk sums); *got then describes them (ncp == 0: nothing was produced).  plan_only: no launch, only
+// report in *got what a real call would produce.
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
-                      int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride);
-int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long **keys_out,
-                size_t proj_offset);
+                      int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride,
+                      float *proj = nullptr, ProjLayout *got = nullptr, bool plan_only = false);
+int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
+                const ProjLayout *have, float *cvb);
+int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj, float **cvb,
+                   unsigned long long **keys);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx);
@@ -37,6 +44,47 @@ static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
   return TSDR_OK;
 }
 
+// The loop body for F frames.  Stage R: raster (optional) + 600x800 image of every frame in one launch; in TSDR_FAST
+// mode the same kernel also forms the images' projection partial sums on the fly, so no kernel re-reads the images
+// for them.  Stage S: vsync statistics (two argmax keys per frame) and, with `combine`, shift + IIR.
+// slot/nslots: which half of the sync workspaces this buffer uses.  pipelined: stage R is enqueued on pipe_r and
+// stage S on pipe_s behind it (tsdr_frames_submit_d); else everything goes to the context's stream.
+static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t S, int y_t, int x_t, int do_align, int F,
+                        float *img, float *raster_out, unsigned long long *keys, int slot, int nslots, float alpha,
+                        float *state, float *frames_out, int *sync_idx, bool pipelined, bool combine = true) {
+  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
+  float *proj = nullptr, *cvb = nullptr;
+  ProjLayout plan{}, got{};
+  int rc;
+  if (do_align) {
+    rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx,
+                           nullptr, &plan, true);
+    if (rc) return rc;
+    rc = sync_workspace(sync, F, slot, nslots, plan.ncp ? &plan : nullptr, &proj, &cvb, nullptr);
+    if (rc) return rc;
+  }
+  if (pipelined) ctx->launch_stream = ctx->pipe_r;
+  rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx,
+                         proj, &got);
+  if (rc) return rc;
+  if (pipelined) {
+    TSDR_HIP(ctx, hipEventRecord(ctx->pipe_er[slot], ctx->pipe_r));
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_er[slot], 0));
+    ctx->launch_stream = ctx->pipe_s;
+  }
+  if (do_align) {
+    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, cvb);
+    if (rc) return rc;
+  }
+  if (combine) {
+    rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, state, frames_out,
+                     do_align ? sync_idx : nullptr);
+    if (rc) return rc;
+  }
+  if (pipelined) TSDR_HIP(ctx, hipEventRecord(ctx->pipe_es[slot], ctx->pipe_s));
+  return TSDR_OK;
+}
+
 int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
                        int do_align, float *img_out, float *raster_out, unsigned long long *keys_out, int *n_frames) {
   if (!ctx || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
@@ -49,17 +97,8 @@ int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t n
   if (nb == 0) return TSDR_OK;
   if (!img_out || (do_align && !keys_out)) return TSDR_EINVAL;
   const int F = (int)nb;
-  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
-  // one launch produces raster + 600x800 image when the raster is wanted; else the raster-free fused kernel
-  rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img_out,
-                         npx);
-  if (rc) return rc;
-  if (do_align) {
-    unsigned long long *keys = keys_out;
-    rc = sync_scan_d(sync, img_out, npx, F, &keys, 0);
-    if (rc) return rc;
-  }
-  return TSDR_OK;
+  return frames_stage(ctx, sync, iq, S, y_t, x_t, do_align, F, img_out, raster_out, keys_out, 0, 1, 0.0f, nullptr, nullptr, nullptr,
+                      /*pipelined=*/false, /*combine=*/false);
 }
 
 int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, const unsigned long long *keys, int n_frames,
@@ -115,6 +154,14 @@ static int pipe_init(tsdr_ctx *ctx) {
   return TSDR_OK;
 }
 
+namespace {
+struct LaunchStreamGuard {  // TSDR_LAUNCH targets ctx->launch_stream: whatever path leaves submit, it is the caller's again
+  tsdr_ctx *ctx;
+  explicit LaunchStreamGuard(tsdr_ctx *c) : ctx(c) {}
+  ~LaunchStreamGuard() { ctx->launch_stream = ctx->stream; }
+};
+}  // namespace
+
 int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                          int *sync_idx, int *n_frames) {
@@ -130,31 +177,32 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   if (rc) return rc;
   const int F = (int)nb;
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
+  // The two image slots sit nb frames apart, so a submission whose frame count differs from the one in flight (S or
+  // nEch changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images stage S of the previous buffer is still
+  // reading.  Such a submission first lets the pipeline run empty -- on the device, nothing waits on the host.
+  if (ctx->pipe_n > 0 && ctx->pipe_nb != nb) {
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_es[(ctx->pipe_n - 1) & 1ull], 0));
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_es[(ctx->pipe_n - 1) & 1ull], 0));
+    ctx->pipe_n = 0;
+  }
+  ctx->pipe_nb = nb;
   const unsigned slot = (unsigned)(ctx->pipe_n & 1ull);
   float *img2 = (float *)ctx->scratch(WS_IMG, 2 * nb * npx * 4);  // a growing buffer drains the pipeline first
   unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, nb * 2 * 8);
   if (!img2 || !keys) return TSDR_ENOMEM;
   float *img = img2 + (size_t)slot * nb * npx;
+  LaunchStreamGuard guard(ctx);
   // whatever produced iq / the state on the caller's stream comes first
   TSDR_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));
   TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_in, 0));
   TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_in, 0));
   if (ctx->pipe_n >= 2) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_es[slot], 0));  // image slot free again
-  ctx->launch_stream = ctx->pipe_r;
-  rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx);
-  if (!rc) {
-    TSDR_HIP(ctx, hipEventRecord(ctx->pipe_er[slot], ctx->pipe_r));
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_er[slot], 0));
-    ctx->launch_stream = ctx->pipe_s;
-    if (do_align) rc = sync_scan_d(sync, img, npx, F, &keys, 0);
-    if (!rc)
-      rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
-                       do_align ? sync_idx : nullptr);
-    if (!rc) TSDR_HIP(ctx, hipEventRecord(ctx->pipe_es[slot], ctx->pipe_s));
-  }
-  ctx->launch_stream = ctx->stream;
-  if (!rc) ++ctx->pipe_n;
-  return rc;
+  // stage R on pipe_r: raster + images (+ in-walk projection sums); stage S on pipe_s: statistics, shift, IIR
+  rc = frames_stage(ctx, sync, iq, S, y_t, x_t, do_align, F, img, raster_out, keys, (int)slot, 2, alpha, imageOut_state,
+                    frames_out, sync_idx, /*pipelined=*/true);
+  if (rc) return rc;
+  ++ctx->pipe_n;
+  return TSDR_OK;
 }
 
 int tsdr_frames_flush(tsdr_ctx *ctx) {

@@ -26,6 +26,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "sync_layout.h"
 
 namespace tsdr {
 
@@ -891,7 +892,9 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   if (frames <= 0) return TSDR_OK;
   const size_t P = (size_t)y_t * x_t;
   const double sf = (double)S / (double)P;
-  const bool exact = ctx->precision == TSDR_EXACT || P >= (size_t(1) << 30);
+  // TSDR_FAST exists for the steady-state frame loop (tsdr_frames*), whose input is IQ; the per-function entry
+  // points (real input) always run the oracle's operation sequence
+  const bool exact = ctx->precision == TSDR_EXACT || !cplx || P >= (size_t(1) << 30);
   // fused downgrade in the raster launch: only when both axes shrink (<= 66 x 130 candidates per tile)
   const bool want_down = down && !(y_t == h_out && x_t == w_out) && y_t >= 2 * 64 && x_t >= 2 * 128 &&
                          (double)y_t / h_out >= 1.0 && (double)x_t / w_out >= 1.0;
@@ -960,7 +963,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       TSDR_LAUNCH(ctx, NAME, (k_raster_fast<C, W32, D, PW, true, VWK>), grid, dim3(256 * VWK), lds, in, in_stride, q, fa,   \
                   fi, out, out_stride, down, down_stride);                                                             \
     } else {                                                                                                          \
-      TSDR_LAUNCH(ctx, (C ? "down_walk_iq" : "down_walk_f32"), (k_raster_fast<C, W32, D, PW, false, VWK>), grid,          \
+      TSDR_LAUNCH(ctx, "down_walk_iq", (k_raster_fast<C, W32, D, PW, false, VWK>), grid,                                \
                   dim3(256 * VWK), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);                   \
     }                                                                                                                 \
   } while (0)
@@ -981,12 +984,10 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     }                                                                                                                 \
   } while (0)
     if (dn) {
-      if (cplx) { if (w32) { FASTK(true, true, true, "raster_down_iq"); } else { FASTK(true, false, true, "raster_down_iq"); } }
-      else { if (w32) { FASTK(false, true, true, "raster_down_f32"); } else { FASTK(false, false, true, "raster_down_f32"); } }
+      if (w32) { FASTK(true, true, true, "raster_down_iq"); } else { FASTK(true, false, true, "raster_down_iq"); }
       if (did_down) *did_down = true;
     } else {
-      if (cplx) { if (w32) { FASTK(true, true, false, "raster_iq"); } else { FASTK(true, false, false, "raster_iq"); } }
-      else { if (w32) { FASTK(false, true, false, "raster_f32"); } else { FASTK(false, false, false, "raster_f32"); } }
+      if (w32) { FASTK(true, true, false, "raster_iq"); } else { FASTK(true, false, false, "raster_iq"); }
     }
 #undef FASTK1
 #undef FASTK2
@@ -1100,7 +1101,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   // imresize returns a copy when the sizes already match: the raster IS the result
   if (same2) return raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, out, out_stride);
   const size_t P = (size_t)y_t * x_t;
-  const bool exact = ctx->precision == TSDR_EXACT;
+  const bool exact = ctx->precision == TSDR_EXACT || !cplx;
   DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact);
   if (pl.fused) {
     dim3 grid((unsigned)(ceil_div((size_t)h_out, 64) * (size_t)pl.q.tiles_c), (unsigned)frames);
@@ -1110,9 +1111,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
       else if (pl.mode == DM_FAST_PAIR) { DOWNK(true, DM_FAST_PAIR, "down_fused_iq"); }
       else { DOWNK(true, DM_FAST_F32, "down_fused_iq"); }
     } else {
-      if (pl.mode == DM_EXACT) { DOWNK(false, DM_EXACT, "down_fused_f32_exact"); }
-      else if (pl.mode == DM_FAST_PAIR) { DOWNK(false, DM_FAST_PAIR, "down_fused_f32"); }
-      else { DOWNK(false, DM_FAST_F32, "down_fused_f32"); }
+      DOWNK(false, DM_EXACT, "down_fused_f32_exact");
     }
 #undef DOWNK
     return TSDR_OK;
@@ -1131,10 +1130,14 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
 
 // raster (optional) + (h_out,w_out) image for every frame with as few passes over IQ as possible
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
-                      int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride) {
+                      int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride,
+                      float *proj, ProjLayout *got, bool plan_only) {
+  if (got) *got = ProjLayout{};
+  if (plan_only) return TSDR_OK;
+  (void)proj;
   // FAST without a raster to write: the tile kernel still wins (its walk produces the raster values in registers and
   // downgrades them on the spot; k_down_fused re-derives four taps per output pixel), so it runs with out == null
-  if (raster || ctx->precision == TSDR_FAST) {
+  if (raster || (ctx->precision == TSDR_FAST && cplx)) {
     bool did = false;
     int rc = raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, raster, raster_stride, down, down_stride, h_out,
                              w_out, &did);

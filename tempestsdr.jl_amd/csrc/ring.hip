@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -36,12 +37,17 @@ struct tsdr_ring {
   bool stop = false;
   // which slot sequence number sits (or is arriving) in dev[i]; -1 = none
   long long staged_seq[2] = {-1, -1};
+  // generation of every host slot (bumped each time the producer publishes it) and the generation the slot had
+  // when the DMA into dev[i] was issued: a prefetch is good only while the producer has not rewritten that slot
+  std::vector<unsigned long long> slot_gen;
+  unsigned long long staged_gen[2] = {0, 0};
   int next_dev = 0;
   int dma_slot[2] = {-1, -1};   // host slot the last DMA into dev[i] reads (guards against a lapping producer)
   int writing_slot = -1;         // slot the producer is filling right now
   bool staging[2] = {false, false};  // a DMA into dev[i] is being enqueued (its `ready` event is not recorded yet)
   long long seq_written = 0, seq_read = 0;  // counts of put / take
   unsigned long long produced = 0, consumed = 0, overflow = 0;
+  unsigned long long prefetch_hits = 0, prefetch_misses = 0;  // takes served by the DMA sent ahead / staged at take time
   std::chrono::steady_clock::time_point t0;
 };
 
@@ -84,6 +90,7 @@ int tsdr_ring_create(tsdr_ctx *ctx, size_t nEch, int depth, int fmt, float scale
   tsdr_ring *r = new tsdr_ring();
   r->ctx = ctx; r->nEch = nEch; r->depth = depth; r->fmt = fmt; r->scale = scale;
   r->slot_bytes = nEch * (fmt == 0 ? 8 : 4);
+  r->slot_gen.assign((size_t)depth, 0ull);
   bool ok = hipHostMalloc((void **)&r->host, r->slot_bytes * depth, hipHostMallocDefault) == hipSuccess;
   for (int i = 0; i < 2 && ok; ++i) {
     ok = hipMalloc((void **)&r->dev[i], nEch * 8) == hipSuccess;
@@ -133,6 +140,7 @@ static void ring_publish(tsdr_ring *r) {
   {
     std::lock_guard<std::mutex> g(r->m);
     r->writing_slot = -1;
+    ++r->slot_gen[(size_t)r->ptr_write];                           // this slot now holds a newer buffer
     r->ptr_write = (r->ptr_write + 1) % r->depth;                  // atomic_update
     if (r->t_new == r->depth) ++r->overflow;                        // the oldest unread buffer was just overwritten
     r->t_new = r->t_new + 1 < r->depth ? r->t_new + 1 : r->depth;  // atomic_prodData: min(ptr+1, depth)
@@ -192,10 +200,13 @@ int tsdr_ring_take_d(tsdr_ring *r, int timeout_ms, float **dev_iq) {
     r->ptr_read = (r->ptr_read + 1) % r->depth;   // atomic_update
     r->t_new -= 1;                                 // atomic_consData
     ++r->consumed;
-    // was this slot already sent ahead?  (a prefetch is only valid if the producer has not lapped it since)
+    // was this slot already sent ahead?  A prefetch is valid only if the producer has not rewritten the slot since
+    // the DMA was issued (a full ring overwrites slot ptr_read itself, :125-129).  The test is per slot: lifetime
+    // counters would include every overflow ever recorded and never recover after the first `depth` drops.
     d = r->next_dev;
-    staged = r->staged_seq[d] == r->seq_read && r->seq_written - r->seq_read <= r->depth;
+    staged = r->staged_seq[d] == r->seq_read && r->staged_gen[d] == r->slot_gen[(size_t)slot];
     ++r->seq_read;
+    if (staged) ++r->prefetch_hits; else ++r->prefetch_misses;
     if (!staged) { r->dma_slot[d] = slot; r->staging[d] = true; }
   }
   // the device buffer about to be refilled further down (the other one) was handed out two takes ago: the
@@ -220,6 +231,7 @@ int tsdr_ring_take_d(tsdr_ring *r, int timeout_ms, float **dev_iq) {
     if (r->t_new > 0 && r->writing_slot != r->ptr_read) {
       nslot = r->ptr_read;
       r->staged_seq[d ^ 1] = r->seq_read;
+      r->staged_gen[d ^ 1] = r->slot_gen[(size_t)nslot];
       r->dma_slot[d ^ 1] = nslot;
       r->staging[d ^ 1] = true;
     }
@@ -252,6 +264,16 @@ int tsdr_ring_stats(tsdr_ring *r, unsigned long long *produced, unsigned long lo
   if (overflow) *overflow = r->overflow;
   if (producer_msps) *producer_msps = dt > 0 ? (double)r->produced * (double)r->nEch / dt / 1e6 : 0.0;
   if (consumer_msps) *consumer_msps = dt > 0 ? (double)r->consumed * (double)r->nEch / dt / 1e6 : 0.0;
+  return TSDR_OK;
+}
+
+/* how many takes found their buffer already sent ahead (H2D overlapped with the previous buffer's kernels) and how
+ * many had to stage it at take time (first take, empty ring, or a slot the producer rewrote after the prefetch) */
+int tsdr_ring_prefetch_stats(tsdr_ring *r, unsigned long long *hits, unsigned long long *misses) {
+  if (!r) return TSDR_EINVAL;
+  std::lock_guard<std::mutex> g(r->m);
+  if (hits) *hits = r->prefetch_hits;
+  if (misses) *misses = r->prefetch_misses;
   return TSDR_OK;
 }
 

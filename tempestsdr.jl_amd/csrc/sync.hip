@@ -6,28 +6,33 @@
 //   circshift + IIR              GUI.jl:172,175
 //
 // The arithmetic follows the oracle's evaluation ORDER, not only its formulas, so that for the same image
-// the projections, beta values and therefore the argmax indices are bit-identical:
-//   * column sums: 64-row blocks, each accumulated in order, block sums added top to bottom; row sums: 8 column
-//     chunks, each accumulated in order, added left to right; Sigma = sum(c_v) in sum64 order (lane m
-//     accumulates elements m, m+64, ..., then the xor-butterfly 32,16,..,1 = the oracle's tree64).
-//     Julia's own sum() order is SIMD-width dependent, so no order is "the" reference's; these are fixed,
-//     documented in the oracle, and shaped so that ONE pass over the image yields every partial sum,
-//   * the 5-tap causal FIR uses the transposed-direct-form association
-//       y[i] = ((((h4 x[i-4]) + h3 x[i-3]) + h2 x[i-2]) + h1 x[i-1]) + h0 x[i],
+// the projections, beta values and therefore the argmax indices are bit-identical (oracle: "summation orders"):
+//   * row sums  sum(image;dims=2): STRICTLY left to right from 0.0f -- the order Base's _mapreducedim! fixes when
+//     the first dimension is kept.  One lane owns a row; the eight wavefronts of a workgroup take turns along the
+//     columns and hand the running sums on through LDS, so the loads of all eight run in parallel while the adds
+//     stay one chain (k_proj);
+//   * column sums  sum(image;dims=1): Julia leaves the order to @simd; fixed as 64-row blocks, each accumulated in
+//     order, block sums added top to bottom;  Sigma = sum(c_v) likewise open, fixed in sum64 order (lane m
+//     accumulates elements m, m+64, ..., then the xor-butterfly 32,16,..,1 = the oracle's tree64);
+//   * the 5-tap causal FIR is DSP.jl's transposed-direct-form muladd chain,
+//       y[i] = fma(x[i],h0, fma(x[i-1],h1, fma(x[i-2],h2, fma(x[i-3],h3, h4*x[i-4]))))   (x[<0] = 0);
 //   * each centre's running blank sum _Sigma is the reference's sequential recurrence over w.
-// Launches per buffer: k_proj (one pass over every image: per-(row block, chunk) partial sums) and k_beta
-// (fold partials -> FIR -> Sigma -> beta scan -> argmax).  In k_beta four lanes share one blank-band centre:
-// each replays the cheap running-sum prefix (adds only, same order => same bits) and evaluates a quarter of the
-// widths.  The two divisions per width are by small integers: they use a table of correctly rounded
-// reciprocals and Markstein's two-FMA correction, which returns the correctly rounded quotient (bit-identical
-// to IEEE division) at a third of the instruction count.
+// Launches per buffer: k_proj (one pass over every image) or, in TSDR_FAST mode, the partial sums the raster
+// kernel forms on the fly; k_fold (partials -> raw projections -> FIR -> Sigma, once per frame and axis); k_beta
+// (beta scan + argmax).  In k_beta LPC lanes share one blank-band centre: each replays the cheap running-sum
+// prefix (adds only, same order => same bits) and evaluates its share of the widths, so the 2*(w_min+W) serial
+// adds of a centre are the only serial part and the ~20 operations per (centre, w) run LPC-wide.  The two
+// divisions per width are by small integers: a table of correctly rounded reciprocals and Markstein's two-FMA
+// correction return the correctly rounded quotient (bit-identical to IEEE division) at a third of the
+// instruction count.
 // The argmax over (w,c) is a lane-local scan, a 64-wide shuffle reduction and one 64-bit atomicMax per
 // wavefront on a packed key (beta bits << 32 | ~c): beta >= +0 so its bit pattern is order-preserving, NaN
 // patterns sort above +Inf (Julia's findmax treats NaN as maximal), and ~c makes the smallest column win
-// ties = first maximum in column-major order.
+// ties = first maximum in column-major order (only the column of the maximum is ever used, :66,:76).
 #include <algorithm>
 
 #include "common.h"
+#include "sync_layout.h"
 
 struct tsdr_sync {
   tsdr_ctx *ctx;
@@ -47,36 +52,99 @@ struct SyncGeom {
   float h0, h1, h2, h3, h4;
 };
 
-// proj layout per frame: colpart[nrb][x_t] (64-row block sums of every column) | rowpart[8][y_t] (chunk sums of
-// every row); nrb = ceil(y_t/64)
-__host__ __device__ inline size_t proj_stride(int y_t, int x_t) { return (size_t)((y_t + 63) >> 6) * x_t + (size_t)8 * y_t; }
-
 __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+off], off = 32..1 ; result in lane 0
   for (int off = 32; off > 0; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
   return v;
 }
 
 // ---- projections: ONE pass over the image ---------------------------------------------------------------
-// One wavefront per (64-row block, column chunk): lanes are rows.  Each lane folds its row across the chunk's
-// columns in order (-> rowpart[chunk][row]) while the values go through an LDS tile; then lanes become columns
-// and fold the tile's 64 rows in order (-> colpart[block][column]).  grid = (8 * nrb, frames).
+#ifndef TSDR_ROWSUM_CHUNK8
+// Workgroup = (frame, 64-row block), 8 wavefronts; lanes are rows.  The columns go by in rounds of 8*SUB: wavefront j
+// loads the SUB columns [8*SUB*round + SUB*j, +SUB) of its rows (SUB coalesced 256-byte loads in flight), passes them
+// through its own LDS tile so that lanes-as-columns can fold the 64 rows in order (-> colpart[block][column]),
+// and then the eight wavefronts add their SUB values to the row's running sum one after the other, wavefront 0
+// first: the row sum is one left-to-right chain (-> rowpart[0][row], already final), but only the adds are serial.
+// The next round's loads are issued before the chain, so HBM latency overlaps it.  grid = (nrb, frames).
+__global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
+                                              float *__restrict__ proj, size_t proj_stride) {
+  constexpr int SUB = 24, PITCH = SUB + 1, RND = 8 * SUB;  // 8 tiles of 64 x 25 floats = 50 KiB of LDS
+  __shared__ float tile[8][64 * PITCH];
+  __shared__ float chain[64];
+  const int f = blockIdx.y, rb = blockIdx.x;
+  const int nrb = (y_t + 63) >> 6;
+  const float *im = img + (size_t)f * img_stride;
+  float *pr = proj + (size_t)f * proj_stride;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = rb * 64 + lane;
+  const bool rv = r < y_t;
+  const int nval = min(64, y_t - rb * 64);
+  const float *p = im + (rv ? r : 0);
+  float *mytile = tile[wave];
+  const int rounds = (x_t + RND - 1) / RND;
+  float v[SUB], nx[SUB];
+  auto load = [&](int round, float (&dst)[SUB]) {
+    const int cs = round * RND + wave * SUB;
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) dst[u] = (rv && cs + u < x_t) ? p[(size_t)(cs + u) * y_t] : 0.0f;
+  };
+  load(0, v);
+  for (int round = 0; round < rounds; ++round) {
+    const int cs = round * RND + wave * SUB;
+    const int nc = max(0, min(SUB, x_t - cs));
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) mytile[lane * PITCH + u] = v[u];
+    if (round + 1 < rounds) load(round + 1, nx);
+    __syncthreads();
+    if (lane < nc) {  // lanes become columns: the rows of the block in row order
+      float t = 0.0f;
+      const float *col = mytile + lane;
+      int rr = 0;
+      for (; rr + 16 <= nval; rr += 16) {  // reads first, then the adds
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = col[(rr + u) * PITCH];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t = __fadd_rn(t, w[u]);
+      }
+      for (; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
+      pr[(size_t)rb * x_t + cs + lane] = t;
+    }
+    for (int k = 0; k < 8; ++k) {  // the row chain: wavefront k's turn
+      if (wave == k && nc > 0) {
+        float a = (round == 0 && k == 0) ? 0.0f : chain[lane];
+        if (nc == SUB) {
+#pragma unroll
+          for (int u = 0; u < SUB; ++u) a = __fadd_rn(a, v[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < SUB; ++u) if (u < nc) a = __fadd_rn(a, v[u]);
+        }
+        chain[lane] = a;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) v[u] = nx[u];
+  }
+  if (wave == 0 && rv) pr[(size_t)nrb * x_t + r] = chain[lane];
+}
+constexpr int kProjRowParts = 1;
+static inline dim3 proj_grid(int y_t, int frames) { return dim3((unsigned)((y_t + 63) >> 6), (unsigned)frames); }
+static inline dim3 proj_block() { return dim3(512); }
+#else
+// Round-1 order (compile-time alternative, see the oracle's ORC_ROWSUM_CHUNK8): row sums in 8 column chunks, each
+// accumulated in order from 0.0f, the chunk sums added left to right by k_fold.  One wavefront per (64-row block,
+// column chunk); grid = (8 * nrb, frames).
 __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                             float *__restrict__ proj, unsigned long long *__restrict__ keys) {
-  // The chunk goes through LDS in sub-tiles of SUB columns: [64][SUB + 1] floats = 8.4 KiB, so that every workgroup
-  // of the launch is resident at once (the whole-chunk tile, 26 KiB at 800 columns, held a CU to six single-wave
-  // workgroups and the 2400 of a C2 buffer ran in two rounds).
+                                             float *__restrict__ proj, size_t proj_stride) {
   constexpr int SUB = 32, PITCH = SUB + 1;
   __shared__ float tile[64 * PITCH];
   const int f = blockIdx.y;
   const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3;
-  // workgroups are dealt round-robin over the 8 XCDs and there are 8 column chunks: chunk = id mod 8 keeps all row
-  // blocks of a chunk on one XCD, so the 128-byte lines straddling two row blocks (600 rows * 4 B is not a multiple
-  // of 128) are fetched into one L2 once instead of into two
   const int j = blockIdx.x & 7, rb = blockIdx.x >> 3;
   const float *im = img + (size_t)f * img_stride;
-  float *pr = proj + (size_t)f * proj_stride(y_t, x_t);
+  float *pr = proj + (size_t)f * proj_stride;
   const int lane = threadIdx.x;
-  if (blockIdx.x == 0 && lane < 2) keys[(size_t)f * 2 + lane] = 0ull;
   const int r = rb * 64 + lane;
   const bool rv = r < y_t;
   const int c0 = j * chunk, c1 = min(c0 + chunk, x_t);
@@ -85,35 +153,23 @@ __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size
   float a = 0.0f;
   for (int cs = c0; cs < c1; cs += SUB) {
     const int nc = min(SUB, c1 - cs);
-    if (nc == SUB) {  // SUB independent coalesced loads in flight, folded in column order
-      float v[SUB];
-#pragma unroll
-      for (int u = 0; u < SUB; ++u) v[u] = p[(size_t)u * y_t];
-#pragma unroll
-      for (int u = 0; u < SUB; ++u) { a = __fadd_rn(a, v[u]); tile[lane * PITCH + u] = v[u]; }
-    } else {
-      for (int u = 0; u < nc; ++u) { const float v = p[(size_t)u * y_t]; a = __fadd_rn(a, v); tile[lane * PITCH + u] = v; }
-    }
+    for (int u = 0; u < nc; ++u) { const float v = p[(size_t)u * y_t]; a = __fadd_rn(a, v); tile[lane * PITCH + u] = v; }
     p += (size_t)SUB * y_t;
     __syncthreads();
-    if (lane < nc) {  // lanes become columns: the 64 rows of the block in row order
+    if (lane < nc) {
       float t = 0.0f;
       const float *col = tile + lane;
-      int rr = 0;
-      for (; rr + 16 <= nval; rr += 16) {  // reads first, then the adds
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = col[(rr + u) * PITCH];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t = __fadd_rn(t, v[u]);
-      }
-      for (; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
+      for (int rr = 0; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
       pr[(size_t)rb * x_t + cs + lane] = t;
     }
     __syncthreads();
   }
   if (rv) pr[(size_t)nrb * x_t + (size_t)j * y_t + r] = a;
 }
+constexpr int kProjRowParts = 8;
+static inline dim3 proj_grid(int y_t, int frames) { return dim3((unsigned)(8 * ((y_t + 63) >> 6)), (unsigned)frames); }
+static inline dim3 proj_block() { return dim3(64); }
+#endif
 
 __device__ inline unsigned long long pack_key(float v, int c) {
   unsigned bits = (v != v) ? 0x7FC00000u : __float_as_uint(v);
@@ -129,6 +185,25 @@ __device__ inline float div_small(float x, float d, float rd) {
   const float q = __fmul_rn(x, rd);
   const float res = __fmaf_rn(-q, d, x);
   return __fmaf_rn(res, rd, q);
+}
+
+// DSP.filt's short-FIR chain at output i (x[<0] = 0): see the file header / oracle fir_filt
+__device__ inline float fir5(const float *raw, int i, float h0, float h1, float h2, float h3, float h4) {
+  const float x4 = i >= 4 ? raw[i - 4] : 0.0f, x3 = i >= 3 ? raw[i - 3] : 0.0f, x2 = i >= 2 ? raw[i - 2] : 0.0f,
+              x1 = i >= 1 ? raw[i - 1] : 0.0f, x0 = raw[i];
+#ifdef TSDR_FIR_NOFMA
+  float acc = __fmul_rn(h4, x4);
+  acc = __fadd_rn(acc, __fmul_rn(h3, x3));
+  acc = __fadd_rn(acc, __fmul_rn(h2, x2));
+  acc = __fadd_rn(acc, __fmul_rn(h1, x1));
+  return __fadd_rn(acc, __fmul_rn(h0, x0));
+#else
+  float acc = __fmul_rn(h4, x4);
+  acc = __fmaf_rn(x3, h3, acc);
+  acc = __fmaf_rn(x2, h2, acc);
+  acc = __fmaf_rn(x1, h1, acc);
+  return __fmaf_rn(x0, h0, acc);
+#endif
 }
 
 // beta of one centre over widths [wa, wb] after replaying the running sum up to wa-1; returns the first
@@ -170,148 +245,125 @@ __device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int
   return bv;
 }
 
-// ---- fold partials + FIR + Sigma + beta scan + argmax.  One workgroup = 64 blank-band centres.
-// Phase 1 (wave 0, one lane per centre): the reference's sequential running sum _Sigma(w), every value parked
-// in LDS; the centres' circular neighbourhood is first unwrapped into a linear LDS window.  Phase 2 (all 256 threads): the (centre, w) pairs are independent now -- thread t owns centre t & 63
-// and widths w_min + (t >> 6) + 4i.  grid.x = ceil(x_t/64) + ceil(y_t/64), grid.y = frames.
+// ---- fold: partial sums -> raw projection -> FIR -> Sigma, once per (frame, axis) ----------------------------
+// proj per frame: colpart[ncp][x_t] | rowpart[nrp][y_t]; the partials of an element are added in index order
+// starting from the first (the order the producer defines: k_proj's row blocks top to bottom, the raster kernel's
+// tiles in tile order).  cvb per frame: cv_x[x_t], Sigma_x, cv_y[y_t], Sigma_y  (x_t + y_t + 2 floats).
+// grid = (2, frames); also clears the frame's two argmax keys.
+__global__ __launch_bounds__(256) void k_fold(const float *__restrict__ proj, size_t proj_stride, int ncp, int nrp,
+                                              SyncGeom g, float *__restrict__ cvb, unsigned long long *__restrict__ keys) {
+  extern __shared__ float sh[];
+  const int f = blockIdx.y, axis = blockIdx.x;
+  const int n = axis == 0 ? g.x_t : g.y_t;
+  const int cnt = axis == 0 ? ncp : nrp;
+  const float *pr = proj + (size_t)f * proj_stride + (axis == 0 ? 0 : (size_t)ncp * g.x_t);
+  float *out = cvb + (size_t)f * (g.x_t + g.y_t + 2) + (axis == 0 ? 0 : g.x_t + 1);
+  float *raw = sh, *cv = sh + n;
+  const int tid = threadIdx.x;
+  if (tid == 0) keys[(size_t)f * 2 + axis] = 0ull;
+  for (int i = tid; i < n; i += 256) {
+    const float *q = pr + i;
+    float tot = q[0];
+    int j = 1;
+    for (; j + 8 <= cnt; j += 8) {  // loads batched, adds in order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(j + u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot = __fadd_rn(tot, v[u]);
+    }
+    for (; j < cnt; ++j) tot = __fadd_rn(tot, q[(size_t)j * n]);
+    raw[i] = tot;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    const float y = fir5(raw, i, g.h0, g.h1, g.h2, g.h3, g.h4);
+    cv[i] = y;
+    out[i] = y;
+  }
+  __syncthreads();
+  if (tid < 64) {  // Sigma in sum64 order
+    float a = 0.0f;
+    for (int i = tid; i < n; i += 64) a = __fadd_rn(a, cv[i]);
+    a = wave_tree64(a);
+    if (tid == 0) out[n] = a;
+  }
+}
+
+// ---- beta scan + argmax.  Workgroup = CPW = 256/LPC blank-band centres of one (frame, axis); LPC lanes per centre.
+// The centres' circular neighbourhood is unwrapped into a linear LDS window, so a lane's walk is plain ascending /
+// descending addresses.  Lane q of a centre replays the running sum _Sigma(w) (FrameSynchronisation.jl:101-107) up
+// to the first width of its share -- fma(2, c_v, s) is the reference's s + 2*c_v exactly, doubling being exact --
+// and evaluates beta for its share.  grid.x = ceil(x_t/CPW) + ceil(y_t/CPW), grid.y = frames.
 // write_frame: frame whose beta matrices are stored.
-__global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, SyncGeom g,
+template <int LPC>
+__global__ __launch_bounds__(256) void k_beta(const float *__restrict__ cvb, SyncGeom g,
                                               unsigned long long *__restrict__ keys, int write_frame,
                                               float *__restrict__ bx, float *__restrict__ by) {
+  constexpr int CPW = 256 / LPC;
   extern __shared__ float sh[];
   const int f = blockIdx.y;
-  const int nbx = (g.x_t + 63) >> 6;
+  const int nbx = (g.x_t + CPW - 1) / CPW;
   const int axis = (int)blockIdx.x < nbx ? 0 : 1;
   const int n = axis == 0 ? g.x_t : g.y_t;
   const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
-  const int W = w_max - w_min + 1, Wp = W | 1;
-  float *raw = sh;                                          // [n]
-  float *cv = sh + n;                                       // [n]
-  float2 *rtab = reinterpret_cast<float2 *>(sh + 2 * n);    // [W] {RN(1/(2(n-w))), RN(1/(2w))}
-  float *sw = sh + 2 * n + 2 * W;                           // [64][Wp] running sums
-  const int NU = 64 + 2 * w_max;
-  float *cu = sw + 64 * Wp;                                 // [NU] cv[(cbase - w_max + j) mod n]: the circular
-                                                            // neighbourhood of the 64 centres, laid out linearly
-  __shared__ float Ssh;
-  const float *pr = proj + (size_t)f * proj_stride(g.y_t, g.x_t);
-  const int nrb = (g.y_t + 63) >> 6;
+  const int W = w_max - w_min + 1;
+  const int NU = CPW + 2 * w_max;
+  float *cu = sh;                                          // [NU] cv[(cbase - w_max + j) mod n]
+  float2 *rtab = reinterpret_cast<float2 *>(sh + ((NU + 1) & ~1));  // [W] {RN(1/(2(n-w))), RN(1/(2w))}
+  const float *cv = cvb + (size_t)f * (g.x_t + g.y_t + 2) + (axis == 0 ? 0 : g.x_t + 1);
   const int tid = threadIdx.x;
-  // fold the projection partials in their defined order (loads batched, adds in order)
-  for (int i = tid; i < n; i += 256) {
-    const float *q = axis == 0 ? pr + i : pr + (size_t)nrb * g.x_t + i;
-    const size_t st = axis == 0 ? (size_t)g.x_t : (size_t)g.y_t;
-    const int cnt = axis == 0 ? nrb : 8;
-    float tot;
-    if (cnt <= 16) {  // all partials of this element requested together, added in their defined order
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = u < cnt ? q[(size_t)u * st] : 0.0f;
-      tot = v[0];
-#pragma unroll
-      for (int u = 1; u < 16; ++u) if (u < cnt) tot = __fadd_rn(tot, v[u]);
-    } else {
-      tot = q[0];
-      int j = 1;
-      for (; j + 8 <= cnt; j += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(j + u) * st];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) tot = __fadd_rn(tot, v[u]);
-      }
-      for (; j < cnt; ++j) tot = __fadd_rn(tot, q[(size_t)j * st]);
-    }
-    raw[i] = tot;
+  const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * CPW;
+  {
+    int k0 = (cbase - w_max) % n; if (k0 < 0) k0 += n;
+    for (int j = tid; j < NU; j += 256) cu[j] = cv[(k0 + j) % n];
   }
   for (int i = tid; i < W; i += 256) {
     const int w = w_min + i;
     rtab[i] = make_float2(__fdiv_rn(1.0f, (float)(2 * (n - w))), __fdiv_rn(1.0f, (float)(2 * w)));
   }
+  const float S = cv[n];
   __syncthreads();
-  for (int i = tid; i < n; i += 256) {  // FIR, transposed-direct-form association
-    float acc = __fmul_rn(g.h4, i >= 4 ? raw[i - 4] : 0.0f);
-    acc = __fadd_rn(acc, __fmul_rn(g.h3, i >= 3 ? raw[i - 3] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h2, i >= 2 ? raw[i - 2] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h1, i >= 1 ? raw[i - 1] : 0.0f));
-    acc = __fadd_rn(acc, __fmul_rn(g.h0, raw[i]));
-    cv[i] = acc;
-  }
-  __syncthreads();
-  const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64;
-  {
-    int k0 = (cbase - w_max) % n; if (k0 < 0) k0 += n;
-    for (int j = tid; j < NU; j += 256) cu[j] = cv[(k0 + j) % n];
-  }
-  if (tid < 64) {
-    // Sigma in sum64 order
-    float a = 0.0f;
-    for (int i = tid; i < n; i += 64) a = __fadd_rn(a, cv[i]);
-    a = wave_tree64(a);
-    if (tid == 0) Ssh = a;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    // phase 1: running sum of centre cbase + tid (FrameSynchronisation.jl:101-107), sequential.  In the unwrapped
-    // window the walk is plain ascending / descending addresses: no wrap test per step, immediate LDS offsets.
-    const int c0 = cbase + tid;
-    if (c0 < n) {
-      const float *ctr = cu + w_max + tid;
-      float acc = 0.0f;
-      {
-        const float *pk = ctr - (w_min - 1);
-        const int np = 2 * (w_min - 1) + 1;
-        int t = 0;
-        for (; t + 8 <= np; t += 8) {
-          float v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = pk[t + u];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
-        }
-        for (; t < np; ++t) acc = __fadd_rn(acc, pk[t]);
-      }
-      float s = __fmul_rn(2.0f, acc);
-      const float *plo = ctr - w_min, *phi = ctr + w_min;
-      float *dst = sw + tid * Wp;
-      // blocks of 8 widths: the 16 reads first (they do not depend on s, but the compiler will not move them across
-      // the LDS stores of the previous block on its own), then the serial adds, then the 8 stores
-      int i = 0;
-      for (; i + 8 <= W; i += 8) {
-        float lo[8], hi[8], out[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { lo[u] = plo[-(i + u)]; hi[u] = phi[i + u]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          s = __fadd_rn(s, __fmul_rn(2.0f, lo[u]));
-          s = __fadd_rn(s, __fmul_rn(2.0f, hi[u]));
-          out[u] = s;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dst[i + u] = out[u];
-      }
-      for (; i < W; ++i) {
-        s = __fadd_rn(s, __fmul_rn(2.0f, plo[-i]));
-        s = __fadd_rn(s, __fmul_rn(2.0f, phi[i]));
-        dst[i] = s;
-      }
-    }
-  }
-  __syncthreads();
-  // phase 2: beta[w, c] = ((Sigma - s)/(2(n-w)) + s/(2w))^2 for this thread's centre and every 4th width
-  const float S = Ssh;
-  const int ci = tid & 63, c0 = cbase + ci;
+  const int ci = tid / LPC, q = tid % LPC, c0 = cbase + ci;
   unsigned long long key = 0ull;
   if (c0 < n) {
+    const int Wq = (W + LPC - 1) / LPC;
+    const int ia = q * Wq, ib = min(ia + Wq, W);  // this lane's widths: w_min + [ia, ib)
+    const float *ctr = cu + w_max + ci;
+    float acc = 0.0f;
+    {
+      const float *pk = ctr - (w_min - 1);
+      const int np = 2 * (w_min - 1) + 1;
+      int t = 0;
+      for (; t + 8 <= np; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pk[t + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
+      }
+      for (; t < np; ++t) acc = __fadd_rn(acc, pk[t]);
+    }
+    float s = __fmul_rn(2.0f, acc);
+    const float *plo = ctr - w_min, *phi = ctr + w_min;
+    int i = 0;
+    for (; i + 8 <= ia; i += 8) {  // prefix replay
+      float lo[8], hi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { lo[u] = plo[-(i + u)]; hi[u] = phi[i + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s = __fmaf_rn(2.0f, lo[u], s); s = __fmaf_rn(2.0f, hi[u], s); }
+    }
+    for (; i < ia; ++i) { s = __fmaf_rn(2.0f, plo[-i], s); s = __fmaf_rn(2.0f, phi[i], s); }
     float *bout = (f == write_frame) ? (axis == 0 ? bx : by) + (size_t)c0 * W : nullptr;
-    const float *src = sw + ci * Wp;
     float bv = 0.0f;
     bool have = false;
-#pragma unroll 4
-    for (int i = tid >> 6; i < W; i += 4) {
+    for (; i < ib; ++i) {
+      s = __fmaf_rn(2.0f, plo[-i], s);
+      s = __fmaf_rn(2.0f, phi[i], s);
       const int w = w_min + i;
-      const float sv = src[i];
       const float2 rr = rtab[i];
-      float v = __fadd_rn(div_small(__fsub_rn(S, sv), (float)(2 * (n - w)), rr.x), div_small(sv, (float)(2 * w), rr.y));
+      float v = __fadd_rn(div_small(__fsub_rn(S, s), (float)(2 * (n - w)), rr.x), div_small(s, (float)(2 * w), rr.y));
       v = __fmul_rn(v, v);
       if (bout) bout[i] = v;
       if (!have) { bv = v; have = true; }
@@ -323,7 +375,7 @@ __global__ __launch_bounds__(256) void k_beta(const float *__restrict__ proj, Sy
     unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  if ((tid & 63) == 0) atomicMax(&keys[(size_t)f * 2 + axis], key);
+  if ((tid & 63) == 0 && key) atomicMax(&keys[(size_t)f * 2 + axis], key);
 }
 
 __device__ inline int key_col1(unsigned long long key) {  // 1-based column of the packed argmax
@@ -427,30 +479,68 @@ static SyncGeom geom_of(const tsdr_sync *s) {
   return g;
 }
 
-// vsync statistics for `frames` images already on the device: fills keys[2*frames]
-// (x then y per frame); beta matrices of the LAST frame are materialised into the sync state.
-// proj_offset (floats): where this call's projections live inside WS_PROJ; the chunk pipeline pre-sizes the
-// workspace for the whole buffer and hands every chunk its own slice
-int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long **keys_out,
-                size_t proj_offset) {
+// layout k_proj produces for this state's image size
+ProjLayout sync_proj_layout(const tsdr_sync *s) {
+  ProjLayout pl;
+  pl.ncp = (s->y_t + 63) >> 6;
+  pl.nrp = kProjRowParts;
+  return pl;
+}
+
+void sync_image_size(const tsdr_sync *s, int *y_t, int *x_t) { *y_t = s->y_t; *x_t = s->x_t; }
+
+// vsync statistics for `frames` images already on the device: fills keys[2*frames] (x then y per frame); beta
+// matrices of the LAST frame are materialised into the sync state.
+//   proj: workspace of frames * proj_floats(layout) floats.  have == nullptr: the projections are formed here from
+//   the images (k_proj); else *have describes partial sums some producer has already written to proj.
+//   cvb: workspace of frames * (x_t + y_t + 2) floats (filtered projections and their sums).
+int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
+                const ProjLayout *have, float *cvb) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
-  float *proj = (float *)ctx->scratch(WS_PROJ, (proj_offset + (size_t)frames * proj_stride(y, x)) * 4);
-  if (proj) proj += proj_offset;
-  // *keys_out != nullptr: caller-provided key buffer (2 per frame); else workspace
-  unsigned long long *keys = *keys_out ? *keys_out : (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)frames * 2 * 8);
-  if (!proj || !keys) return TSDR_ENOMEM;
+  if (!proj || !keys || !cvb) return TSDR_ENOMEM;
   const SyncGeom g = geom_of(s);
-  const unsigned nrb = (unsigned)ceil_div((size_t)y, 64);
-  TSDR_LAUNCH(ctx, "sync_proj", k_proj, dim3(8 * nrb, (unsigned)frames), dim3(64), 0, img, img_stride, y,
-              x, proj, keys);
+  ProjLayout pl;
+  if (have) {
+    pl = *have;
+  } else {
+    pl = sync_proj_layout(s);
+    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames), proj_block(), 0, img, img_stride, y, x, proj,
+                proj_floats(y, x, pl));
+  }
   const size_t nmax = (size_t)(x > y ? x : y);
-  const size_t wmax = (size_t)std::max(1 + s->wmax_x - s->wmin_x, 1 + s->wmax_y - s->wmin_y);
-  const unsigned nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta, dim3(nbb, (unsigned)frames), dim3(256),
-              (2 * nmax + 2 * wmax + 64 * (wmax | 1) + 64 + 2 * (size_t)std::max(s->wmax_x, s->wmax_y)) * 4,
-              (const float *)proj, g, keys, frames - 1, s->beta_x, s->beta_y);
-  *keys_out = keys;
+  TSDR_LAUNCH(ctx, "sync_fold", k_fold, dim3(2, (unsigned)frames), dim3(256), 2 * nmax * 4, (const float *)proj,
+              proj_floats(y, x, pl), pl.ncp, pl.nrp, g, cvb, keys);
+  constexpr int LPC = 8, CPW = 256 / LPC;
+  const size_t wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
+  const size_t Wmax = (size_t)std::max(1 + s->wmax_x - s->wmin_x, 1 + s->wmax_y - s->wmin_y);
+  const unsigned nbb = (unsigned)(ceil_div((size_t)x, CPW) + ceil_div((size_t)y, CPW));
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta<LPC>, dim3(nbb, (unsigned)frames), dim3(256), (CPW + 2 * wmax + 2 + 2 * Wmax) * 4,
+              (const float *)cvb, g, keys, frames - 1, s->beta_x, s->beta_y);
+  return TSDR_OK;
+}
+
+// workspace for sync_scan_d: returns proj / cvb / keys pointers for `frames` frames in slot `slot` (0/1: the
+// two-stage pipeline keeps two buffers in flight) with room for `pl` (or k_proj's layout when pl == nullptr)
+int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj, float **cvb,
+                   unsigned long long **keys) {
+  tsdr_ctx *ctx = s->ctx;
+  const ProjLayout k = sync_proj_layout(s);
+  ProjLayout pl = pl_in ? *pl_in : k;
+  pl.ncp = std::max(pl.ncp, k.ncp);
+  pl.nrp = std::max(pl.nrp, k.nrp);
+  const size_t pf = (size_t)frames * proj_floats(s->y_t, s->x_t, pl);
+  const size_t cf = (size_t)frames * (size_t)(s->x_t + s->y_t + 2);
+  float *p = (float *)ctx->scratch(WS_PROJ, (size_t)nslots * pf * 4);
+  float *c = (float *)ctx->scratch(WS_CV, (size_t)nslots * cf * 4);
+  if (!p || !c) return TSDR_ENOMEM;
+  *proj = p + (size_t)slot * pf;
+  *cvb = c + (size_t)slot * cf;
+  if (keys) {  // callers that bring their own key buffer pass nullptr and WS_KEYS is left alone
+    unsigned long long *kk = (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)nslots * frames * 2 * 8);
+    if (!kk) return TSDR_ENOMEM;
+    *keys = kk + (size_t)slot * frames * 2;
+  }
   return TSDR_OK;
 }
 
@@ -476,6 +566,9 @@ int tsdr_sync_create(tsdr_ctx *ctx, int y_t, int x_t, tsdr_sync **out) {
   if (!ctx || !out) return TSDR_EINVAL;
   *out = nullptr;
   if (y_t < 8 || x_t < 20) return set_err(ctx, TSDR_EINVAL, "SyncXY needs an image of at least 8x20");
+  // k_fold keeps one axis' raw and filtered projection in LDS (2 * 4 * max(x_t, y_t) bytes of the 64 KiB a kernel
+  // gets without opting in): larger images are refused here, loudly, not at launch
+  if (y_t > 8000 || x_t > 8000) return set_err(ctx, TSDR_EINVAL, "SyncXY supports images up to 8000x8000 (got %dx%d)", y_t, x_t);
   tsdr_sync *s = new tsdr_sync();
   s->ctx = ctx; s->y_t = y_t; s->x_t = x_t;
   // init_gaussian_filter(5): exp(-2k^2/25), k=-2..2, normalised in f64, stored as Float32
@@ -529,8 +622,11 @@ int tsdr_sync_bounds(const tsdr_sync *s, int b[4]) {
 int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   if (!s || !img) return TSDR_EINVAL;
   tsdr_ctx *ctx = s->ctx;
+  float *proj = nullptr, *cvb = nullptr;
   unsigned long long *keys = nullptr;
-  int rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, &keys, 0);
+  int rc = sync_workspace(s, 1, 0, 1, nullptr, &proj, &cvb, &keys);
+  if (rc) return rc;
+  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr, cvb);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
               (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);

@@ -73,13 +73,16 @@ def test_fft_mixed_radix(ctx, n):
 
 
 @pytest.mark.parametrize("n", [1000, 30000, 390_625, 2_000_000, 2_400_000])
-def test_fft_mixed_radix_lds_stage_kernel(ctx, n, monkeypatch):
+def test_fft_mixed_radix_lds_stage_kernel(ctx, n):
     """Factor sizes without a two-register-step kernel (e.g. 60, 120, 150) go through the generic LDS-stage kernel;
-    TSDR_FFT_NO_MIX2 sends every factor there so that it stays covered on the common sizes too."""
-    monkeypatch.setenv("TSDR_FFT_NO_MIX2", "1")
-    x = crandn(n)
-    assert relmax(ctx.fft(x), np.fft.fft(x.astype(np.complex128))) < FFT_TOL
-    assert relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128))) < FFT_TOL
+    the "fft_no_mix2" option sends every factor there so that it stays covered on the common sizes too."""
+    ctx.set_option("fft_no_mix2", 1)
+    try:
+        x = crandn(n)
+        assert relmax(ctx.fft(x), np.fft.fft(x.astype(np.complex128))) < FFT_TOL
+        assert relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128))) < FFT_TOL
+    finally:
+        ctx.set_option("fft_no_mix2", 0)
 
 
 @pytest.mark.parametrize("n,batch", [(10, 777), (100, 41), (250, 300), (1000, 7), (6000, 5), (160_000, 2)])
@@ -112,21 +115,22 @@ def test_autocorr_periodic_known_answer(ctx):
                                            # n odd / n/2 with a factor 7: the zero-padded power-of-two route
                                            (4001, 1000.0, 4.0, 0.0), (14_000, 1000.0, 7.0, 0.5)])
 @pytest.mark.parametrize("mixed", [False, True])
-def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind, mixed, monkeypatch):
-    # TSDR_AC_MIXED=1 routes n = 2 * (2^a 3^b 5^c) through the native mixed-radix transform (no padding, no fold)
-    if mixed:
-        monkeypatch.setenv("TSDR_AC_MIXED", "1")
-    else:
-        monkeypatch.delenv("TSDR_AC_MIXED", raising=False)
-    x = (rng.random(n) ** 2).astype(np.float32) * 1e-5  # power-like, non-negative (GUI.jl:70)
-    for scale in ("lin", "log"):
-        g, _ = ctx.calculate_autocorrelation(x, Fs, mind, maxd, scale)
-        o, _ = O.calculate_autocorrelation(x, Fs, mind, maxd, scale)
-        assert g.shape == o.shape
-        if scale == "lin":
-            assert relmax(g, o) < 2 * CORR_TOL, relmax(g, o)   # abs2 doubles the relative error
-        else:
-            assert np.max(np.abs(g - o)) < 2e-4, np.max(np.abs(g - o))  # dB; 8.7*CORR_TOL
+def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind, mixed):
+    # "ac_mixed" (default on) routes n = 2 * (2^a 3^b 5^c) through the native mixed-radix transform (no padding, no
+    # fold); off = the zero-padded power-of-two route, which also serves every other n
+    ctx.set_option("ac_mixed", int(mixed))
+    try:
+        x = (rng.random(n) ** 2).astype(np.float32) * 1e-5  # power-like, non-negative (GUI.jl:70)
+        for scale in ("lin", "log"):
+            g, _ = ctx.calculate_autocorrelation(x, Fs, mind, maxd, scale)
+            o, _ = O.calculate_autocorrelation(x, Fs, mind, maxd, scale)
+            assert g.shape == o.shape
+            if scale == "lin":
+                assert relmax(g, o) < 2 * CORR_TOL, relmax(g, o)   # abs2 doubles the relative error
+            else:
+                assert np.max(np.abs(g - o)) < 2e-4, np.max(np.abs(g - o))  # dB; 8.7*CORR_TOL
+    finally:
+        ctx.set_option("ac_mixed", 1)
 
 
 def test_autocorr_bounds_error(ctx):

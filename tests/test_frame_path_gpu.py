@@ -193,6 +193,7 @@ def run_frames_both(ctx, tsdr, iq, S, y_t, x_t, alpha, do_align, want_raster):
     dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, nfr=3, align=True),    # C2 geometry
     dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, nfr=2, align=False),
     dict(Fs=200e6, x_t=2576, y_t=1125, fv=60.0, nfr=2, align=True),   # C3 geometry (downsample)
+    dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, nfr=2, align=True),    # C5 geometry (4K60 total raster)
 ])
 def test_frames_bitexact(ctx, tsdr, synth, case):
     S = synth.samples_per_frame(case["Fs"], case["fv"])
@@ -309,3 +310,98 @@ def test_full_c2_buffer_bitexact(ctx, tsdr, synth):
     for f in (0, 29):
         assert_bitexact(g["raster"][f], o["raster"][f], f"raster {f}")
     assert_bitexact(gs, os_, "imageOut state after 30 frames")
+
+
+# ---------------------------------------------------------------- robustness items (round-1 review)
+def test_set_stream_orders_work_with_the_callers_stream(ctx, tsdr):
+    """tsdr_set_stream adopts the caller's hipStream_t: a *_d call is then ordered after what the caller enqueued on
+    that stream before it and before what it enqueues afterwards -- no synchronisation in between.  NULL returns
+    the context to a stream of its own."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    c2 = tsdr.Context(0)
+    s = torch.cuda.Stream(device=dev)
+    n = 3_000_001
+    try:
+        c2.set_stream(s.cuda_stream)
+        with torch.cuda.stream(s):
+            z = torch.randn(2 * n, device=dev, dtype=torch.float32)          # producer on the caller's stream
+            out = torch.empty(n, device=dev, dtype=torch.float32)
+            c2.call("tsdr_am_demod_d", C.c_void_p(z.data_ptr()), n, C.c_void_p(out.data_ptr()))
+            got = out.clone()                                                   # consumer on the caller's stream
+        s.synchronize()
+        zc = z.cpu().numpy().view(np.complex64)
+        assert_bitexact(got.cpu().numpy(), O.amDemod(zc), "amDemod on the adopted stream")
+        c2.set_stream(None)
+        assert_bitexact(c2.amDemod(zc[:1000]), O.amDemod(zc[:1000]), "amDemod back on the own stream")
+    finally:
+        c2.close()
+
+
+def test_vsync_large_image(ctx, tsdr):
+    """SyncXY on a 1080x1920 image (the reference accepts any size; round 1's kernel needed > 64 KiB of LDS there
+    and failed at launch) and an oversize request refused at creation, not at launch."""
+    h, w = 1080, 1920
+    g, o = tsdr.SyncXY(ctx, h, w), O.SyncXY(h, w)
+    for k, im in enumerate([band_image(h, w, (300, 40), (1000, 200)), band_image(h, w, (900, 30), (100, 150))]):
+        assert g.vsync(im) == o.vsync(im), k
+        assert_bitexact(g.beta("x"), o.beta("x"), f"beta_x {k}")
+        assert_bitexact(g.beta("y"), o.beta("y"), f"beta_y {k}")
+    with pytest.raises(AssertionError):
+        tsdr.SyncXY(ctx, 9000, 100)
+
+
+def test_submit_with_changing_frame_count(ctx, tsdr, synth):
+    """tsdr_frames_submit_d when the number of frames per buffer changes between un-flushed submissions (S or nEch
+    changed: GUI.jl's FLAG_CONFIG_UPDATE): the image slots of the two-stage pipeline move, so the pipeline must run
+    empty first -- results equal one tsdr_frames_d per buffer."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y_t, fv = 2.0e6, 1056, 628, 60.0
+    S = synth.samples_per_frame(Fs, fv)
+    npx = 600 * 800
+    counts = [5, 5, 2, 2, 6, 1, 4]
+    bufs, off = [], 0
+    for c in counts:
+        bufs.append(synth.synth_leak(Fs, x_t, y_t, fv, S * c + 3, n0=off))
+        off += S * c + 3
+
+    def run(pipelined):
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
+        d_fr = [ctx.dev_alloc(c * npx * 4) for c in counts]
+        d_ix = [ctx.dev_alloc(c * 8) for c in counts]
+        try:
+            for b, c in enumerate(counts):
+                f = api.frames_submit_d if pipelined else api.frames_d
+                assert f(ctx, sync, d_iq[b], bufs[b].size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr[b], None, d_ix[b]) == c
+            if pipelined:
+                api.frames_flush(ctx)
+            ctx.synchronize()
+            return ([ctx.download(p, (c * npx,), np.uint32) for p, c in zip(d_fr, counts)],
+                    [ctx.download(p, (c * 2,), np.int32) for p, c in zip(d_ix, counts)], ctx.download(d_state, (npx,), np.uint32))
+        finally:
+            for p in [d_state] + d_iq + d_fr + d_ix:
+                ctx.dev_free(p)
+
+    a, b = run(False), run(True)
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[2], b[2])
+
+
+def test_sync_margins_on_the_synthetic_leak(ctx, tsdr, synth):
+    """How far the synthetic C2 frames are from a tied frame-sync decision (printed; asserted to be orders of
+    magnitude above the 1e-7 level at which implementations may differ)."""
+    from sync_margin import beta_margin
+    Fs, x_t, y_t, fv = 20e6, 2576, 1125, 60.0
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, 2 * S)
+    st = np.zeros((600, 800), np.float32, order="F")
+    sync = tsdr.SyncXY(ctx, 600, 800)
+    ctx.frames(sync, iq, S, y_t, x_t, np.float32(0.1), st)
+    for w in ("x", "y"):
+        col, margin = beta_margin(sync.beta(w))
+        print(f"C2 beta_{w}: argmax column {col}, relative margin to the best other column {margin:.3e}")
+        assert margin > 1e-4, (w, col, margin)

@@ -49,6 +49,35 @@ def test_ring_overflow_overwrites_like_the_reference(ctx, tsdr):
     ring.close()
 
 
+def test_ring_prefetch_survives_overflow(ctx, tsdr):
+    """After the ring has dropped more than `depth` buffers the consumer must go back to finding its next buffer
+    already sent ahead (the H2D of buffer k+1 under the kernels of buffer k).  The validity test of a prefetch is
+    per slot (was the slot rewritten since the DMA was issued?), not a lifetime counter that never recovers."""
+    n, depth = 4096, 3
+    ring = tsdr.StagingRing(ctx, n, depth)
+    for k in range(9):                      # six overflows before the first take
+        ring.put(_buf(n, k))
+    assert ring.stats()["overflow"] == 6
+    seen = [int(ctx.download(ring.take_d(1000), (n,), np.complex64)[0].real) for _ in range(3)]
+    assert seen == [6, 7, 8], seen          # slots hold 6,7,8 and ptr_read sits on slot 0
+    for k in range(9, 15):                  # steady state: one in, one out, never full again
+        ring.put(_buf(n, k))
+        ring.put(_buf(n, 100 + k))
+        a = int(ctx.download(ring.take_d(1000), (n,), np.complex64)[0].real)
+        b = int(ctx.download(ring.take_d(1000), (n,), np.complex64)[0].real)
+        assert (a, b) == (k, 100 + k)
+    st = ring.stats()
+    # of the 15 takes: the first of each burst is staged at take time; every second one was sent ahead
+    assert st["prefetch_hits"] >= 8, st
+    # a slot rewritten after its prefetch must NOT be served from the stale device copy
+    ring.put(_buf(n, 200)); ring.put(_buf(n, 201))
+    assert int(ctx.download(ring.take_d(1000), (n,), np.complex64)[0].real) == 200   # prefetches slot of 201
+    ring.put(_buf(n, 202)); ring.put(_buf(n, 203)); ring.put(_buf(n, 204))           # laps: slot of 201 now holds 204
+    got = [int(ctx.download(ring.take_d(1000), (n,), np.complex64)[0].real) for _ in range(3)]
+    assert got == [204, 202, 203], got
+    ring.close()
+
+
 def test_ring_sc16_expansion(ctx, tsdr):
     n = 50_000
     scale = 1.0 / 2048.0

@@ -27,8 +27,8 @@ for it in range(60):
         assert e < 1e-5, (n, batch, inv, e)
 print("fft: 60 lengths ok, worst", worst)
 worst = 0.0
-for mixed in ("", "1"):
-    if mixed: os.environ["TSDR_AC_MIXED"] = "1"
+for mixed in (0, 1):
+    ctx.set_option("ac_mixed", mixed)
     for it in range(12):
         n = 2 * smooth(1_000_000) if it % 2 else int(rng.integers(1500, 500_000))
         x = (rng.random(n) ** 2).astype(np.float32) * 1e-5
