@@ -101,6 +101,8 @@ struct TileParams {
   float inv_tiles_p;    // 1/tiles_p (unit -> frame, strip without an integer division)
   RsAxis ax, ay, axx;   // sig->raster, raster lines->rows, raster pixels->columns (host-computed)
   double inv_sfy, inv_sfx;
+  float *proj;          // k_raster_fast<DOWN>: projection partial sums of the (h_out, w_out) images, or null
+  size_t proj_stride;   // floats per frame: colpart[tiles_l][w_out] | rowpart[tiles_p][h_out]
 };
 
 template <bool CPLX, bool DOWN>
@@ -347,7 +349,26 @@ struct DownInfo {   // per-lane / per-wave state of the in-walk downgrade
   int below;                   // ds_bpermute address of the lane below
   float *dn;                   // frame base of the (h_out, w_out) image
   int h_out;
+  bool proj;                   // also accumulate the image's projection sums (wave-uniform)
+  float racc;                  // sum of this lane's output row over the wave's output columns, in column order
+  float csum;                  // lane j: sum over the wave's output rows of the column whose left tap is pixel j
+  int lane;
 };
+
+// sum over the 64 lanes by the fixed DPP tree (row_shr 1, 2, 4, 8, then row_bcast 15 and 31); the total lands in lane 63.
+// Lanes a step does not reach (out of their row, or masked by row/bank mask) add the `old` operand, 0.
+#define TSDR_DPP_ADD(x, ctrl, rmask, bmask) \
+  __fadd_rn((x), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), (rmask), (bmask), false)))
+__device__ inline float wave_sum63(float v) {
+  v = TSDR_DPP_ADD(v, 0x111, 0xF, 0xF);
+  v = TSDR_DPP_ADD(v, 0x112, 0xF, 0xF);
+  v = TSDR_DPP_ADD(v, 0x114, 0xF, 0xE);
+  v = TSDR_DPP_ADD(v, 0x118, 0xF, 0xC);
+  v = TSDR_DPP_ADD(v, 0x142, 0xA, 0xF);
+  v = TSDR_DPP_ADD(v, 0x143, 0xC, 0xF);
+  return v;
+}
+#undef TSDR_DPP_ADD
 
 // dword store with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (the compiler keeps
 // emitting a 64-bit VGPR address, i.e. a 64-bit VALU add per store, for this pattern)
@@ -358,7 +379,7 @@ __device__ inline void store_saddr(float *base_uniform, unsigned lane_off_bytes,
 // One output column: this lane's line gives the upper blend along the pixel axis; the lower one is the same
 // quantity of the lane below (one ds_bpermute), so it is bit-identical to what that lane computes for itself.
 template <bool F32W>
-__device__ inline void down_event(const DownInfo &di, int j, float R00, float R01) {
+__device__ inline void down_event(DownInfo &di, int j, float R00, float R01) {
   const int c = __builtin_amdgcn_readlane(di.ccol, j);
   // The blend runs in f64 in both walks (rounded once to f32, like the oracle's): f32 blends measured 5 ulp on
   // white-noise input, where neighbouring taps differ by their own size, against 3 ulp this way.
@@ -375,6 +396,16 @@ __device__ inline void down_event(const DownInfo &di, int j, float R00, float R0
     v = (float)fma(di.rdyd, bot - top, top);
   }
   if (di.rrow >= 0) store_saddr(di.dn + (size_t)c * di.h_out, (unsigned)di.rrow * 4u, v);
+  if (di.proj) {
+    // projection sums of the (h_out, w_out) image, formed where its pixels are: this lane's row gains the pixel
+    // (columns arrive in ascending order), and the column's sum over the wave's rows is one fixed-order DPP tree,
+    // parked in lane j until the walk is over
+    const float m = di.rrow >= 0 ? v : 0.0f;
+    di.racc = __fadd_rn(di.racc, m);
+    const float tot = wave_sum63(m);
+    const float t63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
+    di.csum = di.lane == j ? t63 : di.csum;
+  }
 }
 
 // The common case of a lane's walk: a full segment of PW pixels in chunks of CH, each chunk unrolled -- the (k, r)
@@ -384,7 +415,7 @@ __device__ inline void down_event(const DownInfo &di, int j, float R00, float R0
 // whole segment keeps the kernel at 64 VGPRs, i.e. eight waves per SIMD.
 template <bool F32W, bool OUT, bool DOWNR, int PW>
 __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, bool extra,
-                                      float *__restrict__ ob, int loff, size_t ostride, const DownInfo &di) {
+                                      float *__restrict__ ob, int loff, size_t ostride, DownInfo &di) {
   // ob is wave-uniform (first pixel of the segment, line 0 of the frame), loff the lane's line: the store then
   // takes a scalar base advanced by scalar adds and a fixed VGPR offset -- no per-pixel VALU address math
   constexpr int CH = PW >= 4 ? 4 : PW;
@@ -440,7 +471,7 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
 // n_own pixels are stored; one more is evaluated (not stored) when `extra`.
 template <bool F32W, bool CLAMP, bool OUT, bool DOWNR>
 __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, int n_own, bool extra,
-                                  float *__restrict__ o, size_t ostride, const DownInfo &di) {
+                                  float *__restrict__ o, size_t ostride, DownInfo &di) {
   const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
   const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
   const int n = n_own + (extra ? 1 : 0);
@@ -589,11 +620,15 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
     }
   }
   __syncthreads();
+  DownInfo di{};
+  di.rrow = -1;
+  int my_col = -1;  // lane j: the output column whose left tap is pixel j of this wave's segment
   {
     constexpr int pw = PW;  // = TP/4
     const int pbeg = p0 + wave * pw;
     const int n_own = min(pw, q.x_t - pbeg);
-    if (n_own <= 0) return;
+    if (n_own <= 0 && !(DOWN && q.proj)) return;
+    if (n_own > 0) {
     // one pixel past the segment (evaluated, not stored) lets the last owned pixel be a left tap
     const bool extra = DOWN && wave < 3 && pbeg + pw < q.x_t;
     int k; unsigned r;
@@ -604,13 +639,13 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
     else fast_pos(fa, (unsigned)min(l0 + lbase + lane, q.y_t - 1) * (unsigned)q.x_t + (unsigned)pbeg, k, r);
     const int l = min(l0 + lbase + lane, q.y_t - 1);
     float *o = OUT ? out + (size_t)f * out_stride + (size_t)l + (size_t)pbeg * q.y_t : nullptr;
-    DownInfo di{};
     if (DOWN) {
       const int cj = lane <= pw ? wave * pw + lane : q.TP;  // entry TP is never a column
       di.ccol = ccol[cj];
       di.cdxd = cdxd[cj];
       di.cdx = (float)di.cdxd;
       di.colmask = __ballot(lane < pw && di.ccol >= 0);
+      my_col = lane < pw ? di.ccol : -1;
       // lane 63 is the next wave's lane 0 unless this is the bottom wave of the tile
       di.rrow = (lane < 63 || wv == VW - 1) ? rrow[lbase + lane] : -1;
       di.rdyd = rdyd[lbase + lane];
@@ -618,6 +653,8 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
       di.below = ((lane + 1) & 63) << 2;
       di.dn = down + (size_t)f * down_stride;
       di.h_out = q.h_out;
+      di.proj = q.proj != nullptr;
+      di.lane = lane;
     }
     const void *row = F32W ? (const void *)(smp4 + (lbase + lane) * Wp) : (const void *)(smp2 + (lbase + lane) * Wp);
     const int kk = k - kf;
@@ -627,6 +664,31 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
     else {
       float *ob = OUT ? out + (size_t)f * out_stride + (size_t)pbeg * q.y_t : nullptr;
       fast_walk_full<F32W, OUT, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
+    }
+    }
+  }
+  if (DOWN && q.proj) {
+    // Projection partial sums of this tile: the four wavefronts side by side are added left to right into one row
+    // partial per output row (-> rowpart[strip][row]), the VW stacked ones top to bottom into one column partial
+    // per output column (-> colpart[line tile][column]).  Every (strip, row) and (line tile, column) slot is
+    // written by exactly one lane of one workgroup, so the buffer needs no clearing; k_fold adds the partials of
+    // a row strip by strip and those of a column line tile by line tile.
+    float *rp = reinterpret_cast<float *>(ccol + q.TP + 1);  // [4*VW][64] row sums per wavefront
+    float *cp = rp + 256 * VW;                               // [4*VW][64] column sums per wavefront
+    rp[wave_id * 64 + lane] = di.racc;
+    cp[wave_id * 64 + lane] = di.csum;
+    __syncthreads();
+    float *pr = q.proj + (size_t)f * q.proj_stride;
+    if (wave == 0 && di.rrow >= 0) {
+      const float *x = rp + (wv * 4) * 64 + lane;
+      const float a = __fadd_rn(__fadd_rn(__fadd_rn(x[0], x[64]), x[128]), x[192]);
+      pr[(size_t)q.tiles_l * q.w_out + (size_t)tp * q.h_out + di.rrow] = a;
+    }
+    if (wv == 0 && my_col >= 0) {
+      float a = cp[wave * 64 + lane];
+#pragma unroll
+      for (int v2 = 1; v2 < VW; ++v2) a = __fadd_rn(a, cp[(v2 * 4 + wave) * 64 + lane]);
+      pr[(size_t)tl * q.w_out + my_col] = a;
     }
   }
 }
@@ -883,9 +945,11 @@ static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t 
 // sig_to_image for `frames` consecutive frames (raster `out`, may be null when only `down` is wanted and the
 // tile kernel applies) and, when `down` != null, the (h_out,w_out) image of each frame from the same launch.
 // Returns TSDR_OK and sets *did_down when the down image was produced here.
+// proj / got / plan_only: see raster_and_down_d.
 int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int frames,
                     float *out, size_t out_stride, float *down = nullptr, size_t down_stride = 0, int h_out = 0,
-                    int w_out = 0, bool *did_down = nullptr) {
+                    int w_out = 0, bool *did_down = nullptr, float *proj = nullptr, ProjLayout *got = nullptr,
+                    bool plan_only = false) {
   if (did_down) *did_down = false;
   int rc = check_geom(ctx, S, y_t, x_t);
   if (rc) return rc;
@@ -943,10 +1007,20 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.lpl_log = best;
     q.cs = (int)ceil_div((size_t)q.W, (size_t)1 << best);
     size_t lds = (size_t)NL * (size_t)(q.W | 1) * 16 + 16;
+    // the images' projection partial sums come out of the same walk when the caller has room for them
+    const bool pj = dn && got != nullptr && (proj != nullptr || plan_only);
     if (dn) {
       q.h_out = h_out; q.w_out = w_out;
       lds += (size_t)(NL + q.TP + 1) * 12 + 16;
+      if (pj) {
+        lds += (size_t)2 * 256 * VW * 4;
+        got->ncp = q.tiles_l;
+        got->nrp = q.tiles_p;
+        q.proj = proj;
+        q.proj_stride = proj_floats(h_out, w_out, *got);
+      }
     }
+    if (plan_only) { if (did_down) *did_down = dn; return TSDR_OK; }
     const FastAx fa = fast_axis(S, P);
     const FastInc fi = fast_inc(S, P, x_t, q.own_l, q.own_p);
     // f32 walk and 32-bit position advance: D = 2P < 2^24 and few enough tiles that the advances stay below 2^32
@@ -994,6 +1068,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
 #undef FASTK
     return TSDR_OK;
   }
+  if (plan_only) return TSDR_OK;  // only k_raster_fast produces projection sums
   if (tiled) {
     const bool dn = want_down && q.TP >= 32;
     q.own_l = dn ? 63 : 64;
@@ -1128,21 +1203,25 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   return TSDR_OK;
 }
 
-// raster (optional) + (h_out,w_out) image for every frame with as few passes over IQ as possible
+// raster (optional) + (h_out,w_out) image for every frame with as few passes over IQ as possible.
+// proj != nullptr: room for the projection partial sums of every (h_out, w_out) image (layout: sync_layout.h); when the
+// FAST tile kernel runs it leaves them there and describes them in *got (ncp == 0: not produced -- the caller then
+// forms the projections from the images).  plan_only: nothing is launched, *got says what a real call would produce.
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride,
                       float *proj, ProjLayout *got, bool plan_only) {
   if (got) *got = ProjLayout{};
-  if (plan_only) return TSDR_OK;
-  (void)proj;
   // FAST without a raster to write: the tile kernel still wins (its walk produces the raster values in registers and
   // downgrades them on the spot; k_down_fused re-derives four taps per output pixel), so it runs with out == null
   if (raster || (ctx->precision == TSDR_FAST && cplx)) {
     bool did = false;
+    ProjLayout pl{};
     int rc = raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, raster, raster_stride, down, down_stride, h_out,
-                             w_out, &did);
-    if (rc || did) return rc;
+                             w_out, &did, proj, got ? &pl : nullptr, plan_only);
+    if (rc) return rc;
+    if (did) { if (got) *got = pl; return TSDR_OK; }
   }
+  if (plan_only) return TSDR_OK;
   return down_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, h_out, w_out, frames, down, down_stride);
 }
 

@@ -290,92 +290,144 @@ __global__ __launch_bounds__(256) void k_fold(const float *__restrict__ proj, si
   }
 }
 
-// ---- beta scan + argmax.  Workgroup = CPW = 256/LPC blank-band centres of one (frame, axis); LPC lanes per centre.
-// The centres' circular neighbourhood is unwrapped into a linear LDS window, so a lane's walk is plain ascending /
-// descending addresses.  Lane q of a centre replays the running sum _Sigma(w) (FrameSynchronisation.jl:101-107) up
-// to the first width of its share -- fma(2, c_v, s) is the reference's s + 2*c_v exactly, doubling being exact --
-// and evaluates beta for its share.  grid.x = ceil(x_t/CPW) + ceil(y_t/CPW), grid.y = frames.
-// write_frame: frame whose beta matrices are stored.
-template <int LPC>
-__global__ __launch_bounds__(256) void k_beta(const float *__restrict__ cvb, SyncGeom g,
-                                              unsigned long long *__restrict__ keys, int write_frame,
-                                              float *__restrict__ bx, float *__restrict__ by) {
-  constexpr int CPW = 256 / LPC;
-  extern __shared__ float sh[];
+// ---- beta scan + argmax.  Workgroup = 64 blank-band centres of one (frame, axis) x NWV wavefronts; lane = centre,
+// wavefront q = the q-th share of the widths, so the width -- and with it both divisors and their reciprocals -- is
+// uniform over a wavefront and every LDS read is 64 consecutive words.  The centres' circular neighbourhood is
+// unwrapped into a linear LDS window: a lane's walk is plain descending / ascending addresses.  Wavefront q replays the
+// running sum _Sigma(w) (FrameSynchronisation.jl:101-107) up to the first width of its share -- fma(2, c_v, s) is the
+// reference's s + 2*c_v exactly, doubling being exact -- then evaluates beta over its share.  The replay is adds
+// only and every LDS read is issued eight widths ahead of its use, so the ~24 operations per (centre, width) run
+// NWV-wide while the serial part of a centre stays the 2*(w_min + W) adds the reference has.
+// The two divisions per width are by small integers: RN(1/d) (one IEEE division per width and wavefront, kept in a
+// lane and read back with v_readlane) and Markstein's two-FMA correction give the correctly rounded quotient.  The
+// correction needs |x| comfortably normal: min/max of |x| are tracked and a lane that ever left [1e-30, 1e30] (or
+// met an Inf) redoes its share with IEEE divisions.
+// grid.x = ceil(x_t/64) + ceil(y_t/64), grid.y = frames.  write_frame: frame whose beta matrices are stored.
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_beta(const float *__restrict__ cvb, SyncGeom g,
+                                                   unsigned long long *__restrict__ keys, int write_frame,
+                                                   float *__restrict__ bx, float *__restrict__ by) {
+  extern __shared__ float cu[];  // [64 + 2*w_max] cv[(cbase - w_max + j) mod n]
+  __shared__ unsigned long long wkey[NWV];
   const int f = blockIdx.y;
-  const int nbx = (g.x_t + CPW - 1) / CPW;
+  const int nbx = (g.x_t + 63) >> 6;
   const int axis = (int)blockIdx.x < nbx ? 0 : 1;
   const int n = axis == 0 ? g.x_t : g.y_t;
   const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
   const int W = w_max - w_min + 1;
-  const int NU = CPW + 2 * w_max;
-  float *cu = sh;                                          // [NU] cv[(cbase - w_max + j) mod n]
-  float2 *rtab = reinterpret_cast<float2 *>(sh + ((NU + 1) & ~1));  // [W] {RN(1/(2(n-w))), RN(1/(2w))}
+  const int NU = 64 + 2 * w_max;
   const float *cv = cvb + (size_t)f * (g.x_t + g.y_t + 2) + (axis == 0 ? 0 : g.x_t + 1);
   const int tid = threadIdx.x;
-  const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * CPW;
+  const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64;
   {
-    int k0 = (cbase - w_max) % n; if (k0 < 0) k0 += n;
-    for (int j = tid; j < NU; j += 256) cu[j] = cv[(k0 + j) % n];
-  }
-  for (int i = tid; i < W; i += 256) {
-    const int w = w_min + i;
-    rtab[i] = make_float2(__fdiv_rn(1.0f, (float)(2 * (n - w))), __fdiv_rn(1.0f, (float)(2 * w)));
+    int k = (cbase - w_max) % n; if (k < 0) k += n;
+    k += tid;
+    for (int j = tid; j < NU; j += 64 * NWV) {
+      while (k >= n) k -= n;
+      cu[j] = cv[k];
+      k += 64 * NWV;
+    }
   }
   const float S = cv[n];
   __syncthreads();
-  const int ci = tid / LPC, q = tid % LPC, c0 = cbase + ci;
-  unsigned long long key = 0ull;
-  if (c0 < n) {
-    const int Wq = (W + LPC - 1) / LPC;
-    const int ia = q * Wq, ib = min(ia + Wq, W);  // this lane's widths: w_min + [ia, ib)
-    const float *ctr = cu + w_max + ci;
-    float acc = 0.0f;
-    {
-      const float *pk = ctr - (w_min - 1);
-      const int np = 2 * (w_min - 1) + 1;
-      int t = 0;
-      for (; t + 8 <= np; t += 8) {
-        float v[8];
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int c0 = cbase + lane;
+  const int Wq = (W + NWV - 1) / NWV;
+  const int ia = min(q * Wq, W), ib = min(ia + Wq, W);  // this wavefront's widths: w_min + [ia, ib)
+  const float *ctr = cu + w_max + lane;
+  float acc = 0.0f;
+  {
+    const float *pk = ctr - (w_min - 1);
+    const int np = 2 * (w_min - 1) + 1;
+    int t = 0;
+    for (; t + 8 <= np; t += 8) {
+      float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = pk[t + u];
+      for (int u = 0; u < 8; ++u) v[u] = pk[t + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
-      }
-      for (; t < np; ++t) acc = __fadd_rn(acc, pk[t]);
+      for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
     }
-    float s = __fmul_rn(2.0f, acc);
-    const float *plo = ctr - w_min, *phi = ctr + w_min;
-    int i = 0;
-    for (; i + 8 <= ia; i += 8) {  // prefix replay
+    for (; t < np; ++t) acc = __fadd_rn(acc, pk[t]);
+  }
+  float s = __fmul_rn(2.0f, acc);
+  const float *plo = ctr - w_min, *phi = ctr + w_min;
+  int i = 0;
+  for (; i + 8 <= ia; i += 8) {  // replay of the widths before this wavefront's share
+    float lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { lo[u] = plo[-(i + u)]; hi[u] = phi[i + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s = __fmaf_rn(2.0f, lo[u], s); s = __fmaf_rn(2.0f, hi[u], s); }
+  }
+  for (; i < ia; ++i) { s = __fmaf_rn(2.0f, plo[-i], s); s = __fmaf_rn(2.0f, phi[i], s); }
+  const float s_share = s;  // running sum at the start of the share (kept for the IEEE re-run)
+  float *bout = (f == write_frame && c0 < n) ? (axis == 0 ? bx : by) + (size_t)c0 * W : nullptr;
+  unsigned kb = 0u;          // largest beta of the share as an order-preserving word (beta >= +0; NaN above +Inf)
+  float amin = 1.0f, amax = 1.0f;
+  for (int i0 = ia; i0 < ib; i0 += 64) {
+    const int i1 = min(i0 + 64, ib);
+    // lane L holds the reciprocals of width i0 + L
+    const int wl = w_min + min(i0 + lane, W - 1);
+    const float r1l = __fdiv_rn(1.0f, (float)(2 * (n - wl))), r2l = __fdiv_rn(1.0f, (float)(2 * wl));
+    for (i = i0; i < i1; i += 8) {
       float lo[8], hi[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { lo[u] = plo[-(i + u)]; hi[u] = phi[i + u]; }
+      for (int u = 0; u < 8; ++u) {  // (reads past the share stay inside the window: i + u < W + 8 <= w_max + 8)
+        const int iu = min(i + u, W - 1);
+        lo[u] = plo[-iu]; hi[u] = phi[iu];
+      }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { s = __fmaf_rn(2.0f, lo[u], s); s = __fmaf_rn(2.0f, hi[u], s); }
+      for (int u = 0; u < 8; ++u) {
+        if (i + u < i1) {  // uniform
+          s = __fmaf_rn(2.0f, lo[u], s);
+          s = __fmaf_rn(2.0f, hi[u], s);
+          const int w = w_min + i + u;
+          const float d1 = (float)(2 * (n - w)), d2 = (float)(2 * w);
+          const float rd1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r1l), i + u - i0));
+          const float rd2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(r2l), i + u - i0));
+          const float x1 = __fsub_rn(S, s);
+          const float q1 = __fmul_rn(x1, rd1), q2 = __fmul_rn(s, rd2);
+          const float t1 = __fmaf_rn(__fmaf_rn(-q1, d1, x1), rd1, q1), t2 = __fmaf_rn(__fmaf_rn(-q2, d2, s), rd2, q2);
+          float v = __fadd_rn(t1, t2);
+          v = __fmul_rn(v, v);
+          amin = fminf(amin, fminf(fabsf(x1), fabsf(s)));
+          amax = fmaxf(amax, fmaxf(fabsf(x1), fabsf(s)));
+          if (bout) bout[i + u] = v;
+          const unsigned bits = (v != v) ? 0x7FC00000u : __float_as_uint(v);
+          kb = max(kb, bits);
+        }
+      }
     }
-    for (; i < ia; ++i) { s = __fmaf_rn(2.0f, plo[-i], s); s = __fmaf_rn(2.0f, phi[i], s); }
-    float *bout = (f == write_frame) ? (axis == 0 ? bx : by) + (size_t)c0 * W : nullptr;
-    float bv = 0.0f;
-    bool have = false;
-    for (; i < ib; ++i) {
+  }
+  // rare: a value outside Markstein's safe range (all-zero image, denormals, Inf).  The lane redoes its share with
+  // IEEE divisions; everything else is unchanged.
+  if (!(amin > 1e-30f && amax < 1e30f)) {
+    s = s_share;
+    kb = 0u;
+    for (i = ia; i < ib; ++i) {
       s = __fmaf_rn(2.0f, plo[-i], s);
       s = __fmaf_rn(2.0f, phi[i], s);
       const int w = w_min + i;
-      const float2 rr = rtab[i];
-      float v = __fadd_rn(div_small(__fsub_rn(S, s), (float)(2 * (n - w)), rr.x), div_small(s, (float)(2 * w), rr.y));
+      float v = __fadd_rn(__fdiv_rn(__fsub_rn(S, s), (float)(2 * (n - w))), __fdiv_rn(s, (float)(2 * w)));
       v = __fmul_rn(v, v);
       if (bout) bout[i] = v;
-      if (!have) { bv = v; have = true; }
-      else if (!(bv != bv) && (v != v || v > bv)) bv = v;
+      const unsigned bits = (v != v) ? 0x7FC00000u : __float_as_uint(v);
+      kb = max(kb, bits);
     }
-    if (have) key = pack_key(bv, c0);
   }
+  unsigned long long key = (c0 < n && ia < ib) ? (((unsigned long long)kb << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c0)) : 0ull;
   for (int off = 32; off > 0; off >>= 1) {
-    unsigned long long o = __shfl_xor(key, off, 64);
+    const unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  if ((tid & 63) == 0 && key) atomicMax(&keys[(size_t)f * 2 + axis], key);
+  if (lane == 0) wkey[q] = key;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long b = wkey[0];
+#pragma unroll
+    for (int j = 1; j < NWV; ++j) b = wkey[j] > b ? wkey[j] : b;
+    if (b) atomicMax(&keys[(size_t)f * 2 + axis], b);
+  }
 }
 
 __device__ inline int key_col1(unsigned long long key) {  // 1-based column of the packed argmax
@@ -511,11 +563,10 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   const size_t nmax = (size_t)(x > y ? x : y);
   TSDR_LAUNCH(ctx, "sync_fold", k_fold, dim3(2, (unsigned)frames), dim3(256), 2 * nmax * 4, (const float *)proj,
               proj_floats(y, x, pl), pl.ncp, pl.nrp, g, cvb, keys);
-  constexpr int LPC = 8, CPW = 256 / LPC;
+  constexpr int NWV = 8;
   const size_t wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
-  const size_t Wmax = (size_t)std::max(1 + s->wmax_x - s->wmin_x, 1 + s->wmax_y - s->wmin_y);
-  const unsigned nbb = (unsigned)(ceil_div((size_t)x, CPW) + ceil_div((size_t)y, CPW));
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta<LPC>, dim3(nbb, (unsigned)frames), dim3(256), (CPW + 2 * wmax + 2 + 2 * Wmax) * 4,
+  const unsigned nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta<NWV>, dim3(nbb, (unsigned)frames), dim3(64 * NWV), (64 + 2 * wmax + 8) * 4,
               (const float *)cvb, g, keys, frames - 1, s->beta_x, s->beta_y);
   return TSDR_OK;
 }
