@@ -23,7 +23,6 @@ enum Slot {
   WS_IMG,         // per-frame 600x800 images of one buffer
   WS_PROJ,        // raw + filtered projections, sums
   WS_KEYS,        // packed argmax keys per frame
-  WS_CV,          // filtered projections + their sums per frame
   WS_FFT_A,       // FFT ping
   WS_FFT_B,       // FFT pong
   WS_FFT_C,       // Bluestein / correlation scratch

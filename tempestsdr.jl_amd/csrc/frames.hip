@@ -16,14 +16,16 @@ struct tsdr_sync;
 
 namespace tsdr {
 // proj != nullptr: the kernel may also leave the projection partial sums of every (h_out, w_out) image there
-// (TSDR_FAST in-walk sums); *got then describes them (ncp == 0: nothing was produced).  plan_only: no launch, only
-// report in *got what a real call would produce.
+// (TSDR_FAST in-walk sums) and clear the two argmax keys of every frame in `keys`; *got then describes the sums
+// (ncp == 0: nothing was produced, keys untouched).  plan_only: no launch, only report in *got what a real call would
+// produce.
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride,
-                      float *proj = nullptr, ProjLayout *got = nullptr, bool plan_only = false);
+                      float *proj = nullptr, ProjLayout *got = nullptr, bool plan_only = false,
+                      unsigned long long *keys = nullptr);
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
-                const ProjLayout *have, float *cvb);
-int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj, float **cvb,
+                const ProjLayout *have);
+int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
@@ -53,19 +55,19 @@ static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t 
                         float *img, float *raster_out, unsigned long long *keys, int slot, int nslots, float alpha,
                         float *state, float *frames_out, int *sync_idx, bool pipelined, bool combine = true) {
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
-  float *proj = nullptr, *cvb = nullptr;
+  float *proj = nullptr;
   ProjLayout plan{}, got{};
   int rc;
   if (do_align) {
     rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx,
                            nullptr, &plan, true);
     if (rc) return rc;
-    rc = sync_workspace(sync, F, slot, nslots, plan.ncp ? &plan : nullptr, &proj, &cvb, nullptr);
+    rc = sync_workspace(sync, F, slot, nslots, plan.ncp ? &plan : nullptr, &proj, nullptr);
     if (rc) return rc;
   }
   if (pipelined) ctx->launch_stream = ctx->pipe_r;
   rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx,
-                         proj, &got);
+                         proj, &got, false, keys);
   if (rc) return rc;
   if (pipelined) {
     TSDR_HIP(ctx, hipEventRecord(ctx->pipe_er[slot], ctx->pipe_r));
@@ -73,7 +75,7 @@ static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t 
     ctx->launch_stream = ctx->pipe_s;
   }
   if (do_align) {
-    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, cvb);
+    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr);
     if (rc) return rc;
   }
   if (combine) {

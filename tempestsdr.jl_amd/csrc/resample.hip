@@ -103,6 +103,7 @@ struct TileParams {
   double inv_sfy, inv_sfx;
   float *proj;          // k_raster_fast<DOWN>: projection partial sums of the (h_out, w_out) images, or null
   size_t proj_stride;   // floats per frame: colpart[tiles_l][w_out] | rowpart[tiles_p][h_out]
+  unsigned long long *keys;  // with proj: two vsync argmax keys per frame, cleared here for k_beta's atomicMax
 };
 
 template <bool CPLX, bool DOWN>
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
     cp[wave_id * 64 + lane] = di.csum;
     __syncthreads();
     float *pr = q.proj + (size_t)f * q.proj_stride;
+    if (tl == 0 && tp == 0 && tid < 2) q.keys[(size_t)f * 2 + tid] = 0ull;
     if (wave == 0 && di.rrow >= 0) {
       const float *x = rp + (wv * 4) * 64 + lane;
       const float a = __fadd_rn(__fadd_rn(__fadd_rn(x[0], x[64]), x[128]), x[192]);
@@ -949,7 +951,7 @@ static int launch_tile(tsdr_ctx *ctx, const char *name, const float *in, size_t 
 int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int frames,
                     float *out, size_t out_stride, float *down = nullptr, size_t down_stride = 0, int h_out = 0,
                     int w_out = 0, bool *did_down = nullptr, float *proj = nullptr, ProjLayout *got = nullptr,
-                    bool plan_only = false) {
+                    bool plan_only = false, unsigned long long *keys = nullptr) {
   if (did_down) *did_down = false;
   int rc = check_geom(ctx, S, y_t, x_t);
   if (rc) return rc;
@@ -1008,7 +1010,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.cs = (int)ceil_div((size_t)q.W, (size_t)1 << best);
     size_t lds = (size_t)NL * (size_t)(q.W | 1) * 16 + 16;
     // the images' projection partial sums come out of the same walk when the caller has room for them
-    const bool pj = dn && got != nullptr && (proj != nullptr || plan_only);
+    const bool pj = dn && got != nullptr && ((proj != nullptr && keys != nullptr) || plan_only);
     if (dn) {
       q.h_out = h_out; q.w_out = w_out;
       lds += (size_t)(NL + q.TP + 1) * 12 + 16;
@@ -1017,6 +1019,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
         got->ncp = q.tiles_l;
         got->nrp = q.tiles_p;
         q.proj = proj;
+        q.keys = keys;
         q.proj_stride = proj_floats(h_out, w_out, *got);
       }
     }
@@ -1209,7 +1212,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
 // forms the projections from the images).  plan_only: nothing is launched, *got says what a real call would produce.
 int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride,
-                      float *proj, ProjLayout *got, bool plan_only) {
+                      float *proj, ProjLayout *got, bool plan_only, unsigned long long *keys) {
   if (got) *got = ProjLayout{};
   // FAST without a raster to write: the tile kernel still wins (its walk produces the raster values in registers and
   // downgrades them on the spot; k_down_fused re-derives four taps per output pixel), so it runs with out == null
@@ -1217,7 +1220,7 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
     bool did = false;
     ProjLayout pl{};
     int rc = raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, raster, raster_stride, down, down_stride, h_out,
-                             w_out, &did, proj, got ? &pl : nullptr, plan_only);
+                             w_out, &did, proj, got ? &pl : nullptr, plan_only, keys);
     if (rc) return rc;
     if (did) { if (got) *got = pl; return TSDR_OK; }
   }

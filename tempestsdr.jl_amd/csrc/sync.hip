@@ -66,7 +66,8 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 // first: the row sum is one left-to-right chain (-> rowpart[0][row], already final), but only the adds are serial.
 // The next round's loads are issued before the chain, so HBM latency overlaps it.  grid = (nrb, frames).
 __global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                              float *__restrict__ proj, size_t proj_stride) {
+                                              float *__restrict__ proj, size_t proj_stride,
+                                              unsigned long long *__restrict__ keys) {
   constexpr int SUB = 24, PITCH = SUB + 1, RND = 8 * SUB;  // 8 tiles of 64 x 25 floats = 50 KiB of LDS
   __shared__ float tile[8][64 * PITCH];
   __shared__ float chain[64];
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, siz
   const int nrb = (y_t + 63) >> 6;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride;
+  if (rb == 0 && threadIdx.x < 2) keys[(size_t)f * 2 + threadIdx.x] = 0ull;  // this frame's argmax keys (k_beta's atomicMax)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = rb * 64 + lane;
   const bool rv = r < y_t;
@@ -136,7 +138,8 @@ static inline dim3 proj_block() { return dim3(512); }
 // accumulated in order from 0.0f, the chunk sums added left to right by k_fold.  One wavefront per (64-row block,
 // column chunk); grid = (8 * nrb, frames).
 __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                             float *__restrict__ proj, size_t proj_stride) {
+                                             float *__restrict__ proj, size_t proj_stride,
+                                             unsigned long long *__restrict__ keys) {
   constexpr int SUB = 32, PITCH = SUB + 1;
   __shared__ float tile[64 * PITCH];
   const int f = blockIdx.y;
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride;
   const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane < 2) keys[(size_t)f * 2 + lane] = 0ull;
   const int r = rb * 64 + lane;
   const bool rv = r < y_t;
   const int c0 = j * chunk, c1 = min(c0 + chunk, x_t);
@@ -245,70 +249,32 @@ __device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int
   return bv;
 }
 
-// ---- fold: partial sums -> raw projection -> FIR -> Sigma, once per (frame, axis) ----------------------------
-// proj per frame: colpart[ncp][x_t] | rowpart[nrp][y_t]; the partials of an element are added in index order
-// starting from the first (the order the producer defines: k_proj's row blocks top to bottom, the raster kernel's
-// tiles in tile order).  cvb per frame: cv_x[x_t], Sigma_x, cv_y[y_t], Sigma_y  (x_t + y_t + 2 floats).
-// grid = (2, frames); also clears the frame's two argmax keys.
-__global__ __launch_bounds__(256) void k_fold(const float *__restrict__ proj, size_t proj_stride, int ncp, int nrp,
-                                              SyncGeom g, float *__restrict__ cvb, unsigned long long *__restrict__ keys) {
-  extern __shared__ float sh[];
-  const int f = blockIdx.y, axis = blockIdx.x;
-  const int n = axis == 0 ? g.x_t : g.y_t;
-  const int cnt = axis == 0 ? ncp : nrp;
-  const float *pr = proj + (size_t)f * proj_stride + (axis == 0 ? 0 : (size_t)ncp * g.x_t);
-  float *out = cvb + (size_t)f * (g.x_t + g.y_t + 2) + (axis == 0 ? 0 : g.x_t + 1);
-  float *raw = sh, *cv = sh + n;
-  const int tid = threadIdx.x;
-  if (tid == 0) keys[(size_t)f * 2 + axis] = 0ull;
-  for (int i = tid; i < n; i += 256) {
-    const float *q = pr + i;
-    float tot = q[0];
-    int j = 1;
-    for (; j + 8 <= cnt; j += 8) {  // loads batched, adds in order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(j + u) * n];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) tot = __fadd_rn(tot, v[u]);
-    }
-    for (; j < cnt; ++j) tot = __fadd_rn(tot, q[(size_t)j * n]);
-    raw[i] = tot;
-  }
-  __syncthreads();
-  for (int i = tid; i < n; i += 256) {
-    const float y = fir5(raw, i, g.h0, g.h1, g.h2, g.h3, g.h4);
-    cv[i] = y;
-    out[i] = y;
-  }
-  __syncthreads();
-  if (tid < 64) {  // Sigma in sum64 order
-    float a = 0.0f;
-    for (int i = tid; i < n; i += 64) a = __fadd_rn(a, cv[i]);
-    a = wave_tree64(a);
-    if (tid == 0) out[n] = a;
-  }
-}
-
-// ---- beta scan + argmax.  Workgroup = 64 blank-band centres of one (frame, axis) x NWV wavefronts; lane = centre,
-// wavefront q = the q-th share of the widths, so the width -- and with it both divisors and their reciprocals -- is
-// uniform over a wavefront and every LDS read is 64 consecutive words.  The centres' circular neighbourhood is
-// unwrapped into a linear LDS window: a lane's walk is plain descending / ascending addresses.  Wavefront q replays the
-// running sum _Sigma(w) (FrameSynchronisation.jl:101-107) up to the first width of its share -- fma(2, c_v, s) is the
-// reference's s + 2*c_v exactly, doubling being exact -- then evaluates beta over its share.  The replay is adds
-// only and every LDS read is issued eight widths ahead of its use, so the ~24 operations per (centre, width) run
-// NWV-wide while the serial part of a centre stays the 2*(w_min + W) adds the reference has.
+// ---- fold + FIR + Sigma + beta scan + argmax.  Workgroup = 64 blank-band centres of one (frame, axis) x NWV
+// wavefronts; lane = centre, wavefront q = the q-th share of the widths, so the width -- and with it both divisors and
+// their reciprocals -- is uniform over a wavefront and every LDS read is 64 consecutive words.
+// Prologue (every workgroup of an axis repeats it; the inputs are a few KB out of L2): the projection partial sums
+//   proj per frame: colpart[ncp][x_t] | rowpart[nrp][y_t]
+// are added per element in index order starting from the first (the order the producer defines: k_proj's row blocks
+// top to bottom, the raster kernel's tiles in tile order), filtered (fir5) and summed (Sigma, sum64 order).
+// The centres' circular neighbourhood is then unwrapped into a linear LDS window: a lane's walk is plain descending /
+// ascending addresses.  Wavefront q replays the running sum _Sigma(w) (FrameSynchronisation.jl:101-107) up to the
+// first width of its share -- fma(2, c_v, s) is the reference's s + 2*c_v exactly, doubling being exact -- then
+// evaluates beta over its share.  The replay is adds only and every LDS read is issued eight widths ahead of its
+// use, so the ~24 operations per (centre, width) run NWV-wide while the serial part of a centre stays the
+// 2*(w_min + W) adds the reference has.
 // The two divisions per width are by small integers: RN(1/d) (one IEEE division per width and wavefront, kept in a
 // lane and read back with v_readlane) and Markstein's two-FMA correction give the correctly rounded quotient.  The
 // correction needs |x| comfortably normal: min/max of |x| are tracked and a lane that ever left [1e-30, 1e30] (or
 // met an Inf) redoes its share with IEEE divisions.
 // grid.x = ceil(x_t/64) + ceil(y_t/64), grid.y = frames.  write_frame: frame whose beta matrices are stored.
+// The frame's two argmax keys must be zero on entry (the projection producer clears them).
 template <int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_beta(const float *__restrict__ cvb, SyncGeom g,
-                                                   unsigned long long *__restrict__ keys, int write_frame,
+__global__ __launch_bounds__(64 * NWV) void k_beta(const float *__restrict__ proj, size_t proj_stride, int ncp, int nrp,
+                                                   SyncGeom g, unsigned long long *__restrict__ keys, int write_frame,
                                                    float *__restrict__ bx, float *__restrict__ by) {
-  extern __shared__ float cu[];  // [64 + 2*w_max] cv[(cbase - w_max + j) mod n]
+  extern __shared__ float sh[];
   __shared__ unsigned long long wkey[NWV];
+  __shared__ float Ssh;
   const int f = blockIdx.y;
   const int nbx = (g.x_t + 63) >> 6;
   const int axis = (int)blockIdx.x < nbx ? 0 : 1;
@@ -316,20 +282,49 @@ __global__ __launch_bounds__(64 * NWV) void k_beta(const float *__restrict__ cvb
   const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
   const int W = w_max - w_min + 1;
   const int NU = 64 + 2 * w_max;
-  const float *cv = cvb + (size_t)f * (g.x_t + g.y_t + 2) + (axis == 0 ? 0 : g.x_t + 1);
+  float *raw = sh, *cv = sh + n, *cu = sh + 2 * n;  // [n] raw projection, [n] filtered, [NU] cv[(cbase - w_max + j) mod n]
   const int tid = threadIdx.x;
   const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64;
   {
-    int k = (cbase - w_max) % n; if (k < 0) k += n;
-    k += tid;
-    for (int j = tid; j < NU; j += 64 * NWV) {
-      while (k >= n) k -= n;
-      cu[j] = cv[k];
-      k += 64 * NWV;
+    const int cnt = axis == 0 ? ncp : nrp;
+    const float *pr = proj + (size_t)f * proj_stride + (axis == 0 ? 0 : (size_t)ncp * g.x_t);
+    for (int i0 = tid; i0 < n; i0 += 2 * 64 * NWV) {  // two elements per thread and trip: their loads overlap
+      const int i1 = i0 + 64 * NWV;
+      const bool two = i1 < n;
+      const float *qa = pr + i0, *qb = pr + (two ? i1 : i0);
+      float ta = qa[0], tb = qb[0];
+      int j = 1;
+      for (; j + 8 <= cnt; j += 8) {  // loads batched, adds in order
+        float va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { va[u] = qa[(size_t)(j + u) * n]; vb[u] = qb[(size_t)(j + u) * n]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ta = __fadd_rn(ta, va[u]); tb = __fadd_rn(tb, vb[u]); }
+      }
+      for (; j < cnt; ++j) { ta = __fadd_rn(ta, qa[(size_t)j * n]); tb = __fadd_rn(tb, qb[(size_t)j * n]); }
+      raw[i0] = ta;
+      if (two) raw[i1] = tb;
     }
   }
-  const float S = cv[n];
   __syncthreads();
+  for (int i = tid; i < n; i += 64 * NWV) cv[i] = fir5(raw, i, g.h0, g.h1, g.h2, g.h3, g.h4);
+  __syncthreads();
+  if (tid < 64) {  // Sigma in sum64 order
+    float a = 0.0f;
+    for (int i = tid; i < n; i += 64) a = __fadd_rn(a, cv[i]);
+    a = wave_tree64(a);
+    if (tid == 0) Ssh = a;
+  } else {
+    int k = (cbase - w_max) % n; if (k < 0) k += n;
+    k += tid - 64;
+    for (int j = tid - 64; j < NU; j += 64 * (NWV - 1)) {
+      while (k >= n) k -= n;
+      cu[j] = cv[k];
+      k += 64 * (NWV - 1);
+    }
+  }
+  __syncthreads();
+  const float S = Ssh;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int c0 = cbase + lane;
   const int Wq = (W + NWV - 1) / NWV;
@@ -545,12 +540,12 @@ void sync_image_size(const tsdr_sync *s, int *y_t, int *x_t) { *y_t = s->y_t; *x
 // matrices of the LAST frame are materialised into the sync state.
 //   proj: workspace of frames * proj_floats(layout) floats.  have == nullptr: the projections are formed here from
 //   the images (k_proj); else *have describes partial sums some producer has already written to proj.
-//   cvb: workspace of frames * (x_t + y_t + 2) floats (filtered projections and their sums).
+//   A producer other than k_proj must also have cleared keys[2*frames].
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
-                const ProjLayout *have, float *cvb) {
+                const ProjLayout *have) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
-  if (!proj || !keys || !cvb) return TSDR_ENOMEM;
+  if (!proj || !keys) return TSDR_ENOMEM;
   const SyncGeom g = geom_of(s);
   ProjLayout pl;
   if (have) {
@@ -558,22 +553,20 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   } else {
     pl = sync_proj_layout(s);
     TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames), proj_block(), 0, img, img_stride, y, x, proj,
-                proj_floats(y, x, pl));
+                proj_floats(y, x, pl), keys);
   }
-  const size_t nmax = (size_t)(x > y ? x : y);
-  TSDR_LAUNCH(ctx, "sync_fold", k_fold, dim3(2, (unsigned)frames), dim3(256), 2 * nmax * 4, (const float *)proj,
-              proj_floats(y, x, pl), pl.ncp, pl.nrp, g, cvb, keys);
   constexpr int NWV = 8;
+  const size_t nmax = (size_t)(x > y ? x : y);
   const size_t wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
   const unsigned nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta<NWV>, dim3(nbb, (unsigned)frames), dim3(64 * NWV), (64 + 2 * wmax + 8) * 4,
-              (const float *)cvb, g, keys, frames - 1, s->beta_x, s->beta_y);
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta<NWV>, dim3(nbb, (unsigned)frames), dim3(64 * NWV), (2 * nmax + 64 + 2 * wmax + 8) * 4,
+              (const float *)proj, proj_floats(y, x, pl), pl.ncp, pl.nrp, g, keys, frames - 1, s->beta_x, s->beta_y);
   return TSDR_OK;
 }
 
-// workspace for sync_scan_d: returns proj / cvb / keys pointers for `frames` frames in slot `slot` (0/1: the
-// two-stage pipeline keeps two buffers in flight) with room for `pl` (or k_proj's layout when pl == nullptr)
-int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj, float **cvb,
+// workspace for sync_scan_d: the projection buffer (and, on request, a key buffer) for `frames` frames in slot `slot`
+// (0/1: the two-stage pipeline keeps two buffers in flight) with room for `pl` (or k_proj's layout when pl == nullptr)
+int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys) {
   tsdr_ctx *ctx = s->ctx;
   const ProjLayout k = sync_proj_layout(s);
@@ -581,12 +574,9 @@ int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLay
   pl.ncp = std::max(pl.ncp, k.ncp);
   pl.nrp = std::max(pl.nrp, k.nrp);
   const size_t pf = (size_t)frames * proj_floats(s->y_t, s->x_t, pl);
-  const size_t cf = (size_t)frames * (size_t)(s->x_t + s->y_t + 2);
   float *p = (float *)ctx->scratch(WS_PROJ, (size_t)nslots * pf * 4);
-  float *c = (float *)ctx->scratch(WS_CV, (size_t)nslots * cf * 4);
-  if (!p || !c) return TSDR_ENOMEM;
+  if (!p) return TSDR_ENOMEM;
   *proj = p + (size_t)slot * pf;
-  *cvb = c + (size_t)slot * cf;
   if (keys) {  // callers that bring their own key buffer pass nullptr and WS_KEYS is left alone
     unsigned long long *kk = (unsigned long long *)ctx->scratch(WS_KEYS, (size_t)nslots * frames * 2 * 8);
     if (!kk) return TSDR_ENOMEM;
@@ -617,9 +607,9 @@ int tsdr_sync_create(tsdr_ctx *ctx, int y_t, int x_t, tsdr_sync **out) {
   if (!ctx || !out) return TSDR_EINVAL;
   *out = nullptr;
   if (y_t < 8 || x_t < 20) return set_err(ctx, TSDR_EINVAL, "SyncXY needs an image of at least 8x20");
-  // k_fold keeps one axis' raw and filtered projection in LDS (2 * 4 * max(x_t, y_t) bytes of the 64 KiB a kernel
-  // gets without opting in): larger images are refused here, loudly, not at launch
-  if (y_t > 8000 || x_t > 8000) return set_err(ctx, TSDR_EINVAL, "SyncXY supports images up to 8000x8000 (got %dx%d)", y_t, x_t);
+  // k_beta keeps one axis' raw and filtered projection plus a window of it in LDS (about 10 * max(x_t, y_t) bytes of the
+  // 64 KiB a kernel gets without opting in): larger images are refused here, loudly, not at launch
+  if (y_t > 6000 || x_t > 6000) return set_err(ctx, TSDR_EINVAL, "SyncXY supports images up to 6000x6000 (got %dx%d)", y_t, x_t);
   tsdr_sync *s = new tsdr_sync();
   s->ctx = ctx; s->y_t = y_t; s->x_t = x_t;
   // init_gaussian_filter(5): exp(-2k^2/25), k=-2..2, normalised in f64, stored as Float32
@@ -673,11 +663,11 @@ int tsdr_sync_bounds(const tsdr_sync *s, int b[4]) {
 int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   if (!s || !img) return TSDR_EINVAL;
   tsdr_ctx *ctx = s->ctx;
-  float *proj = nullptr, *cvb = nullptr;
+  float *proj = nullptr;
   unsigned long long *keys = nullptr;
-  int rc = sync_workspace(s, 1, 0, 1, nullptr, &proj, &cvb, &keys);
+  int rc = sync_workspace(s, 1, 0, 1, nullptr, &proj, &keys);
   if (rc) return rc;
-  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr, cvb);
+  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
               (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);
