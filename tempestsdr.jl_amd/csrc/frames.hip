@@ -190,9 +190,11 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   ctx->pipe_nb = nb;
   const unsigned slot = (unsigned)(ctx->pipe_n & 1ull);
   float *img2 = (float *)ctx->scratch(WS_IMG, 2 * nb * npx * 4);  // a growing buffer drains the pipeline first
-  unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, nb * 2 * 8);
-  if (!img2 || !keys) return TSDR_ENOMEM;
+  // (the keys are per slot too: stage R of this buffer clears its keys while stage S of the previous one still reads its own)
+  unsigned long long *keys2 = (unsigned long long *)ctx->scratch(WS_KEYS, 2 * nb * 2 * 8);
+  if (!img2 || !keys2) return TSDR_ENOMEM;
   float *img = img2 + (size_t)slot * nb * npx;
+  unsigned long long *keys = keys2 + (size_t)slot * nb * 2;
   LaunchStreamGuard guard(ctx);
   // whatever produced iq / the state on the caller's stream comes first
   TSDR_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));

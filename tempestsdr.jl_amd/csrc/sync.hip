@@ -59,16 +59,17 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 
 // ---- projections: ONE pass over the image ---------------------------------------------------------------
 #ifndef TSDR_ROWSUM_CHUNK8
-// Workgroup = (frame, 64-row block), 8 wavefronts; lanes are rows.  The columns go by in rounds of 8*SUB: wavefront j
-// loads the SUB columns [8*SUB*round + SUB*j, +SUB) of its rows (SUB coalesced 256-byte loads in flight), passes them
-// through its own LDS tile so that lanes-as-columns can fold the 64 rows in order (-> colpart[block][column]),
-// and then the eight wavefronts add their SUB values to the row's running sum one after the other, wavefront 0
-// first: the row sum is one left-to-right chain (-> rowpart[0][row], already final), but only the adds are serial.
-// The next round's loads are issued before the chain, so HBM latency overlaps it.  grid = (nrb, frames).
+// Workgroup = (frame, 64-row block), 8 wavefronts; lanes are rows.  Wavefront j owns the CH columns [CH*j, CH*(j+1)) of
+// a super-round of 8*CH columns (one super-round covers an 800-column image): it loads them all (CH coalesced 256-byte
+// loads per lane in flight -- the whole 64 x 800 slab of the workgroup is requested at once), passes them SB at a time
+// through its own LDS tile so that lanes-as-columns can fold the 64 rows in order (-> colpart[block][column]), and then
+// the eight wavefronts add their CH values to the row's running sum one after the other, wavefront 0 first: the row
+// sum is ONE left-to-right chain (-> rowpart[0][row], already final), but only the adds are serial -- 8 hand-overs per
+// super-round.  grid = (nrb, frames).
 __global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
                                               float *__restrict__ proj, size_t proj_stride,
                                               unsigned long long *__restrict__ keys) {
-  constexpr int SUB = 24, PITCH = SUB + 1, RND = 8 * SUB;  // 8 tiles of 64 x 25 floats = 50 KiB of LDS
+  constexpr int CH = 100, SB = 25, PITCH = SB + 1, RND = 8 * CH;  // 8 tiles of 64 x 26 floats = 52 KiB of LDS
   __shared__ float tile[8][64 * PITCH];
   __shared__ float chain[64];
   const int f = blockIdx.y, rb = blockIdx.x;
@@ -83,50 +84,55 @@ __global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, siz
   const float *p = im + (rv ? r : 0);
   float *mytile = tile[wave];
   const int rounds = (x_t + RND - 1) / RND;
-  float v[SUB], nx[SUB];
-  auto load = [&](int round, float (&dst)[SUB]) {
-    const int cs = round * RND + wave * SUB;
-#pragma unroll
-    for (int u = 0; u < SUB; ++u) dst[u] = (rv && cs + u < x_t) ? p[(size_t)(cs + u) * y_t] : 0.0f;
-  };
-  load(0, v);
   for (int round = 0; round < rounds; ++round) {
-    const int cs = round * RND + wave * SUB;
-    const int nc = max(0, min(SUB, x_t - cs));
+    const int cs = round * RND + wave * CH;
+    const int nc = max(0, min(CH, x_t - cs));
+    float v[CH];
 #pragma unroll
-    for (int u = 0; u < SUB; ++u) mytile[lane * PITCH + u] = v[u];
-    if (round + 1 < rounds) load(round + 1, nx);
-    __syncthreads();
-    if (lane < nc) {  // lanes become columns: the rows of the block in row order
-      float t = 0.0f;
-      const float *col = mytile + lane;
-      int rr = 0;
-      for (; rr + 16 <= nval; rr += 16) {  // reads first, then the adds
-        float w[16];
+    for (int u = 0; u < CH; ++u) v[u] = (rv && u < nc) ? p[(size_t)(cs + u) * y_t] : 0.0f;
+    // column sums of this wavefront's chunk, SB columns at a time (the tile is private to the wavefront: LDS
+    // operations of one wavefront complete in order, the workgroup barrier is not needed)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = col[(rr + u) * PITCH];
+    for (int sb = 0; sb < CH / SB; ++sb) {
+      if (sb * SB < nc) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t = __fadd_rn(t, w[u]);
+        for (int u = 0; u < SB; ++u) mytile[lane * PITCH + u] = v[sb * SB + u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < min(SB, nc - sb * SB)) {  // lanes become columns: the rows of the block in row order
+          float t = 0.0f;
+          const float *col = mytile + lane;
+          int rr = 0;
+          for (; rr + 16 <= nval; rr += 16) {  // reads first, then the adds
+            float w[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[u] = col[(rr + u) * PITCH];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t = __fadd_rn(t, w[u]);
+          }
+          for (; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
+          pr[(size_t)rb * x_t + cs + sb * SB + lane] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      for (; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
-      pr[(size_t)rb * x_t + cs + lane] = t;
     }
     for (int k = 0; k < 8; ++k) {  // the row chain: wavefront k's turn
       if (wave == k && nc > 0) {
         float a = (round == 0 && k == 0) ? 0.0f : chain[lane];
-        if (nc == SUB) {
+        if (nc == CH) {
 #pragma unroll
-          for (int u = 0; u < SUB; ++u) a = __fadd_rn(a, v[u]);
+          for (int u = 0; u < CH; ++u) a = __fadd_rn(a, v[u]);
         } else {
 #pragma unroll
-          for (int u = 0; u < SUB; ++u) if (u < nc) a = __fadd_rn(a, v[u]);
+          for (int u = 0; u < CH; ++u) if (u < nc) a = __fadd_rn(a, v[u]);
         }
         chain[lane] = a;
       }
       __syncthreads();
     }
-#pragma unroll
-    for (int u = 0; u < SUB; ++u) v[u] = nx[u];
   }
   if (wave == 0 && rv) pr[(size_t)nrb * x_t + r] = chain[lane];
 }

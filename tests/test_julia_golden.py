@@ -61,7 +61,7 @@ def compare(cand, ref, vs_julia, only=None):
     for k in sorted(ref):
         if k not in cand or (only is not None and k not in only):
             continue
-        a, b = np.asarray(cand[k]), np.asarray(ref[k])
+        a, b = np.atleast_1d(np.asarray(cand[k])), np.atleast_1d(np.asarray(ref[k]))
         kind, tol = policy_for(k, vs_julia)
         if kind == "skip":
             continue
@@ -80,7 +80,10 @@ def compare(cand, ref, vs_julia, only=None):
             if kind == "sqrtrel":
                 a64, b64 = np.sqrt(a64), np.sqrt(b64)
             d = float(np.max(np.abs(a64 - b64))) if a64.size else 0.0
-            lim = tol if kind == "abs" else tol * float(np.max(np.abs(b64)))
+            scale = float(np.max(np.abs(b64)))
+            if k.startswith("up_H"):  # real and imaginary part of one complex vector: relative to its largest magnitude
+                scale = float(np.max(np.hypot(np.asarray(ref["up_H_re"], np.float64), np.asarray(ref["up_H_im"], np.float64))))
+            lim = tol if kind == "abs" else tol * scale
             ok, err = d <= lim, d
             if vs_julia and ok and any(k.startswith(p) for p, _ in OPEN_VS_JULIA) and d == 0.0:
                 exact_open.append(k)
