@@ -1,9 +1,10 @@
 // spectrum.hip -- GetSpectrum.jl on gfx950 (getSpectrum :21-30, getWelch :36-52,
 // getWaterfall :54-66) and the init_resampler closure of Resampler.jl:26-99.
 // All transforms go through the hand-written FFT engine (fft.hip).
+#include <algorithm>
 #include <cmath>
 
-#include "common.h"
+#include "fft_dev.h"
 
 struct tsdr_resampler {
   tsdr_ctx *ctx;
@@ -52,6 +53,160 @@ __global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X,
     const size_t s = i / sizeFFT, j = i - s * sizeFFT;
     const float2 c = X[s * sizeFFT + shift_src(j, sizeFFT)];
     m[i] = (double)(c.x * c.x + c.y * c.y);
+  }
+}
+
+// ---- 1024-point segments without leaving the chip (getWelch / getWaterfall at their default sizeFFT) -------------
+// One WAVEFRONT transforms one segment: 64 lanes x 16 complex values in registers, two exchanges through a private
+// 8.25 KiB LDS region, no workgroup barrier inside a transform.  With n = l + 64 m (l = lane, m < 16) and
+// k = ka + 16 (kb1 + 16 kb0):
+//   step 1   A[ka]   = sum_m x[l + 64 m] W_16^(m ka)                  16-point DFT in registers, then * W_1024^(l ka)
+//   LDS      Z1[ka][l]  (row pitch 66: the transposed read below is conflict-free)
+//   step 2   lane = (ka, l0), l = l0 + 4 l1:  B[kb1] = sum_l1 Z1[ka][l0 + 4 l1] W_16^(l1 kb1),  then * W_64^(l0 kb1)
+//   LDS      Z2[kb1][ka][l0]
+//   step 3   lane l' reads, for j < 4, the four l0 of (ka = l' & 15, kb1 = 4 j + (l' >> 4)): 4-point DFT over l0
+//            -> X[l' + 64 j + 256 kb0]: for a fixed register the 64 lanes hold 64 consecutive frequencies, so
+//            every global access of the kernel -- loads included -- is one contiguous run per wave-instruction.
+// A wavefront walks a contiguous chunk of segments.  Welch: |X|^2 is accumulated in registers across the chunk
+// (ascending segments), the wavefronts of a workgroup are added in order through LDS and each workgroup leaves one
+// partial spectrum; k_welch_finish adds those in index order, 16 at a time (so the sum over segments is a fixed
+// blocked order: chunk -> workgroup -> groups of 16 workgroups -> total).  The reference accumulates its f32 sum
+// strictly segment by segment (GetSpectrum.jl:44); with f32 FFT outputs that already differ from FFTW's in the last
+// bits the order cannot make the result bit-exact either way, and the blocked order has the smaller rounding error.
+// Waterfall: Float64(|X|^2) goes straight from the registers to sMatrix[:, segment] (fftshift applied to the index).
+constexpr int kSegN = 1024, kSegWaves = 4, kSegPitch = 66;
+
+template <bool WATERFALL, bool CPLX>
+__global__ __launch_bounds__(64 * kSegWaves, 3) void k_seg1024(const float *__restrict__ sig, size_t nbSeg,
+                                                            unsigned nwaves, float *__restrict__ part,
+                                                            double *__restrict__ wf) {
+  __shared__ float2 lds[kSegWaves][16 * kSegPitch];
+  __shared__ float2 tw2t[64];  // W_64^(l0 kb1) at [l0 * 16 + kb1]: four distinct addresses per wave-instruction
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  float2 *z = lds[wave];
+  if (threadIdx.x < 64) tw2t[threadIdx.x] = tw_unit((unsigned)((threadIdx.x >> 4) * (threadIdx.x & 15)), 6);
+  __syncthreads();
+  // wavefront w of nwaves takes the segments [w * nbSeg / nwaves, (w + 1) * nbSeg / nwaves): contiguous, sizes differ by <= 1
+  const size_t wglobal = (size_t)blockIdx.x * kSegWaves + wave;
+  const size_t seg0 = wglobal < nwaves ? wglobal * nbSeg / nwaves : nbSeg;
+  const size_t seg1 = wglobal < nwaves ? (wglobal + 1) * nbSeg / nwaves : nbSeg;
+  // per-lane twiddles W_1024^(l ka), the same for every segment
+  float2 tw1[16];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) tw1[k] = tw_unit((unsigned)(lane * k), 10);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  const int ka2 = lane & 15, l0 = lane >> 4;
+  // the next segment's samples are requested before the current one is transformed: HBM latency under the arithmetic
+  float2 nx[16];
+  auto fetch = [&](size_t seg) {
+    if (CPLX) {
+      const float2 *x = reinterpret_cast<const float2 *>(sig) + seg * kSegN + lane;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) nx[m] = x[64 * m];
+    } else {
+      const float *x = sig + seg * kSegN + lane;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) nx[m] = make_float2(x[64 * m], 0.0f);
+    }
+  };
+  if (seg0 < seg1) fetch(seg0);
+  for (size_t seg = seg0; seg < seg1; ++seg) {
+    float2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = nx[m];
+    if (seg + 1 < seg1) fetch(seg + 1);
+    reg_dft<16>(v);
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) {
+      float2 t = v[brev<16>(ka)];
+      if (ka) t = cmul(t, tw1[ka]);
+      z[ka * kSegPitch + lane] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int l1 = 0; l1 < 16; ++l1) v[l1] = z[ka2 * kSegPitch + l0 + 4 * l1];
+    reg_dft<16>(v);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // every lane has its Z1 values before Z2 overwrites the region
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kb1 = 0; kb1 < 16; ++kb1) {
+      float2 t = v[brev<16>(kb1)];
+      if (kb1) t = cmul(t, tw2t[l0 * 16 + kb1]);
+      z[(kb1 * 16 + ka2) * 4 + l0] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float2 d[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] = z[(64 * j + lane) * 4 + q];
+      reg_dft<4>(d);
+#pragma unroll
+      for (int kb0 = 0; kb0 < 4; ++kb0) {
+        const float2 X = d[brev<4>(kb0)];
+        const float p = X.x * X.x + X.y * X.y;  // abs2 in f32, as the reference's abs2.(::ComplexF32)
+        if (WATERFALL) {
+          const int k = lane + 64 * j + 256 * kb0;
+          wf[seg * kSegN + ((k + kSegN / 2) & (kSegN - 1))] = (double)p;   // fftshift: output index of frequency k
+        } else {
+          acc[j * 4 + kb0] += p;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // Z2 fully read before the next segment's Z1 lands in the region
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (!WATERFALL) {
+    // the workgroup's wavefronts, in wavefront order, through LDS: one partial spectrum per workgroup
+    __syncthreads();
+    float *sp = reinterpret_cast<float *>(&lds[0][0]);  // [kSegWaves][1024] floats fit the kSegWaves x 8448-byte regions
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sp[wave * kSegN + lane + 64 * (i >> 2) + 256 * (i & 3)] = acc[i];
+    __syncthreads();
+    for (int k = threadIdx.x; k < kSegN; k += 64 * kSegWaves) {
+      float t = sp[k];
+#pragma unroll
+      for (int w = 1; w < kSegWaves; ++w) t += sp[w * kSegN + k];
+      part[(size_t)blockIdx.x * kSegN + k] = t;
+    }
+  }
+}
+
+// S[k] = sum over workgroup partials (index order, blocks of 16), then fftshift and optional dB.
+// grid = 1024/16 blocks of 256 threads: thread (kq, g) adds partials [16 g, 16 g + 16) of frequency 16*blockIdx.x + kq.
+__global__ __launch_bounds__(256) void k_welch_finish(const float *__restrict__ part, unsigned nparts, int lin,
+                                                      float *__restrict__ y) {
+  __shared__ float sm[16][17];
+  const int kq = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kq;
+  float tot = 0.0f;
+  for (unsigned base = 0; base < nparts; base += 256) {
+    float t = 0.0f;
+    const unsigned p0 = base + 16 * g;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = p0 + i < nparts ? part[(size_t)(p0 + i) * kSegN + k] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += v[i];
+    sm[g][kq] = t;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tot += sm[i][kq];
+    }
+    __syncthreads();
+  }
+  if (g == 0) {
+    const int j = (k + kSegN / 2) & (kSegN - 1);
+    y[j] = lin ? tot : 10.0f * log10f(tot);
   }
 }
 
@@ -132,8 +287,33 @@ int tsdr_spectrum(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int
                   [&](void *i, void *o) { return spectrum_d(ctx, (const float *)i, is_complex, N, lin, (float *)o); });
 }
 
+// wavefronts of the 1024-point fast path: one per segment up to 4096 (three 4-wavefront workgroups per CU), then
+// contiguous chunks of segments per wavefront
+static unsigned seg_waves(size_t nbSeg, unsigned *blocks) {
+  const unsigned nwaves = (unsigned)std::min<size_t>(nbSeg, 4096);
+  *blocks = (unsigned)ceil_div((size_t)nwaves, (size_t)kSegWaves);
+  return nwaves;
+}
+
 int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y) {
   if (!ctx || !y || (len && !sig)) return TSDR_EINVAL;
+  if (sizeFFT == (size_t)kSegN && len / sizeFFT > 0 && len / sizeFFT < (size_t(1) << 31) &&
+      (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
+    const size_t nbSeg = len / sizeFFT;
+    unsigned blocks = 0;
+    const unsigned nwaves = seg_waves(nbSeg, &blocks);
+    float *part = (float *)ctx->scratch(WS_FFT_A, (size_t)blocks * kSegN * 4);
+    if (!part) return TSDR_ENOMEM;
+    if (is_complex) {
+      TSDR_LAUNCH(ctx, "welch_seg1024", (k_seg1024<false, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves, part,
+                  (double *)nullptr);
+    } else {
+      TSDR_LAUNCH(ctx, "welch_seg1024", (k_seg1024<false, false>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves, part,
+                  (double *)nullptr);
+    }
+    TSDR_LAUNCH(ctx, "welch_finish", k_welch_finish, dim3(kSegN / 16), dim3(256), 0, (const float *)part, blocks, lin, y);
+    return TSDR_OK;
+  }
   float2 *X;
   size_t nbSeg;
   int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);
@@ -151,6 +331,20 @@ int tsdr_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size
 
 int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, double *sMatrix) {
   if (!ctx || (len && !sig)) return TSDR_EINVAL;
+  if (sizeFFT == (size_t)kSegN && len / sizeFFT > 0 && len / sizeFFT < (size_t(1) << 31) && sMatrix &&
+      (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
+    const size_t nbSeg = len / sizeFFT;
+    unsigned blocks = 0;
+    const unsigned nwaves = seg_waves(nbSeg, &blocks);
+    if (is_complex) {
+      TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<true, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
+                  (float *)nullptr, sMatrix);
+    } else {
+      TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<true, false>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
+                  (float *)nullptr, sMatrix);
+    }
+    return TSDR_OK;
+  }
   float2 *X;
   size_t nbSeg;
   int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);

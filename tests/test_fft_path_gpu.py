@@ -229,6 +229,22 @@ def test_welch_and_waterfall(ctx, sizeFFT, cplx):
     assert t[1] == sizeFFT / 1.0
 
 
+def test_welch_waterfall_c2_buffer(ctx):
+    """getWelch / getWaterfall over one C2 capture buffer (1e7 complex samples = 9765 segments of 1024: the LDS-resident
+    one-wavefront-per-segment path with its blocked sum over segments) against the oracle's f64 FFTs and strictly
+    sequential f32 sum."""
+    L = 10_000_000
+    sig = crandn(L)
+    _, y = ctx.getWelch(20e6, sig, lin=True)
+    o = O.getWelch(sig, lin=True)
+    assert relmax(y, o) < 4 * FFT_TOL, relmax(y, o)
+    _, ydb = ctx.getWelch(20e6, sig)
+    assert np.max(np.abs(ydb - O.getWelch(sig))) < 1e-3
+    t, f, m = ctx.getWaterfall(20e6, sig[: 1024 * 3000 + 17])
+    om = O.getWaterfall(sig[: 1024 * 3000 + 17])
+    assert m.shape == (1024, 3000) and relmax(np.sqrt(m), np.sqrt(om)) < 4 * FFT_TOL
+
+
 # ------------------------------------------------------------------ init_resampler
 @pytest.mark.parametrize("bufferSize,up", [(1000, 4), (1024, 2), (999, 3)])
 def test_init_resampler(ctx, bufferSize, up):
