@@ -266,3 +266,19 @@ def test_record_buffers_round_trip(tmp_path):
     assert ing.record_buffers(lambda: next(it), nb, nEch, path) == nb * nEch
     back = dat.readComplexBinary(path, "single")
     assert np.array_equal(np.asarray(back, np.complex64), np.concatenate(bufs))
+
+
+def test_search_route_choice():
+    """The sharded search is used only when a rank's segment+halo transform is smaller than the single-GPU one; with
+    the reference's window (n = 2 * n_lags) the halo puts the same floor under both and every rank runs the
+    single-GPU route (no collective)."""
+    from tempestsdr_jl_amd import parallel as par
+    assert par.single_route_points(4_000_000) == 2_000_000          # C2: native 2^7 5^6 transform
+    assert par.single_route_points(4_000_002) == 4_194_304          # not 5-smooth: zero-padded 2^22
+    for world in (2, 4, 8):
+        assert par.search_route(4_000_000, 2_000_000, world) == "replicated"
+        assert par.search_route(40_000_000, 20_000_000, world) == "replicated"
+    assert par.search_route(4_000_000, 2_000_000, 1) == "single"
+    # a window much longer than the lag range does shard
+    assert par.search_route(16_000_000, 500_000, 8) == "sharded"
+    assert par.sharded_route_points(16_000_000, 500_000, 8) == 4_194_304

@@ -1,0 +1,40 @@
+"""Multi-GPU (RCCL) execution of the two sharded paths, on machines that have more than one GPU.
+
+The parent process never touches the GPU (torch.cuda.device_count() does not initialise it on this image): it launches
+fresh one-process-per-GPU children through torch.distributed.run and checks their exit status.  On a 1-GPU box the
+test skips; the same compositions run at world_size 2 over gloo on CPU in tests/test_host_logic.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_hipframes_and_hipsearch_over_rccl(world):
+    n = _ngpu()
+    if n < world:
+        pytest.skip(f"needs {world} GPUs, this box has {n}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "mgpu_child.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"world {world} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    assert "mgpu_child: OK" in r.stdout
