@@ -23,6 +23,7 @@
 // ordered so that the tiles stacked over one pixel strip run back to back on ONE XCD: the 256-byte segments of
 // vertically adjacent tiles share 128-byte lines, which then merge in that XCD's L2 instead of reaching HBM as
 // two partial writes.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -674,7 +675,10 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
     // per output column (-> colpart[line tile][column]).  Every (strip, row) and (line tile, column) slot is
     // written by exactly one lane of one workgroup, so the buffer needs no clearing; k_fold adds the partials of
     // a row strip by strip and those of a column line tile by line tile.
-    float *rp = reinterpret_cast<float *>(ccol + q.TP + 1);  // [4*VW][64] row sums per wavefront
+    // (the staged samples are dead once every wavefront has finished its walk: their LDS is reused, so the sums cost
+    // no LDS of their own -- at C3's sampling ratio 4 KiB more would have halved the workgroups per CU)
+    __syncthreads();
+    float *rp = reinterpret_cast<float *>(lds_d);            // [4*VW][64] row sums per wavefront
     float *cp = rp + 256 * VW;                               // [4*VW][64] column sums per wavefront
     rp[wave_id * 64 + lane] = di.racc;
     cp[wave_id * 64 + lane] = di.csum;
@@ -1015,7 +1019,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
       q.h_out = h_out; q.w_out = w_out;
       lds += (size_t)(NL + q.TP + 1) * 12 + 16;
       if (pj) {
-        lds += (size_t)2 * 256 * VW * 4;
+        lds = std::max(lds, (size_t)2 * 256 * VW * 4);  // the sums reuse the sample region after the walk
         got->ncp = q.tiles_l;
         got->nrp = q.tiles_p;
         q.proj = proj;
