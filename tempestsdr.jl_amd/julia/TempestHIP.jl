@@ -8,6 +8,7 @@
 # (see INTEGRATION.md).  Julia is not available in the build container, so this file has not
 # been executed there; its Python twin tempestsdr.jl_amd/api.py binds the same entry points with
 # the same conventions and IS exercised by the test-suite.  Keep the two in step.
+# julia/runtests.jl replays tests/golden/v2 through this shim on a machine that has Julia and a GPU.
 #
 # Conventions (tempest_hip.h): status 0 = ok; -1 -> AssertionError/ArgumentError, -2 -> BoundsError;
 # ComplexF32 vectors are passed as-is (interleaved f32); matrices are column-major, as here.
@@ -23,7 +24,9 @@ export hip_frames!           # fused GUI.jl:163-178 loop body (optional fast pat
 const LIB = get(ENV, "TEMPEST_HIP_LIB", joinpath(@__DIR__, "..", "libtempest_hip.so"))
 const RENDERING_SIZE = (600, 800)   # GUI.jl:10
 
-# ---- context: one per task (frame loop and configuration search run on different threads) ----
+# ---- context: one per TASK.  The frame loop runs in a `Threads.@spawn`ed task (GUI.jl:381) and the configuration
+# search in an Observable callback on the main task (GUI.jl:411-419); tasks may migrate between OS threads
+# (Julia >= 1.7), so the key is the task, not Threads.threadid().  A tsdr_ctx is not re-entrant.
 mutable struct Ctx
     h::Ptr{Cvoid}
 end
@@ -31,24 +34,33 @@ function Ctx(device::Integer = 0)
     h = ccall((:tsdr_create, LIB), Ptr{Cvoid}, (Cint,), device)
     h == C_NULL && error("tempest_hip: no usable HIP device (there is no CPU fallback)")
     c = Ctx(h)
-    finalizer(x -> ccall((:tsdr_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+    finalizer(c) do x
+        # children (SyncXY, resamplers, rings) test c.h before freeing themselves: finalizers run in no particular order
+        if x.h != C_NULL
+            ccall((:tsdr_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h)
+            x.h = C_NULL
+        end
+    end
     return c
 end
-const _ctxs = Dict{Int,Ctx}()
-const _lock = ReentrantLock()
-ctx() = lock(_lock) do
-    get!(() -> Ctx(parse(Int, get(ENV, "TEMPEST_HIP_DEVICE", "0"))), _ctxs, Threads.threadid())
-end
+ctx() = get!(() -> Ctx(parse(Int, get(ENV, "TEMPEST_HIP_DEVICE", "0"))), task_local_storage(), :tempest_hip_ctx)::Ctx
 
+# what the reference would have thrown: -1 -> AssertionError (@assert / MethodError sites), -2 -> BoundsError
 function check(c::Ctx, rc::Cint, what)
     rc == 0 && return
     detail = unsafe_string(ccall((:tsdr_last_error, LIB), Cstring, (Ptr{Cvoid},), c.h))
     msg = "$what: " * unsafe_string(ccall((:tsdr_strerror, LIB), Cstring, (Cint,), rc)) * " [$detail]"
     rc == -1 && throw(AssertionError(msg))
-    rc == -2 && throw(BoundsError(msg))
+    rc == -2 && throw(BoundsError(what, detail))   # BoundsError(a, i): "attempt to access <what> at index [<detail>]"
     rc == -3 && throw(OutOfMemoryError())
     error(msg)
 end
+
+# dense storage without a copy when the argument already is one: Arrays, and contiguous views such as the
+# `@views sigAbs[(n-1)*S .+ (1:S)]` of GUI.jl:166 (ccall takes their pointer directly)
+_dense(a::Array) = a
+_dense(a::SubArray{T,1,<:Array,<:Tuple{AbstractUnitRange},true}) where {T} = a
+_dense(a::AbstractArray) = collect(a)
 
 # ---- Demodulation.jl --------------------------------------------------------------------
 function amDemod(sig::Array{ComplexF32})                      # Demodulation.jl:26-28
@@ -69,14 +81,14 @@ end
 
 # ---- Resampler.jl -----------------------------------------------------------------------
 function sig_to_image(sig::AbstractVector{Float32}, y_t, x_t)   # Resampler.jl:117-122
-    s = collect(sig)                                            # views (GUI.jl:166) -> dense
+    s = _dense(sig)
     img = Matrix{Float32}(undef, Int(y_t), Int(x_t)); c = ctx()
     check(c, ccall((:tsdr_sig_to_image, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t, Cint, Cint, Ptr{Float32}),
                    c.h, s, length(s), y_t, x_t, img), "sig_to_image")
     return img
 end
 function downgradeImage(image::AbstractMatrix{Float32})         # Resampler.jl:124-126
-    a = collect(image); out = Matrix{Float32}(undef, RENDERING_SIZE...); c = ctx()
+    a = _dense(image); out = Matrix{Float32}(undef, RENDERING_SIZE...); c = ctx()
     check(c, ccall((:tsdr_downgrade, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Cint, Cint, Ptr{Float32}),
                    c.h, a, size(a, 1), size(a, 2), out), "downgradeImage")
     return out
@@ -93,7 +105,12 @@ function init_resampler(T::Type, bufferSize::Int, upCoeff::Int)  # Resampler.jl:
     c = ctx(); r = Ref{Ptr{Cvoid}}(C_NULL)
     check(c, ccall((:tsdr_resampler_init, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Ptr{Ptr{Cvoid}}), c.h, bufferSize, upCoeff, r), "init_resampler")
     h = r[]
+    keep = Ref(c)                           # the closure keeps its context alive
+    finalizer(keep) do k                    # and the native state goes with the closure
+        k[].h != C_NULL && ccall((:tsdr_resampler_free, LIB), Cvoid, (Ptr{Cvoid},), h)
+    end
     function resampler!(out::AbstractVector{T2}, in::AbstractVector{T2}) where T2
+        keep[] === c || error("unreachable")
         @assert T == T2 "Type of input ($T2) should match type used during init ($T)"             # :44
         @assert length(in) == bufferSize "Size of input $(length(in)) should match size used during init $bufferSize"   # :47
         check(c, ccall((:tsdr_resampler_run, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Csize_t, Ptr{Float32}), h, in, length(in), out), "resampler!")
@@ -104,7 +121,7 @@ init_resampler(x::Vector{T}, upCoeff) where T = init_resampler(T, length(x), upC
 
 # ---- Autocorrelations.jl ------------------------------------------------------------------
 function calculate_autocorrelation(x, Fs, minDelay, maxDelay, scale = :log)   # Autocorrelations.jl:23-37
-    xv = convert(Vector{Float32}, x)
+    xv = x isa Vector{Float32} ? x : convert(Vector{Float32}, x)
     indexMin = 1 + round(minDelay * Fs) |> Int
     indexMax = round(maxDelay * Fs) |> Int
     out = Vector{Float32}(undef, max(indexMax - indexMin + 1, 1)); n = Ref{Csize_t}(0); c = ctx()
@@ -118,7 +135,7 @@ function zoom_autocorr(Γ, Fs; rate_min = 20, rate_max = 100)                 # 
     pmin = Ref{Csize_t}(0); pmax = Ref{Csize_t}(0)
     rc = ccall((:tsdr_zoom_bounds, LIB), Cint, (Csize_t, Cdouble, Cdouble, Cdouble, Ptr{Csize_t}, Ptr{Csize_t}),
                length(Γ), Fs, rate_min, rate_max, pmin, pmax)
-    rc == 0 || throw(BoundsError(Γ, Int(pmin[])))
+    rc == 0 || throw(BoundsError(Γ, Int(pmin[]):Int(pmax[])))
     xAx = (Int(pmin[]):Int(pmax[])) ./ Fs
     return (1 ./ xAx, Γ[Int(pmin[]):Int(pmax[])])
 end
@@ -160,12 +177,14 @@ mutable struct SyncXY{T}                                                      # 
         c = ctx(); r = Ref{Ptr{Cvoid}}(C_NULL)
         check(c, ccall((:tsdr_sync_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}), c.h, size(image, 1), size(image, 2), r), "SyncXY")
         s = new{T}(r[], c, size(image, 1), size(image, 2))
-        finalizer(x -> ccall((:tsdr_sync_free, LIB), Cvoid, (Ptr{Cvoid},), x.h), s)
+        finalizer(s) do x   # tsdr_sync_free touches the context's stream: skip it when the context went first
+            x.c.h != C_NULL && ccall((:tsdr_sync_free, LIB), Cvoid, (Ptr{Cvoid},), x.h)
+        end
         return s
     end
 end
 function vsync(image::AbstractMatrix{T}, sync::SyncXY{T}) where T               # FrameSynchronisation.jl:56-79
-    a = collect(image); sy = Ref{Cint}(0); sx = Ref{Cint}(0)
+    a = _dense(image); sy = Ref{Cint}(0); sx = Ref{Cint}(0)
     size(a) == (sync.y_t, sync.x_t) || throw(DimensionMismatch("image does not match the SyncXY state"))
     check(sync.c, ccall((:tsdr_vsync, LIB), Cint, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cint}, Ptr{Cint}), sync.h, a, sy, sx), "vsync")
     return (Int(sy[]), Int(sx[]))      # s_y lags one call, exactly as the reference (:66)
@@ -206,7 +225,9 @@ function HipRing(c::Ctx, nEch::Integer; depth = 16, sc16 = false, scale = 1f0)
     check(c, ccall((:tsdr_ring_create, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Cint, Cfloat, Ptr{Ptr{Cvoid}}),
                    c.h, nEch, depth, sc16 ? 1 : 0, scale, h), "HipRing")
     r = HipRing(c, h[], nEch, sc16)
-    finalizer(x -> ccall((:tsdr_ring_free, LIB), Cvoid, (Ptr{Cvoid},), x.h), r)
+    finalizer(r) do x
+        x.c.h != C_NULL && ccall((:tsdr_ring_free, LIB), Cvoid, (Ptr{Cvoid},), x.h)
+    end
     return r
 end
 write_slot(r::HipRing) = r.sc16 ?
