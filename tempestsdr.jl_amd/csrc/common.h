@@ -76,11 +76,19 @@ struct tsdr_ctx {
   // tsdr_argmax_d: two device key slots (each launch clears the other one) and a pinned host word for the readback
   unsigned long long *amax_keys = nullptr, *amax_host = nullptr;
   int amax_slot = 0;
-  // two-stage frame pipeline (tsdr_frames_submit_d): raster stage and vsync/IIR stage on their own streams
-  hipStream_t pipe_r = nullptr, pipe_s = nullptr;
-  hipEvent_t pipe_in = nullptr, pipe_er[2] = {nullptr, nullptr}, pipe_es[2] = {nullptr, nullptr};
+  // software-pipelined frame loop (tsdr_frames_submit_d)
   unsigned long long pipe_n = 0;  // submissions since the last flush point
   size_t pipe_nb = 0;             // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
+  struct PipePending {            // shift + IIR of the last submitted buffer: enqueued by the NEXT submission (or the flush)
+    bool valid = false;
+    void *sync = nullptr;
+    const float *img = nullptr;
+    int frames = 0, do_align = 0, slot = 0;
+    const unsigned long long *keys = nullptr;
+    float alpha = 0.f;
+    float *state = nullptr, *frames_out = nullptr;
+    int *sync_idx = nullptr;
+  } pipe_pending;
 
   void *scratch(int slot, size_t bytes);  // nullptr on failure (err set)
 };

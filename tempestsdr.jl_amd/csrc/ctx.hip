@@ -70,8 +70,6 @@ void *tsdr_ctx::scratch(int slot, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.cap >= bytes) return b.p;
   if (b.p) {
-    if (pipe_r) (void)hipStreamSynchronize(pipe_r);
-    if (pipe_s) (void)hipStreamSynchronize(pipe_s);
     (void)hipStreamSynchronize(stream);
     (void)hipFree(b.p);
     b.p = nullptr;
@@ -133,10 +131,6 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->pipe_r) { (void)hipStreamSynchronize(ctx->pipe_r); (void)hipStreamDestroy(ctx->pipe_r); }
-  if (ctx->pipe_s) { (void)hipStreamSynchronize(ctx->pipe_s); (void)hipStreamDestroy(ctx->pipe_s); }
-  for (hipEvent_t e : {ctx->pipe_in, ctx->pipe_er[0], ctx->pipe_er[1], ctx->pipe_es[0], ctx->pipe_es[1]})
-    if (e) (void)hipEventDestroy(e);
   for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
   for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -184,8 +178,6 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
 
 int tsdr_synchronize(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;
-  if (ctx->pipe_r) TSDR_HIP(ctx, hipStreamSynchronize(ctx->pipe_r));
-  if (ctx->pipe_s) TSDR_HIP(ctx, hipStreamSynchronize(ctx->pipe_s));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TSDR_OK;
 }

@@ -27,6 +27,9 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
                 const ProjLayout *have);
 int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys);
+int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
+                          const ProjLayout *have, const float *img_c, int frames_c, const unsigned long long *keys_c, int do_align,
+                          float alpha, float *state, float *frames_out, int *sync_idx);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx);
@@ -35,6 +38,8 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
 using namespace tsdr;
 
 extern "C" {
+
+static int pipe_drain(tsdr_ctx *ctx);
 
 static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
   if (!do_align) return TSDR_OK;
@@ -49,11 +54,11 @@ static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
 // The loop body for F frames.  Stage R: raster (optional) + 600x800 image of every frame in one launch; in TSDR_FAST
 // mode the same kernel also forms the images' projection partial sums on the fly, so no kernel re-reads the images
 // for them.  Stage S: vsync statistics (two argmax keys per frame) and, with `combine`, shift + IIR.
-// slot/nslots: which half of the sync workspaces this buffer uses.  pipelined: stage R is enqueued on pipe_r and
-// stage S on pipe_s behind it (tsdr_frames_submit_d); else everything goes to the context's stream.
+// slot/nslots: which half of the sync workspaces this buffer uses.  Everything goes to the context's stream
+// (tsdr_frames_submit_d schedules the same launches over two streams itself).
 static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t S, int y_t, int x_t, int do_align, int F,
                         float *img, float *raster_out, unsigned long long *keys, int slot, int nslots, float alpha,
-                        float *state, float *frames_out, int *sync_idx, bool pipelined, bool combine = true) {
+                        float *state, float *frames_out, int *sync_idx, bool combine = true) {
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   float *proj = nullptr;
   ProjLayout plan{}, got{};
@@ -65,15 +70,9 @@ static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t 
     rc = sync_workspace(sync, F, slot, nslots, plan.ncp ? &plan : nullptr, &proj, nullptr);
     if (rc) return rc;
   }
-  if (pipelined) ctx->launch_stream = ctx->pipe_r;
   rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx,
                          proj, &got, false, keys);
   if (rc) return rc;
-  if (pipelined) {
-    TSDR_HIP(ctx, hipEventRecord(ctx->pipe_er[slot], ctx->pipe_r));
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_er[slot], 0));
-    ctx->launch_stream = ctx->pipe_s;
-  }
   if (do_align) {
     rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr);
     if (rc) return rc;
@@ -83,7 +82,6 @@ static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t 
                      do_align ? sync_idx : nullptr);
     if (rc) return rc;
   }
-  if (pipelined) TSDR_HIP(ctx, hipEventRecord(ctx->pipe_es[slot], ctx->pipe_s));
   return TSDR_OK;
 }
 
@@ -100,7 +98,7 @@ int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t n
   if (!img_out || (do_align && !keys_out)) return TSDR_EINVAL;
   const int F = (int)nb;
   return frames_stage(ctx, sync, iq, S, y_t, x_t, do_align, F, img_out, raster_out, keys_out, 0, 1, 0.0f, nullptr, nullptr, nullptr,
-                      /*pipelined=*/false, /*combine=*/false);
+                      /*combine=*/false);
 }
 
 int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, const unsigned long long *keys, int n_frames,
@@ -120,6 +118,10 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
   if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
   const size_t nb = nEch / S;
   if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
+  if (ctx->pipe_n) {  // buffers submitted through the pipeline come first (SyncXY and imageOut state are sequential)
+    int rcd = pipe_drain(ctx);
+    if (rcd) return rcd;
+  }
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   float *img = (float *)ctx->scratch(WS_IMG, (nb ? nb : 1) * npx * 4);
   unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, (nb ? nb : 1) * 2 * 8);
@@ -134,35 +136,37 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
   return tsdr_frames_combine_d(ctx, sync, img, keys, nf, alpha, do_align, imageOut_state, frames_out, sync_idx);
 }
 
-// ---- the same body as a two-stage pipeline across successive buffers ------------------------------------------
-// Stage R (raster + 600x800 images) of buffer k+1 has no dependence on stage S (vsync statistics, shift, IIR) of
-// buffer k, and the two are bound by different things: R is a full-chip streaming kernel, S is three short
-// launches that are latency-bound and leave most CUs idle.  submit enqueues R on one internal stream and S on
-// another; S(k) waits for R(k), S stages run in order (they carry the SyncXY and imageOut state), and R(k+2) waits
-// for S(k) because the two alternate between two image slots.  Nothing waits on the host.
-static int pipe_init(tsdr_ctx *ctx) {
-  if (ctx->pipe_r) return TSDR_OK;
-  // the S stage is three short dependent launches: it gets the higher priority, so that its workgroups are placed
-  // as soon as raster workgroups retire instead of queueing behind the rest of the raster grid
-  int prio_lo = 0, prio_hi = 0;
-  TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->pipe_r, hipStreamNonBlocking, prio_lo));
-  TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->pipe_s, hipStreamNonBlocking, prio_hi));
-  TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_in, hipEventDisableTiming));
-  for (int i = 0; i < 2; ++i) {
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_er[i], hipEventDisableTiming));
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_es[i], hipEventDisableTiming));
-  }
+// ---- the same body software-pipelined across successive buffers ------------------------------------------------
+// What bounds the three stages of a buffer is different: the raster launch R is held by the memory system (its store
+// stream), shift + IIR (C) likewise, while the vsync statistics (B: k_beta) are a chain of LDS latencies that leaves
+// the memory system idle.  B(k) needs R(k) and C(k) needs B(k), but C(k-1) and B(k) are independent: submit(k)
+// enqueues
+//        R(k)   ->   [ B(k) + C(k-1) ]  as ONE launch (k_tail)
+// on the context's stream, so shift + IIR of a buffer rides along with the statistics of the next one and a buffer
+// costs two launches instead of three.  C(k) is thus enqueued by submit(k+1) -- or by the flush: outputs of a
+// submission are complete (in stream order) after the next submission or tsdr_frames_flush.  Two image / key /
+// projection slots alternate between buffers.
+// Tried on MI355X and dropped: R on one stream with B + C (0.198 vs 0.183 ms per buffer: the two memory-bound
+// launches slow each other down) or B alone (0.196 vs 0.175 ms) on a second stream -- an event hand-over between two
+// HIP streams costs 6-13 us on this stack, more than B is long.
+static int pipe_combine_pending(tsdr_ctx *ctx) {
+  tsdr_ctx::PipePending &p = ctx->pipe_pending;
+  if (!p.valid) return TSDR_OK;
+  int rc = shift_iir_d(ctx, (tsdr_sync *)p.sync, p.img, (size_t)TSDR_RENDER_H * TSDR_RENDER_W, TSDR_RENDER_H, TSDR_RENDER_W, p.frames,
+                       p.keys, p.do_align, p.alpha, p.state, p.frames_out, p.do_align ? p.sync_idx : nullptr);
+  if (rc) return rc;
+  p.valid = false;
   return TSDR_OK;
 }
 
-namespace {
-struct LaunchStreamGuard {  // TSDR_LAUNCH targets ctx->launch_stream: whatever path leaves submit, it is the caller's again
-  tsdr_ctx *ctx;
-  explicit LaunchStreamGuard(tsdr_ctx *c) : ctx(c) {}
-  ~LaunchStreamGuard() { ctx->launch_stream = ctx->stream; }
-};
-}  // namespace
+// everything submitted so far is enqueued; the stream then holds all of it
+static int pipe_drain(tsdr_ctx *ctx) {
+  if (ctx->pipe_n == 0) return TSDR_OK;
+  int rc = pipe_combine_pending(ctx);
+  if (rc) return rc;
+  ctx->pipe_n = 0;
+  return TSDR_OK;
+}
 
 int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
@@ -175,47 +179,58 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
   if (n_frames) *n_frames = (int)nb;
   if (nb == 0) return TSDR_OK;
-  rc = pipe_init(ctx);
-  if (rc) return rc;
   const int F = (int)nb;
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   // The two image slots sit nb frames apart, so a submission whose frame count differs from the one in flight (S or
-  // nEch changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images stage S of the previous buffer is still
-  // reading.  Such a submission first lets the pipeline run empty -- on the device, nothing waits on the host.
+  // nEch changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images the pending shift + IIR still has to
+  // read: that one is enqueued first.
   if (ctx->pipe_n > 0 && ctx->pipe_nb != nb) {
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_es[(ctx->pipe_n - 1) & 1ull], 0));
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_es[(ctx->pipe_n - 1) & 1ull], 0));
-    ctx->pipe_n = 0;
+    rc = pipe_drain(ctx);
+    if (rc) return rc;
   }
   ctx->pipe_nb = nb;
   const unsigned slot = (unsigned)(ctx->pipe_n & 1ull);
-  float *img2 = (float *)ctx->scratch(WS_IMG, 2 * nb * npx * 4);  // a growing buffer drains the pipeline first
-  // (the keys are per slot too: stage R of this buffer clears its keys while stage S of the previous one still reads its own)
+  float *img2 = (float *)ctx->scratch(WS_IMG, 2 * nb * npx * 4);
   unsigned long long *keys2 = (unsigned long long *)ctx->scratch(WS_KEYS, 2 * nb * 2 * 8);
   if (!img2 || !keys2) return TSDR_ENOMEM;
   float *img = img2 + (size_t)slot * nb * npx;
   unsigned long long *keys = keys2 + (size_t)slot * nb * 2;
-  LaunchStreamGuard guard(ctx);
-  // whatever produced iq / the state on the caller's stream comes first
-  TSDR_HIP(ctx, hipEventRecord(ctx->pipe_in, ctx->stream));
-  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_in, 0));
-  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_s, ctx->pipe_in, 0));
-  if (ctx->pipe_n >= 2) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->pipe_r, ctx->pipe_es[slot], 0));  // image slot free again
-  // stage R on pipe_r: raster + images (+ in-walk projection sums); stage S on pipe_s: statistics, shift, IIR
-  rc = frames_stage(ctx, sync, iq, S, y_t, x_t, do_align, F, img, raster_out, keys, (int)slot, 2, alpha, imageOut_state,
-                    frames_out, sync_idx, /*pipelined=*/true);
+  float *proj = nullptr;
+  ProjLayout plan{}, got{};
+  if (do_align) {
+    rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, nullptr,
+                           &plan, true);
+    if (rc) return rc;
+    rc = sync_workspace(sync, F, (int)slot, 2, plan.ncp ? &plan : nullptr, &proj, nullptr);
+    if (rc) return rc;
+  }
+  rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj, &got,
+                         false, keys);
   if (rc) return rc;
+  tsdr_ctx::PipePending &p = ctx->pipe_pending;
+  if (do_align && p.valid && p.do_align && p.sync == sync) {
+    // the tail launch: statistics of this buffer + shift/IIR of the previous one
+    rc = sync_scan_and_shift_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, p.img, p.frames, p.keys, 1, p.alpha, p.state,
+                               p.frames_out, p.sync_idx);
+    if (rc) return rc;
+    p.valid = false;
+  } else {
+    rc = pipe_combine_pending(ctx);
+    if (rc) return rc;
+    if (do_align) {
+      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr);
+      if (rc) return rc;
+    }
+  }
+  p.valid = true; p.sync = sync; p.img = img; p.frames = F; p.do_align = do_align; p.slot = (int)slot; p.keys = keys;
+  p.alpha = alpha; p.state = imageOut_state; p.frames_out = frames_out; p.sync_idx = sync_idx;
   ++ctx->pipe_n;
   return TSDR_OK;
 }
 
 int tsdr_frames_flush(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;
-  if (ctx->pipe_n == 0) return TSDR_OK;
-  // stage S of the last submission is the last thing enqueued: the caller's stream continues after it
-  TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipe_es[(ctx->pipe_n - 1) & 1ull], 0));
-  ctx->pipe_n = 0;
-  return TSDR_OK;
+  return pipe_drain(ctx);
 }
 
 int tsdr_frames(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,

@@ -274,23 +274,37 @@ __device__ inline float beta_scan(const float *cv, int n, int c0, int w_min, int
 // met an Inf) redoes its share with IEEE divisions.
 // grid.x = ceil(x_t/64) + ceil(y_t/64), grid.y = frames.  write_frame: frame whose beta matrices are stored.
 // The frame's two argmax keys must be zero on entry (the projection producer clears them).
+struct BetaArgs {
+  const float *proj;
+  size_t proj_stride;
+  int ncp, nrp;
+  SyncGeom g;
+  unsigned long long *keys;
+  int write_frame;
+  float *bx, *by;
+};
+
+// body of one k_beta workgroup: blk = block index within the frame (x-axis blocks first), f = frame
 template <int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_beta(const float *__restrict__ proj, size_t proj_stride, int ncp, int nrp,
-                                                   SyncGeom g, unsigned long long *__restrict__ keys, int write_frame,
-                                                   float *__restrict__ bx, float *__restrict__ by) {
-  extern __shared__ float sh[];
+__device__ inline void beta_wg(const BetaArgs &A, int blk, int f, float *sh) {
+  const float *__restrict__ proj = A.proj;
+  const size_t proj_stride = A.proj_stride;
+  const int ncp = A.ncp, nrp = A.nrp;
+  const SyncGeom &g = A.g;
+  unsigned long long *__restrict__ keys = A.keys;
+  const int write_frame = A.write_frame;
+  float *__restrict__ bx = A.bx, *__restrict__ by = A.by;
   __shared__ unsigned long long wkey[NWV];
   __shared__ float Ssh;
-  const int f = blockIdx.y;
   const int nbx = (g.x_t + 63) >> 6;
-  const int axis = (int)blockIdx.x < nbx ? 0 : 1;
+  const int axis = blk < nbx ? 0 : 1;
   const int n = axis == 0 ? g.x_t : g.y_t;
   const int w_min = axis == 0 ? g.wmin_x : g.wmin_y, w_max = axis == 0 ? g.wmax_x : g.wmax_y;
   const int W = w_max - w_min + 1;
   const int NU = 64 + 2 * w_max;
   float *raw = sh, *cv = sh + n, *cu = sh + 2 * n;  // [n] raw projection, [n] filtered, [NU] cv[(cbase - w_max + j) mod n]
   const int tid = threadIdx.x;
-  const int cbase = ((int)blockIdx.x - (axis == 0 ? 0 : nbx)) * 64;
+  const int cbase = (blk - (axis == 0 ? 0 : nbx)) * 64;
   {
     const int cnt = axis == 0 ? ncp : nrp;
     const float *pr = proj + (size_t)f * proj_stride + (axis == 0 ? 0 : (size_t)ncp * g.x_t);
@@ -431,6 +445,12 @@ __global__ __launch_bounds__(64 * NWV) void k_beta(const float *__restrict__ pro
   }
 }
 
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_beta(BetaArgs A) {
+  extern __shared__ float sh[];
+  beta_wg<NWV>(A, (int)blockIdx.x, (int)blockIdx.y, sh);
+}
+
 __device__ inline int key_col1(unsigned long long key) {  // 1-based column of the packed argmax
   return (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) + 1;
 }
@@ -440,14 +460,31 @@ __device__ inline int key_col1(unsigned long long key) {  // 1-based column of t
 // out = alpha*out + (1-alpha)*img_shifted, f32, two products and one sum (no FMA).
 // Block 0 also publishes (s_y,s_x) per frame and the s_y the NEXT call starts with (pend_out; the two
 // pending slots alternate between calls, so no block can read a value this launch has overwritten).
-__global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img, size_t img_stride, int h, int w,
-                                                   int frames, const unsigned long long *__restrict__ keys,
-                                                   const int *__restrict__ pend_in, int *__restrict__ pend_out,
-                                                   int *__restrict__ sync_idx, int do_align, float alpha,
-                                                   float *__restrict__ state, float *__restrict__ frames_out) {
+struct IirArgs {
+  const float *img;
+  size_t img_stride;
+  int h, w, frames;
+  const unsigned long long *keys;
+  const int *pend_in;
+  int *pend_out, *sync_idx;
+  int do_align;
+  float alpha;
+  float *state, *frames_out;
+};
+
+// body of one shift + IIR workgroup: wg = workgroup index, nthr = its thread count
+__device__ inline void shift_iir_wg(const IirArgs &A, unsigned wg, unsigned nthr) {
+  const float *__restrict__ img = A.img;
+  const size_t img_stride = A.img_stride;
+  const int h = A.h, w = A.w, frames = A.frames, do_align = A.do_align;
+  const unsigned long long *__restrict__ keys = A.keys;
+  const int *__restrict__ pend_in = A.pend_in;
+  int *__restrict__ pend_out = A.pend_out, *__restrict__ sync_idx = A.sync_idx;
+  const float alpha = A.alpha;
+  float *__restrict__ state = A.state, *__restrict__ frames_out = A.frames_out;
   const size_t npx = (size_t)h * w;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (do_align && blockIdx.x == 0 && threadIdx.x == 0) {
+  const size_t idx = (size_t)wg * nthr + threadIdx.x;
+  if (do_align && wg == 0 && threadIdx.x == 0) {
     int sy = pend_in[0];
     for (int f = 0; f < frames; ++f) {
       if (sync_idx) { sync_idx[2 * f] = sy; sync_idx[2 * f + 1] = key_col1(keys[(size_t)f * 2 + 0]); }
@@ -487,6 +524,24 @@ __global__ __launch_bounds__(256) void k_shift_iir(const float *__restrict__ img
     if (frames_out) frames_out[(size_t)f * npx + idx] = acc;
   }
   state[idx] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_shift_iir(IirArgs A) { shift_iir_wg(A, blockIdx.x, 256u); }
+
+// The pipeline's tail launch: the vsync statistics of buffer k (k_beta workgroups, first in dispatch order) and shift +
+// IIR of buffer k-1 (the rest) in ONE grid.  The two are independent; the first is a chain of LDS latencies that
+// leaves the memory system idle, the second a stream that leaves the ALUs idle, so side by side they take little
+// more than the longer one -- with plain kernel boundaries around them instead of cross-stream events (measured:
+// an event hand-over between two HIP streams costs 6-13 us on this stack, more than it could hide).
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_tail(BetaArgs B, unsigned nbb, unsigned nB, IirArgs I) {
+  extern __shared__ float sh[];
+  // the two kinds of workgroup are interleaved in dispatch order in proportion to their numbers, so that every CU
+  // holds some of each from the start: block i is the b0-th statistics workgroup iff floor((i+1) nB / n) > floor(i nB / n)
+  const unsigned long long i = blockIdx.x, n = gridDim.x;
+  const unsigned b0 = (unsigned)(i * nB / n), b1 = (unsigned)((i + 1) * nB / n);
+  if (b1 > b0) beta_wg<NWV>(B, (int)(b0 % nbb), (int)(b0 / nbb), sh);
+  else shift_iir_wg(I, (unsigned)i - b0, 64u * NWV);
 }
 
 // standalone vsync: publish (s_y,s_x) of one scanned image and roll the pending s_y
@@ -547,12 +602,31 @@ void sync_image_size(const tsdr_sync *s, int *y_t, int *x_t) { *y_t = s->y_t; *x
 //   proj: workspace of frames * proj_floats(layout) floats.  have == nullptr: the projections are formed here from
 //   the images (k_proj); else *have describes partial sums some producer has already written to proj.
 //   A producer other than k_proj must also have cleared keys[2*frames].
+constexpr int kBetaWaves = 8;
+
+static void beta_args(tsdr_sync *s, const float *proj, ProjLayout pl, unsigned long long *keys, int frames, BetaArgs *B,
+                      unsigned *nbb, size_t *lds) {
+  const int y = s->y_t, x = s->x_t;
+  B->proj = proj; B->proj_stride = proj_floats(y, x, pl); B->ncp = pl.ncp; B->nrp = pl.nrp; B->g = geom_of(s);
+  B->keys = keys; B->write_frame = frames - 1; B->bx = s->beta_x; B->by = s->beta_y;
+  const size_t nmax = (size_t)(x > y ? x : y), wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
+  *nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
+  *lds = (2 * nmax + 64 + 2 * wmax + 8) * 4;
+}
+
+static void iir_args(tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames, const unsigned long long *keys,
+                     int do_align, float alpha, float *state, float *frames_out, int *sync_idx, IirArgs *I) {
+  I->img = img; I->img_stride = img_stride; I->h = h; I->w = w; I->frames = frames; I->keys = keys;
+  I->pend_in = do_align ? s->pending + s->cur : nullptr;
+  I->pend_out = do_align ? s->pending + (s->cur ^ 1) : nullptr;
+  I->sync_idx = sync_idx; I->do_align = do_align; I->alpha = alpha; I->state = state; I->frames_out = frames_out;
+}
+
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
                 const ProjLayout *have) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
   if (!proj || !keys) return TSDR_ENOMEM;
-  const SyncGeom g = geom_of(s);
   ProjLayout pl;
   if (have) {
     pl = *have;
@@ -561,12 +635,11 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
     TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames), proj_block(), 0, img, img_stride, y, x, proj,
                 proj_floats(y, x, pl), keys);
   }
-  constexpr int NWV = 8;
-  const size_t nmax = (size_t)(x > y ? x : y);
-  const size_t wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
-  const unsigned nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta<NWV>, dim3(nbb, (unsigned)frames), dim3(64 * NWV), (2 * nmax + 64 + 2 * wmax + 8) * 4,
-              (const float *)proj, proj_floats(y, x, pl), pl.ncp, pl.nrp, g, keys, frames - 1, s->beta_x, s->beta_y);
+  BetaArgs B;
+  size_t lds = 0;
+  unsigned nbb = 0;
+  beta_args(s, proj, pl, keys, frames, &B, &nbb, &lds);
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
   return TSDR_OK;
 }
 
@@ -595,10 +668,37 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx) {
   const size_t npx = (size_t)h * w;
-  const int *pin = do_align ? s->pending + s->cur : nullptr;
-  int *pout = do_align ? s->pending + (s->cur ^ 1) : nullptr;
-  TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, img, img_stride, h, w,
-              frames, keys, pin, pout, sync_idx, do_align, alpha, state, frames_out);
+  IirArgs I;
+  iir_args(s, img, img_stride, h, w, frames, keys, do_align, alpha, state, frames_out, sync_idx, &I);
+  TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, I);
+  if (do_align) s->cur ^= 1;
+  return TSDR_OK;
+}
+
+// the pipeline's tail: vsync statistics of one buffer (frames_b images -> keys_b; projections as in sync_scan_d) and
+// shift + IIR of the PREVIOUS buffer, one launch (k_tail)
+int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
+                          const ProjLayout *have, const float *img_c, int frames_c, const unsigned long long *keys_c, int do_align,
+                          float alpha, float *state, float *frames_out, int *sync_idx) {
+  tsdr_ctx *ctx = s->ctx;
+  const int y = s->y_t, x = s->x_t;
+  if (!proj || !keys_b) return TSDR_ENOMEM;
+  ProjLayout pl;
+  if (have) {
+    pl = *have;
+  } else {
+    pl = sync_proj_layout(s);
+    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames_b), proj_block(), 0, img_b, img_stride, y, x, proj,
+                proj_floats(y, x, pl), keys_b);
+  }
+  BetaArgs B;
+  IirArgs I;
+  size_t lds = 0;
+  unsigned nbb = 0;
+  beta_args(s, proj, pl, keys_b, frames_b, &B, &nbb, &lds);
+  iir_args(s, img_c, img_stride, y, x, frames_c, keys_c, do_align, alpha, state, frames_out, sync_idx, &I);
+  const unsigned nB = nbb * (unsigned)frames_b, nC = (unsigned)ceil_div((size_t)y * x, (size_t)64 * kBetaWaves);
+  TSDR_LAUNCH(ctx, "sync_beta+shift_iir", k_tail<kBetaWaves>, dim3(nB + nC), dim3(64 * kBetaWaves), lds, B, nbb, nB, I);
   if (do_align) s->cur ^= 1;
   return TSDR_OK;
 }
