@@ -1,0 +1,55 @@
+"""Build profiles/traffic.json from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/collect_profiles.sh.
+
+    python tools/make_traffic.py gpurun_out/<tag>_pmc_FETCH_SIZE gpurun_out/<tag>_pmc_WRITE_SIZE <tag> [workload]
+
+Per kernel: median counter value over its launches (KB), corrected as MI355X_MICROARCH.md's HBM section prescribes for
+gfx950 -- FETCH_SIZE counts wide coalesced reads at one half (x2), WRITE_SIZE is taken as is.  For the raster kernel
+only the raster-materialising launches (OUT = true template argument) are used."""
+import csv, glob, json, os, statistics, sys
+
+NAMES = {  # kernel-name substring -> bench.py's launch name
+    "k_raster_fast<true, true, true, 32, true": "raster_down_iq",
+    "k_raster_fast<true, true, true, 32, false": "down_walk_iq",
+    "k_raster_tile<true, true>": "raster_down_iq_exact",
+    "k_shift_iir": "shift_iir", "k_proj": "sync_proj", "k_beta": "sync_beta", "k_tail": "sync_beta+shift_iir",
+    "k_seg1024<false": "welch_seg1024", "k_seg1024<true": "waterfall_seg1024",
+}
+
+
+def collect(d, counter):
+    out = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            for sub, name in NAMES.items():
+                if sub in r["Kernel_Name"]:
+                    out.setdefault(name, []).append(float(r["Counter_Value"]))
+                    break
+    return {k: statistics.median(v) for k, v in out.items()}
+
+
+def main():
+    fdir, wdir, tag = sys.argv[1:4]
+    wl = sys.argv[4] if len(sys.argv) > 4 else "C2"
+    f, w = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        doc = {}
+    doc["_note"] = ("HBM-side bytes per launch from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, --kernel-trace "
+                    "only) on `python3 bench.py --quick --steps 5 --warmup 2` (MI355X, ROCm 7.2); built by tools/make_traffic.py from "
+                    f"the passes tagged {tag}.  Counter unit KB, median over a kernel's launches.  gfx950 correction per "
+                    "MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts coalesced reads at one half, so fetch bytes = "
+                    "FETCH_SIZE*1024*2; WRITE_SIZE taken as is.  Infinity-Cache hits are included in FETCH_SIZE.")
+    doc[wl] = {}
+    for k in sorted(set(f) | set(w)):
+        fk, wk = f.get(k, 0.0), w.get(k, 0.0)
+        doc[wl][k] = {"fetch_size_kb": round(fk), "write_size_kb": round(wk), "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)}
+    json.dump(doc, open(path, "w"), indent=1)
+    print(json.dumps(doc[wl], indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Development aid: build ab/<name>.so from the working tree with one sed edit applied to one csrc file.
+#   tools/mk_variant.sh <name> <file.hip> '<sed expression>' [extra hipcc flags]
+set -e
+NAME=$1; FILE=$2; EXPR=$3; shift 3
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+TMP=$(mktemp -d)
+mkdir -p "$TMP/tempestsdr.jl_amd" "$TMP/obj" "$ROOT/ab"
+cp -r "$ROOT/tempestsdr.jl_amd/csrc" "$TMP/tempestsdr.jl_amd/"; cp -r "$ROOT/include" "$TMP/"
+sed -i "$EXPR" "$TMP/tempestsdr.jl_amd/csrc/$FILE"
+if cmp -s "$TMP/tempestsdr.jl_amd/csrc/$FILE" "$ROOT/tempestsdr.jl_amd/csrc/$FILE"; then echo "sed changed nothing"; exit 1; fi
+# only the edited file is recompiled; the rest comes from the in-tree build
+cp "$ROOT"/tempestsdr.jl_amd/build/*.o "$TMP/obj/"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -w "$@" -c "$TMP/tempestsdr.jl_amd/csrc/$FILE" -o "$TMP/obj/$(basename "$FILE" .hip).o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o
+rm -rf "$TMP"; ls -la "$ROOT/ab/$NAME.so"
