@@ -66,9 +66,11 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 // the eight wavefronts add their CH values to the row's running sum one after the other, wavefront 0 first: the row
 // sum is ONE left-to-right chain (-> rowpart[0][row], already final), but only the adds are serial -- 8 hand-overs per
 // super-round.  grid = (nrb, frames).
-__global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                              float *__restrict__ proj, size_t proj_stride,
-                                              unsigned long long *__restrict__ keys) {
+// (launch bound: 128 registers, so that two workgroups share a CU and the 300 of a C2 buffer are resident at once --
+// at 136 registers they ran in two rounds)
+__global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
+                                                 float *__restrict__ proj, size_t proj_stride,
+                                                 unsigned long long *__restrict__ keys) {
   constexpr int CH = 100, SB = 25, PITCH = SB + 1, RND = 8 * CH;  // 8 tiles of 64 x 26 floats = 52 KiB of LDS
   __shared__ float tile[8][64 * PITCH];
   __shared__ float chain[64];
@@ -104,12 +106,12 @@ __global__ __launch_bounds__(512) void k_proj(const float *__restrict__ img, siz
           float t = 0.0f;
           const float *col = mytile + lane;
           int rr = 0;
-          for (; rr + 16 <= nval; rr += 16) {  // reads first, then the adds
-            float w[16];
+          for (; rr + 8 <= nval; rr += 8) {  // reads first, then the adds
+            float w[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) w[u] = col[(rr + u) * PITCH];
+            for (int u = 0; u < 8; ++u) w[u] = col[(rr + u) * PITCH];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t = __fadd_rn(t, w[u]);
+            for (int u = 0; u < 8; ++u) t = __fadd_rn(t, w[u]);
           }
           for (; rr < nval; ++rr) t = __fadd_rn(t, col[rr * PITCH]);
           pr[(size_t)rb * x_t + cs + sb * SB + lane] = t;
