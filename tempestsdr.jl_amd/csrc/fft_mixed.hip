@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "fft_dev.h"
@@ -67,6 +69,8 @@ __device__ constexpr float kSin25[17] = {0.f, 0.24868988716485479f, 0.4817536741
     -0.58778525229247269f, -0.77051324277578936f};
 __device__ constexpr float kCos10[5] = {1.f, 0.80901699437494745f, 0.30901699437494745f, -0.30901699437494734f, -0.80901699437494734f};
 __device__ constexpr float kSin10[5] = {0.f, 0.58778525229247314f, 0.95105651629515353f, 0.95105651629515364f, 0.58778525229247325f};
+__device__ constexpr float kCos20[13] = {1.0f, 0.9510565162951535f, 0.8090169943749475f, 0.5877852522924731f, 0.30901699437494745f, 6.123233995736766e-17f, -0.30901699437494734f, -0.587785252292473f, -0.8090169943749473f, -0.9510565162951535f, -1.0f, -0.9510565162951538f, -0.8090169943749476f};
+__device__ constexpr float kSin20[13] = {0.0f, 0.3090169943749474f, 0.5877852522924731f, 0.8090169943749475f, 0.9510565162951535f, 1.0f, 0.9510565162951536f, 0.8090169943749475f, 0.5877852522924732f, 0.3090169943749475f, 1.2246467991473532e-16f, -0.3090169943749469f, -0.587785252292473f};
 __device__ constexpr float kCos9[5] = {1.f, 0.76604444311897801f, 0.17364817766693041f, -0.5f, -0.93969262078590832f};
 __device__ constexpr float kSin9[5] = {0.f, 0.64278760968653925f, 0.98480775301220802f, 0.86602540378443871f, 0.34202014332566888f};
 
@@ -75,8 +79,8 @@ __device__ inline float2 mul_c(float2 x) {
   if constexpr (K == 0) {
     return x;
   } else {
-    constexpr float c = N == 25 ? kCos25[K] : N == 10 ? kCos10[K] : kCos9[K];
-    constexpr float sn = N == 25 ? kSin25[K] : N == 10 ? kSin10[K] : kSin9[K];
+    constexpr float c = N == 25 ? kCos25[K] : N == 20 ? kCos20[K] : N == 10 ? kCos10[K] : kCos9[K];
+    constexpr float sn = N == 25 ? kSin25[K] : N == 20 ? kSin20[K] : N == 10 ? kSin10[K] : kSin9[K];
     return make_float2(x.x * c + x.y * sn, x.y * c - x.x * sn);
   }
 }
@@ -138,6 +142,8 @@ __device__ inline void dft_nat(float2 *x) {
     x[3] = make_float2(p2.x - q2.y, p2.y + q2.x);
   } else if constexpr (r == 25) {
     dft_two_step<5, 5>(x);
+  } else if constexpr (r == 20) {
+    dft_two_step<5, 4>(x);
   } else if constexpr (r == 10) {
     dft_two_step<5, 2>(x);
   } else if constexpr (r == 9) {
@@ -339,14 +345,18 @@ struct Mix2Geom {
   static constexpr int R = RA * RB;
   static constexpr int tmax() { int t = 1; while (2 * t * R <= 4096 && 2 * t <= 256) t *= 2; return t; }
   static constexpr int TM = tmax();                       // widest tile (columns, a power of two)
-  static constexpr int CA = (RB * TM + 255) / 256;        // step-1 slots per thread
-  static constexpr int CB = (RA * TM + 255) / 256;        // step-2 slots per thread
+  // threads per workgroup: one DFT slot per thread in the larger step when that fits 384 threads (10 x 10 with 32
+  // columns: 320 threads, every lane busy in both steps), else 256 threads with several slots each
+  static constexpr int BIG = (RA > RB ? RA : RB) * TM;
+  static constexpr int NT = BIG <= 384 ? (BIG + 63) / 64 * 64 : 256;
+  static constexpr int CA = (RB * TM + NT - 1) / NT;      // step-1 slots per thread
+  static constexpr int CB = (RA * TM + NT - 1) / NT;      // step-2 slots per thread
 };
 
 template <int RA, int RB, int MODE>
-__global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in, float2 *__restrict__ out, MixDesc d) {
+__global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float2 *__restrict__ in, float2 *__restrict__ out, MixDesc d) {
   using G = Mix2Geom<RA, RB>;
-  constexpr int R = G::R, CA = G::CA, CB = G::CB;
+  constexpr int R = G::R, CA = G::CA, CB = G::CB, NT = G::NT;
   extern __shared__ float2 sm[];
   const int logT = d.logT, T = 1 << logT, TP = T + 1;
   const int SA = (RB << logT) + (T < 32 ? T : 0);  // pitch of one ka plane of the exchange buffer
@@ -357,49 +367,50 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
   const int tid = threadIdx.x;
   const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
   if (RB > 1)
-    for (int e = tid; e < R; e += 256) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
+    for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
   const unsigned bid = blockIdx.x;
   const int n1 = RB << logT, n2 = RA << logT;  // DFT slots of step 1 / step 2
 
   float2 v[CA * RA > CB * RB ? CA * RA : CB * RB];
-  float2 tw[MODE == FFT_STRIDED ? CB * RB : 1];
   size_t base = 0, tbase = 0;
-  unsigned col0 = 0, a = 0, kt = 0, arest = 0;
+  unsigned col0 = 0, a = 0, kt = 0, arest = 0, Ka = 0;
   if (MODE == FFT_STRIDED) {
     const unsigned tile = bid % d.tiles;
     a = (bid / d.tiles) % d.A;
     const unsigned b = bid / (d.tiles * d.A);
     col0 = tile << logT;
     base = (size_t)b * d.N + (size_t)a * R * d.B + col0;
+    if (d.src_mode == SRC_C2C) {  // (decided once: the loader switch inside the unrolled loads costs code and SALU)
 #pragma unroll
-    for (int q = 0; q < CA; ++q) {
-      const int s = tid + 256 * q;
-      const int t = s & (T - 1), j0 = s >> logT;
-      const bool ok = s < n1 && col0 + (unsigned)t < d.B;
+      for (int q = 0; q < CA; ++q) {
+        const int s = tid + NT * q;
+        const int t = s & (T - 1), j0 = s >> logT;
+        const bool ok = s < n1 && col0 + (unsigned)t < d.B;
+        const float2 *src = in + base + (size_t)j0 * d.B + t;
 #pragma unroll
-      for (int m = 0; m < RA; ++m)
-        v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
-                           : make_float2(0.f, 0.f);
+        for (int m = 0; m < RA; ++m) v[q * RA + m] = ok ? conj_if(src[(size_t)(RB * m) * d.B], smask) : make_float2(0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CA; ++q) {
+        const int s = tid + NT * q;
+        const int t = s & (T - 1), j0 = s >> logT;
+        const bool ok = s < n1 && col0 + (unsigned)t < d.B;
+#pragma unroll
+        for (int m = 0; m < RA; ++m)
+          v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
+                             : make_float2(0.f, 0.f);
+      }
     }
-    // inter-pass twiddles of this thread's outputs, evaluated under the latency of the loads just issued; when the
-    // whole tile lies inside one n_{i+1} they depend on the output frequency only and the workgroup evaluates its
-    // R values once into LDS
-    const unsigned Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
+    // inter-pass twiddles: when the whole tile lies inside one n_{i+1} they depend on the output frequency only and
+    // the workgroup evaluates its R values once into LDS (under the latency of the loads just issued); otherwise
+    // every output evaluates its own while storing -- holding them in registers from here on cost 40 VGPRs and a
+    // third of the resident wavefronts
+    Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
     tw_shared = (d.Bnext & (unsigned)(T - 1)) == 0;  // T divides Bnext: tiles never straddle
     if (tw_shared) {
       const unsigned nnext = col0 / d.Bnext;
-      for (int k = tid; k < R; k += 256) twK[k] = tw_q32(phase_q32(nnext * (Ka + (unsigned)k * d.Pprev), d.ntw_hi, d.ntw_lo));
-    } else {
-#pragma unroll
-      for (int q = 0; q < CB; ++q) {
-        const int s = min(tid + 256 * q, n2 - 1);
-        const unsigned col = col0 + (unsigned)(s & (T - 1));
-        const unsigned nnext = col / d.Bnext;
-        const unsigned ka = (unsigned)(s >> logT);
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-          tw[q * RB + i] = tw_q32(phase_q32(nnext * (Ka + (ka + RA * i) * d.Pprev), d.ntw_hi, d.ntw_lo));
-      }
+      for (int k = tid; k < R; k += NT) twK[k] = tw_q32(phase_q32(nnext * (Ka + (unsigned)k * d.Pprev), d.ntw_hi, d.ntw_lo));
     }
   } else {
     kt = bid % d.k1tiles;
@@ -407,18 +418,18 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
     tbase = (size_t)(bid / (d.k1tiles * d.Aprime)) * d.N;
     const int work = R << logT;
     const float invR = 1.0f / (float)R;
-    constexpr int NL = (R * G::TM + 255) / 256;  // staged elements per thread
+    constexpr int NL = (R * G::TM + NT - 1) / NT;  // staged elements per thread
     float2 w[NL];
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-      const int e = min(tid + 256 * u, work - 1);
+      const int e = min(tid + NT * u, work - 1);
       const int t = (int)(((float)e + 0.5f) * invR), j = e - t * R;  // e < 2^13: exact
       const unsigned k1 = (kt << logT) + (unsigned)t;
       w[u] = k1 < d.R1 ? in[tbase + ((size_t)k1 * d.Aprime + arest) * R + j] : make_float2(0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-      const int e = tid + 256 * u;
+      const int e = tid + NT * u;
       if (e < work) {
         const int t = (int)(((float)e + 0.5f) * invR), j = e - t * R;
         buf[j * TP + t] = conj_if(w[u], smask);
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < CA; ++q) {
-      const int s = min(tid + 256 * q, n1 - 1);
+      const int s = min(tid + NT * q, n1 - 1);
       const int t = s & (T - 1), j0 = s >> logT;
 #pragma unroll
       for (int m = 0; m < RA; ++m) v[q * RA + m] = buf[(j0 + RB * m) * TP + t];
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
   if (RB > 1) {
 #pragma unroll
     for (int q = 0; q < CA; ++q) {
-      const int s = tid + 256 * q;
+      const int s = tid + NT * q;
       const int j0 = s >> logT;
       if (s < n1) {
 #pragma unroll
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
     // ---- step 2: RB-point DFTs over j0 ----
 #pragma unroll
     for (int q = 0; q < CB; ++q) {
-      const int s = min(tid + 256 * q, n2 - 1);
+      const int s = min(tid + NT * q, n2 - 1);
       const int t = s & (T - 1), ka = s >> logT;
 #pragma unroll
       for (int j0 = 0; j0 < RB; ++j0) v[q * RB + j0] = buf[ka * SA + (j0 << logT) + t];
@@ -470,13 +481,24 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
   if (MODE == FFT_STRIDED) {
 #pragma unroll
     for (int q = 0; q < CO; ++q) {
-      const int s = tid + 256 * q;
+      const int s = tid + NT * q;
       const int t = s & (T - 1);
       if (s < no && col0 + (unsigned)t < d.B) {
+        float2 *dst = out + base + t;
+        if (tw_shared) {
 #pragma unroll
-        for (int i = 0; i < RO; ++i) {
-          const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
-          out[base + (size_t)k * d.B + t] = conj_if(cmul(v[q * RO + i], tw_shared ? twK[k] : tw[RB > 1 ? q * RB + i : 0]), smask);
+          for (int i = 0; i < RO; ++i) {
+            const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+            dst[(size_t)k * d.B] = conj_if(cmul(v[q * RO + i], twK[k]), smask);
+          }
+        } else {
+          const unsigned nnext = d.Bnext == 1 ? col0 + (unsigned)t : (col0 + (unsigned)t) / d.Bnext;
+          const unsigned e0 = nnext * Ka, est = nnext * d.Pprev;  // exponent of output k: nnext*(Ka + k*Pprev) < N
+#pragma unroll
+          for (int i = 0; i < RO; ++i) {
+            const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+            dst[(size_t)k * d.B] = conj_if(cmul(v[q * RO + i], tw_q32(phase_q32(e0 + (unsigned)k * est, d.ntw_hi, d.ntw_lo))), smask);
+          }
         }
       }
     }
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
     const unsigned Kp = digit_swap_g(arest, d.nprev - 1, d.Rprev + 1, d.Wprev + 1);
 #pragma unroll
     for (int q = 0; q < CO; ++q) {
-      const int s = tid + 256 * q;
+      const int s = tid + NT * q;
       const int t = s & (T - 1);
       const unsigned k1 = (kt << logT) + (unsigned)t;
       if (s < no && k1 < d.R1) {
@@ -502,11 +524,14 @@ __global__ __launch_bounds__(256) void k_fft_mix2(const float2 *__restrict__ in,
 }
 
 typedef void (*mix2_fn)(const float2 *, float2 *, MixDesc);
-struct Mix2Entry { unsigned R, RA; int tm; mix2_fn strided, last; };
+struct Mix2Entry { unsigned R, RA; int tm, nt; mix2_fn strided, last; };
 #define MIX2(RA_, RB_)                                                                                     \
-  { RA_ * RB_, RA_, Mix2Geom<RA_, RB_>::TM, k_fft_mix2<RA_, RB_, FFT_STRIDED>, k_fft_mix2<RA_, RB_, FFT_LAST> }
-// the factor sizes that have a two-step kernel (RB > 1 everywhere: the twiddle array is indexed per output)
+  { RA_ * RB_, RA_, Mix2Geom<RA_, RB_>::TM, Mix2Geom<RA_, RB_>::NT, k_fft_mix2<RA_, RB_, FFT_STRIDED>, k_fft_mix2<RA_, RB_, FFT_LAST> }
+// the factor sizes that have a two-step kernel (RB > 1 everywhere); for a size listed twice the first entry wins.
+// The balanced splits come first: with RA ~ RB one thread owns one DFT of each step and nobody idles, and 10- or
+// 16-point register DFTs keep the kernel near 64 VGPRs; 25 x 5 leaves 3 of 8 lanes without a step-1 DFT at 160 VGPRs.
 static const Mix2Entry kMix2[] = {
+    MIX2(10, 10), MIX2(10, 20), MIX2(10, 5),
     MIX2(16, 16), MIX2(16, 10), MIX2(16, 9), MIX2(16, 8), MIX2(16, 5), MIX2(25, 10), MIX2(25, 9), MIX2(25, 8),
     MIX2(25, 5),  MIX2(25, 4),  MIX2(25, 3), MIX2(25, 2), MIX2(10, 9), MIX2(9, 9),   MIX2(9, 8),  MIX2(9, 5),
     MIX2(8, 8),   MIX2(8, 5),   MIX2(5, 5),
@@ -544,49 +569,112 @@ static void stage_radices(unsigned e2, unsigned e3, unsigned e5, std::vector<uns
   if (e2 == 1) out.push_back(2);
 }
 
-// true when N = 2^a 3^b 5^c (N >= 2) and a pass split with every factor <= 256 exists
-bool fft_mixed_plan(size_t N, MixPlan *plan) {
+// What one pass through a factor costs relative to the best kernels (every pass moves the same 16 bytes per point;
+// measured on MI355X at 2e6..2e7 points): balanced two-step kernels 1, the 25 x n ones ~1.6, the generic LDS-stage
+// kernel ~2.2.
+static double factor_cost(unsigned R) {
+  const Mix2Entry *e = mix2_lookup(R);
+  if (!e) return 2.2;
+  return e->RA == 25 ? 1.6 : 1.0;
+}
+
+struct PlanSearch {
+  unsigned ex[3];
+  int best_p = 0;
+  double best = 1e30;
+  unsigned cur[MIX_MAX_PASS][3], out[MIX_MAX_PASS][3];
+  static unsigned val(const unsigned *e) {
+    unsigned v = 1;
+    for (unsigned i = 0; i < e[0]; ++i) v *= 2;
+    for (unsigned i = 0; i < e[1]; ++i) v *= 3;
+    for (unsigned i = 0; i < e[2]; ++i) v *= 5;
+    return v;
+  }
+  // factors in non-increasing order (the order is fixed afterwards), depth-first with a cost bound
+  void go(int depth, unsigned cap, double cost) {
+    if (!(ex[0] | ex[1] | ex[2])) {
+      // ties: prefer a factor carrying 2^4 (it goes last: every stride a multiple of 16 elements)
+      unsigned m2 = 0;
+      for (int i = 0; i < depth; ++i) m2 = std::max(m2, std::min(cur[i][0], 4u));
+      const double c = cost - 0.01 * m2;
+      if (c < best - 1e-9) {
+        best = c;
+        best_p = depth;
+        for (int i = 0; i < depth; ++i) for (int j = 0; j < 3; ++j) out[i][j] = cur[i][j];
+      }
+      return;
+    }
+    if (depth == MIX_MAX_PASS) return;
+    {
+      double rem = 1.0;
+      for (unsigned i = 0; i < ex[0]; ++i) rem *= 2;
+      for (unsigned i = 0; i < ex[1]; ++i) rem *= 3;
+      for (unsigned i = 0; i < ex[2]; ++i) rem *= 5;
+      const double need = std::max(1.0, std::ceil(std::log(rem) / std::log((double)cap) - 1e-9));  // passes still to come
+      if (depth + (int)need > MIX_MAX_PASS || cost + need >= best + 0.05) return;
+    }
+    for (unsigned a = 0; a <= ex[0]; ++a)
+      for (unsigned b = 0; b <= ex[1]; ++b)
+        for (unsigned c = 0; c <= ex[2]; ++c) {
+          const unsigned e[3] = {a, b, c};
+          if (a > 8 || b > 5 || c > 3) continue;
+          const unsigned R = val(e);
+          if (R < 2 || R > cap || R > 256) continue;
+          std::vector<unsigned char> rad;
+          stage_radices(a, b, c, rad);
+          if (rad.size() > MIX_MAX_STAGE) continue;
+          for (int j = 0; j < 3; ++j) { cur[depth][j] = e[j]; ex[j] -= e[j]; }
+          go(depth + 1, R, cost + factor_cost(R));
+          for (int j = 0; j < 3; ++j) ex[j] += e[j];
+        }
+  }
+};
+
+// true when N = 2^a 3^b 5^c (N >= 2) and a pass split with every factor <= 256 exists.  The split minimises the
+// summed pass costs above; the factor with the most twos goes last, the others largest first.
+static bool fft_mixed_plan_search(size_t N, MixPlan *plan);
+bool fft_mixed_plan(size_t N, MixPlan *plan) {  // the search runs once per length
+  static std::mutex mu;
+  static std::unordered_map<size_t, std::pair<bool, MixPlan>> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find(N);
+  if (it == cache.end()) {
+    if (cache.size() > 4096) cache.clear();
+    MixPlan pl;
+    const bool ok = fft_mixed_plan_search(N, &pl);
+    it = cache.emplace(N, std::make_pair(ok, pl)).first;
+  }
+  if (it->second.first) *plan = it->second.second;
+  return it->second.first;
+}
+static bool fft_mixed_plan_search(size_t N, MixPlan *plan) {
   if (N < 2 || N >= (size_t(1) << 31)) return false;
-  unsigned ex[3] = {0, 0, 0};
+  PlanSearch ps;
+  ps.ex[0] = ps.ex[1] = ps.ex[2] = 0;
   const unsigned pr[3] = {2, 3, 5};
   size_t m = N;
   for (int i = 0; i < 3; ++i)
-    while (m % pr[i] == 0) { m /= pr[i]; ++ex[i]; }
+    while (m % pr[i] == 0) { m /= pr[i]; ++ps.ex[i]; }
   if (m != 1) return false;
-  const int pmin = std::max(1, (int)std::ceil(std::log((double)N) / std::log(256.0) - 1e-9));
-  for (int p = pmin; p <= MIX_MAX_PASS; ++p) {
-    unsigned prod[MIX_MAX_PASS], e[MIX_MAX_PASS][3];
-    for (int i = 0; i < p; ++i) { prod[i] = 1; e[i][0] = e[i][1] = e[i][2] = 0; }
-    unsigned left[3] = {ex[0], ex[1], ex[2]};
-    // the last factor takes up to four 2s first, so that every stride is a multiple of 16 elements
-    if (p > 1) {
-      const unsigned k = std::min(left[0], 4u);
-      prod[p - 1] <<= k;
-      e[p - 1][0] = k;
-      left[0] -= k;
-    }
-    bool ok = true;
-    for (int pi = 2; pi >= 0 && ok; --pi) {  // 5s, then 3s, then 2s: each into the smallest factor so far
-      while (left[pi] && ok) {
-        int best = -1;
-        for (int i = 0; i < p; ++i)
-          if (prod[i] * pr[pi] <= 256 && (best < 0 || prod[i] < prod[best])) best = i;
-        if (best < 0) { ok = false; break; }
-        prod[best] *= pr[pi];
-        ++e[best][pi];
-        --left[pi];
-      }
-    }
-    if (!ok) continue;
-    plan->p = p;
-    for (int i = 0; i < p; ++i) {
-      plan->R[i] = prod[i];
-      stage_radices(e[i][0], e[i][1], e[i][2], plan->rad[i]);
-      if (plan->rad[i].size() > MIX_MAX_STAGE) { ok = false; break; }
-    }
-    if (ok) return true;
+  ps.go(0, 256, 0.0);
+  if (!ps.best_p) return false;
+  const int p = ps.best_p;
+  int last = 0;
+  for (int i = 1; i < p; ++i) {
+    const unsigned ti = std::min(ps.out[i][0], 4u), tl = std::min(ps.out[last][0], 4u);
+    if (ti > tl || (ti == tl && PlanSearch::val(ps.out[i]) > PlanSearch::val(ps.out[last]))) last = i;
   }
-  return false;
+  plan->p = p;
+  int o = 0;
+  for (int i = 0; i < p; ++i) {
+    if (i == last) continue;
+    plan->R[o] = PlanSearch::val(ps.out[i]);
+    stage_radices(ps.out[i][0], ps.out[i][1], ps.out[i][2], plan->rad[o]);
+    ++o;
+  }
+  plan->R[o] = PlanSearch::val(ps.out[last]);
+  stage_radices(ps.out[last][0], ps.out[last][1], ps.out[last][2], plan->rad[o]);
+  return true;
 }
 
 bool fft_mixed_ok(size_t N) {
@@ -679,7 +767,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     const size_t grid = batch * d.A * d.tiles;
     if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
     if (m2) {
-      TSDR_LAUNCH(ctx, kStridedName[i], m2->strided, dim3((unsigned)grid), dim3(256), mix2_lds(d.R, m2->RA, d.logT), src, work, d);
+      TSDR_LAUNCH(ctx, kStridedName[i], m2->strided, dim3((unsigned)grid), dim3(m2->nt), mix2_lds(d.R, m2->RA, d.logT), src, work, d);
     } else {
       TSDR_LAUNCH(ctx, kStridedName[i], k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), src, work, d);
     }
@@ -705,7 +793,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   const size_t grid = batch * d.Aprime * d.k1tiles;
   if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
   if (m2) {
-    TSDR_LAUNCH(ctx, "fftm_last", m2->last, dim3((unsigned)grid), dim3(256), mix2_lds(d.R, m2->RA, d.logT), (const float2 *)work, out, d);
+    TSDR_LAUNCH(ctx, "fftm_last", m2->last, dim3((unsigned)grid), dim3(m2->nt), mix2_lds(d.R, m2->RA, d.logT), (const float2 *)work, out, d);
   } else {
     TSDR_LAUNCH(ctx, "fftm_last", k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), (const float2 *)work, out, d);
   }
