@@ -25,7 +25,7 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
              size_t src_n, size_t keep);
 bool fft_mixed_ok(size_t N);
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep);
+              size_t src_n, size_t keep, const FftEpilogue *epi = nullptr);
 int get_tw(tsdr_ctx *ctx, int logN, TwTable **out);
 
 __device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -182,15 +182,24 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
     float2 *z = (float2 *)ctx->scratch(WS_FFT_A, Mc * sizeof(float2));
     float2 *Z = (float2 *)ctx->scratch(WS_FFT_C, Mc * sizeof(float2));
     if (!z || !Z) return TSDR_ENOMEM;
-    auto fft = [&](const float2 *src, float2 *dst, int dir, float scale, int src_mode, size_t keep) {
-      return half_pow2 ? fft_pow2(ctx, src, dst, ilog2(Mc), 1, dir, scale, src_mode, n, keep)
-                       : fft_mixed(ctx, src, dst, Mc, 1, dir, scale, src_mode, n, keep);
-    };
-    int rc = fft(reinterpret_cast<const float2 *>(x), Z, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, 0);
+    if (!half_pow2) {
+      // mixed-radix route, three fusions: the first forward pass forms abs2 and packs; the first inverse pass forms the
+      // packed power spectrum from Z while loading (no k_ac_power round trip); the last inverse pass writes
+      // abs2 / 10log10 of the wanted lags straight to `out` (no k_ac_finish round trip)
+      int rc = fft_mixed(ctx, reinterpret_cast<const float2 *>(x), Z, Mc, 1, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, n, 0);
+      if (rc) return rc;
+      FftEpilogue epi;
+      epi.out = out;
+      epi.k0 = k0;
+      epi.cnt = cnt;
+      epi.log_scale = log_scale;
+      return fft_mixed(ctx, Z, z, Mc, 1, +1, (float)(0.5 / (double)Mc), SRC_POWER, Mc, (k0 + cnt + 1) / 2, &epi);
+    }
+    int rc = fft_pow2(ctx, reinterpret_cast<const float2 *>(x), Z, ilog2(Mc), 1, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, n, 0);
     if (rc) return rc;
     TSDR_LAUNCH(ctx, "ac_power", k_ac_power, dim3(stream_grid(ctx, Mc / 2 + 1)), dim3(256), 0, Z, Mc, (const float2 *)nullptr,
                 (const float2 *)nullptr, 0, 4.0 / (double)Mc);
-    rc = fft(Z, z, +1, (float)(0.5 / (double)Mc), SRC_C2C, (k0 + cnt + 1) / 2);
+    rc = fft_pow2(ctx, Z, z, ilog2(Mc), 1, +1, (float)(0.5 / (double)Mc), SRC_C2C, n, (k0 + cnt + 1) / 2);
     if (rc) return rc;
     TSDR_LAUNCH(ctx, "ac_finish", k_ac_finish, dim3(stream_grid(ctx, cnt)), dim3(256), 0, reinterpret_cast<const float *>(z),
                 k0, cnt, log_scale, out);

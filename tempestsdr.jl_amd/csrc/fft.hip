@@ -419,7 +419,7 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
 
 bool fft_mixed_ok(size_t N);
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep);
+              size_t src_n, size_t keep, const FftEpilogue *epi = nullptr);
 
 // ---- Bluestein ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chirp(float2 *__restrict__ chirp, unsigned long long n) {

@@ -110,13 +110,17 @@ __device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000
 //   SRC_C2C   in[g]
 //   SRC_REAL  (x[2g], x[2g+1])            real f32 sequence of src_n samples packed two per complex, zero beyond
 //   SRC_IQPOW (|iq[2g]|^2, |iq[2g+1]|^2)  the same with x = abs2.(iq) formed on the fly (GUI.jl:70)
-//   SRC_POWER Y[g] of the autocorrelation: `in` = Z, the length-src_n (a power of two) transform of a packed real
+//   SRC_POWER Y[g] of the autocorrelation: `in` = Z, the length-src_n transform of a packed real
 //             sequence; Y is the packed spectrum whose inverse transform (times 1/2) is the real sequence with
 //             spectrum |X|^2 (see k_ac_power, which this loader replaces: one launch and a 2 x 8*Mc-byte round
 //             trip less)
 enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2, SRC_POWER = 3 };
 
-__device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g) {
+// tw_frac below (needed by the SRC_POWER loader when M = 2*Mc is not a power of two)
+__device__ inline float2 tw_frac(unsigned e, double inv_n8);
+
+__device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g,
+                                  double inv_m8 = 0.0) {
   if (src_mode == SRC_C2C) return in[g];
   if (src_mode == SRC_POWER) {
     const size_t Mc = (size_t)src_n;
@@ -124,7 +128,8 @@ __device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, u
     const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
     const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));  // (Z[g] - conj Z[Mc-g]) / 2
     const float2 O = make_float2(D.y, -D.x);                                // -i*D
-    const float2 W = tw_unit((unsigned)g, 64 - __clzll((unsigned long long)Mc));  // W_M^g, M = 2*Mc
+    // W_M^g, M = 2*Mc: exact octant split for a power of two, f64 phase (inv_m8 = 8/M) otherwise
+    const float2 W = inv_m8 == 0.0 ? tw_unit((unsigned)g, 64 - __clzll((unsigned long long)Mc)) : tw_frac((unsigned)g, inv_m8);
     const float2 WO = cmul(W, O);
     const float2 X0 = make_float2(E.x + WO.x, E.y + WO.y), X1 = make_float2(E.x - WO.x, E.y - WO.y);
     const float P0 = X0.x * X0.x + X0.y * X0.y, P1 = X1.x * X1.x + X1.y * X1.y;
@@ -149,6 +154,19 @@ __device__ inline float2 tw_frac(unsigned e, double inv_n8) {
   const double f = ph - (double)o;
   const float x = (float)((o & 1u) ? 1.0 - f : f);
   return tw_octant(o & 7u, x);
+}
+
+// Epilogue of the last pass for the autocorrelation (Autocorrelations.jl:33-36): the complex output o holds the real
+// lags (2o, 2o+1); lags k0 <= k < k0+cnt leave as abs2 (and 10log10) in f32 -- k_ac_finish without the round trip.
+struct FftEpilogue {
+  float *out = nullptr;
+  unsigned long long k0 = 0, cnt = 0;
+  int log_scale = 0;
+};
+__device__ inline void epilogue_store(const FftEpilogue &e, size_t o, float2 x) {
+  const unsigned long long i0 = 2ull * o - e.k0, i1 = i0 + 1ull;  // (wraps to huge when below k0)
+  if (i0 < e.cnt) { const float p = x.x * x.x; e.out[i0] = e.log_scale ? 10.0f * log10f(p) : p; }
+  if (i1 < e.cnt) { const float p = x.y * x.y; e.out[i1] = e.log_scale ? 10.0f * log10f(p) : p; }
 }
 
 }  // namespace tsdr

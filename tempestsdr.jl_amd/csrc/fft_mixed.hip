@@ -45,6 +45,8 @@ struct MixDesc {
   unsigned rows;                     // rows mode: number of transforms
   int src_mode;
   unsigned long long src_n, keep;
+  double src_w8;                     // SRC_POWER with M = 2*src_n not a power of two: 8/M (else 0)
+  FftEpilogue epi;                   // last pass: autocorrelation epilogue when epi.out != nullptr
 };
 
 // a = k_1*(R_2..R_m) + ... + k_m  ->  k_1*W_1 + ... + k_m*W_m  (uniform per workgroup: scalar code)
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
       for (int u = 0; u < NB; ++u) {
         const unsigned w = w0 + 256 * u;
         const unsigned t = w & (T - 1u), j = w >> logT;
-        v[u] = (w < work && col0 + t < d.B) ? fft_load(in, d.src_mode, d.src_n, base + (size_t)j * d.B + t)
+        v[u] = (w < work && col0 + t < d.B) ? fft_load(in, d.src_mode, d.src_n, base + (size_t)j * d.B + t, d.src_w8)
                                              : make_float2(0.f, 0.f);
       }
 #pragma unroll
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
         const size_t o = orel + (size_t)k * d.Pprev;
         if (o < d.keep) {
           const float2 x = buf[p * TP + t];
-          out[tbase + o] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+          const float2 y = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+          if (d.epi.out) epilogue_store(d.epi, o, y); else out[tbase + o] = y;
         }
       }
     }
@@ -398,7 +401,7 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
         const bool ok = s < n1 && col0 + (unsigned)t < d.B;
 #pragma unroll
         for (int m = 0; m < RA; ++m)
-          v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
+          v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t, d.src_w8), smask)
                              : make_float2(0.f, 0.f);
       }
     }
@@ -516,7 +519,10 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
           const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
           const size_t o = orel + (size_t)k * d.Pprev;
           const float2 x = v[q * RO + i];
-          if (o < d.keep) out[tbase + o] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+          if (o < d.keep) {
+            const float2 y = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+            if (d.epi.out) epilogue_store(d.epi, o, y); else out[tbase + o] = y;
+          }
         }
       }
     }
@@ -702,7 +708,7 @@ static size_t mix_lds(unsigned R, int logT) {
 // src_mode/src_n: fused first-pass loader (fft_dev.h), batch == 1 and p > 1 only; keep: complex outputs per
 // transform the caller will look at (0 = all).
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep) {
+              size_t src_n, size_t keep, const FftEpilogue *epi) {
   MixPlan pl;
   if (!fft_mixed_plan(N, &pl)) return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
   if (batch == 0) return TSDR_OK;
@@ -714,6 +720,8 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   d.N = N;
   d.src_mode = SRC_C2C;
   d.keep = keep ? keep : N;
+  d.src_w8 = src_mode == SRC_POWER && !is_pow2(src_n) ? 4.0 / (double)src_n : 0.0;
+  if (epi && (batch != 1 || p == 1)) return set_err(ctx, TSDR_EINVAL, "fft: epilogue needs one multi-pass transform");
   auto set_radix = [&](int i) {
     d.R = pl.R[i];
     d.nst = (int)pl.rad[i].size();
@@ -777,6 +785,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   set_radix(p - 1);
   d.mode = FFT_LAST;
   d.src_mode = SRC_C2C;
+  if (epi) d.epi = *epi;
   d.R1 = pl.R[0];
   const Mix2Entry *m2 = ctx->opt_fft_no_mix2 ? nullptr : mix2_lookup(d.R);
   d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2(d.R1)}), m2 ? 8 : 4,
