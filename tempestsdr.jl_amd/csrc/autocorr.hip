@@ -142,9 +142,11 @@ __device__ inline unsigned long long argmax_key(float v, unsigned idx) {
 }
 
 // `key` must be zero on entry; `clear` (the slot the next launch will use) is zeroed here, so no memset launch
-// separates two searches
+// separates two searches.  The last workgroup to arrive writes the winning key into pinned host memory itself: no
+// copy launch between the kernel and the host's stream synchronisation.
 __global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, size_t n, unsigned long long *__restrict__ key,
-                                                unsigned long long *__restrict__ clear) {
+                                                unsigned long long *__restrict__ clear, unsigned *__restrict__ arrived,
+                                                unsigned long long *__restrict__ host_out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0ull;
   unsigned long long best = 0ull;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -163,6 +165,12 @@ __global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, siz
     unsigned long long b = wbest[0];
     for (int i = 1; i < 4; ++i) b = wbest[i] > b ? wbest[i] : b;
     atomicMax(key, b);
+    __threadfence();
+    if (atomicAdd(arrived, 1u) == gridDim.x - 1u) {
+      *arrived = 0u;
+      *host_out = atomicMax(key, 0ull);  // (an atomic read: every workgroup's maximum is in)
+      __threadfence_system();
+    }
   }
 }
 
@@ -333,17 +341,18 @@ int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *v
   if (!ctx || !v || !idx || n == 0) return TSDR_EINVAL;  // findmax of an empty collection throws
   if (n >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "argmax: vector too long");
   if (!ctx->amax_keys) {
-    TSDR_HIP(ctx, hipMalloc((void **)&ctx->amax_keys, 16));
-    TSDR_HIP(ctx, hipMemset(ctx->amax_keys, 0, 16));
+    TSDR_HIP(ctx, hipMalloc((void **)&ctx->amax_keys, 32));  // two key slots + the arrival counter
+    TSDR_HIP(ctx, hipMemset(ctx->amax_keys, 0, 32));
     TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->amax_host, 64, hipHostMallocDefault));
+    TSDR_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->amax_host_dev, ctx->amax_host, 0));
     ctx->amax_slot = 0;
   }
   unsigned long long *key = ctx->amax_keys + ctx->amax_slot, *other = ctx->amax_keys + (ctx->amax_slot ^ 1);
   ctx->amax_slot ^= 1;
   const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
-  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key, other);
-  // one pinned-memory DMA and one synchronisation; the value rides in the key's upper half (NaN canonicalised)
-  TSDR_HIP(ctx, hipMemcpyAsync(ctx->amax_host, key, 8, hipMemcpyDeviceToHost, ctx->stream));
+  // the value rides in the key's upper half (NaN canonicalised); the kernel delivers the key to pinned memory
+  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key, other, reinterpret_cast<unsigned *>(ctx->amax_keys + 2),
+              ctx->amax_host_dev);
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const unsigned long long h = *ctx->amax_host;
   *idx = (size_t)(0xFFFFFFFFu - (unsigned)(h & 0xFFFFFFFFull));

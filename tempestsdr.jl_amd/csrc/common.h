@@ -72,9 +72,10 @@ struct tsdr_ctx {
   // FFT state
   float2 *tw_small = nullptr;  // W_4096^e, e < 4096
   std::map<int, tsdr::TwTable> tw;
+  std::map<unsigned, float2 *> twg;  // mixed-radix FFT: W_{R*Rn}^(col*k) tables of the last strided pass, key R << 16 | Rn
   std::map<size_t, tsdr::BluesteinPlan> blu;
   // tsdr_argmax_d: two device key slots (each launch clears the other one) and a pinned host word for the readback
-  unsigned long long *amax_keys = nullptr, *amax_host = nullptr;
+  unsigned long long *amax_keys = nullptr, *amax_host = nullptr, *amax_host_dev = nullptr;
   int amax_slot = 0;
   // software-pipelined frame loop (tsdr_frames_submit_d)
   unsigned long long pipe_n = 0;  // submissions since the last flush point

@@ -140,6 +140,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
+  for (auto &kv : ctx->twg) (void)hipFree(kv.second);
   for (auto &kv : ctx->blu) { (void)hipFree(kv.second.chirp); (void)hipFree(kv.second.bfft); }
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

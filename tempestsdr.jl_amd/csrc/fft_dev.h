@@ -8,7 +8,10 @@ namespace tsdr {
 
 enum { FFT_STRIDED = 0, FFT_LAST = 1, FFT_ROWS = 2 };
 
-__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// (explicit FMAs: the library is built with -ffp-contract=off for the bit-exact kernels, and the passes are VALU-bound)
+__device__ inline float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
 __device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ inline float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
@@ -32,7 +35,7 @@ __device__ inline float2 mul_w(float2 d) {  // d * exp(-2*pi*i*I/N), 0 <= I < N/
   } else if constexpr (E == 6) {
     return make_float2((d.y - d.x) * kCos16[2], -(d.x + d.y) * kCos16[2]);
   } else {
-    return make_float2(d.x * kCos16[E] + d.y * kSin16[E], d.y * kCos16[E] - d.x * kSin16[E]);
+    return make_float2(fmaf(d.x, kCos16[E], d.y * kSin16[E]), fmaf(d.y, kCos16[E], -(d.x * kSin16[E])));
   }
 }
 

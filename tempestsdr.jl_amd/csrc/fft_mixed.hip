@@ -45,6 +45,8 @@ struct MixDesc {
   unsigned rows;                     // rows mode: number of transforms
   int src_mode;
   unsigned long long src_n, keep;
+  int tw_sets;                       // strided, two-step kernels: inter-pass twiddle sets held in LDS (0: none)
+  const float2 *twg;                 // strided, Bnext == 1: W_{R*Rnext}^(col*k) at [k * B + col] (else nullptr)
   double src_w8;                     // SRC_POWER with M = 2*src_n not a power of two: 8/M (else 0)
   FftEpilogue epi;                   // last pass: autocorrelation epilogue when epi.out != nullptr
 };
@@ -83,7 +85,7 @@ __device__ inline float2 mul_c(float2 x) {
   } else {
     constexpr float c = N == 25 ? kCos25[K] : N == 20 ? kCos20[K] : N == 10 ? kCos10[K] : kCos9[K];
     constexpr float sn = N == 25 ? kSin25[K] : N == 20 ? kSin20[K] : N == 10 ? kSin10[K] : kSin9[K];
-    return make_float2(x.x * c + x.y * sn, x.y * c - x.x * sn);
+    return make_float2(fmaf(x.x, c, x.y * sn), fmaf(x.y, c, -(x.x * sn)));
   }
 }
 
@@ -124,7 +126,7 @@ __device__ inline void dft_nat(float2 *x) {
   if constexpr (r == 3) {
     const float s = 0.86602540378443865f;
     const float2 t = cadd(x[1], x[2]), d = csub(x[1], x[2]);
-    const float2 m = make_float2(x[0].x - 0.5f * t.x, x[0].y - 0.5f * t.y);
+    const float2 m = make_float2(fmaf(-0.5f, t.x, x[0].x), fmaf(-0.5f, t.y, x[0].y));
     const float2 q = make_float2(s * d.y, -s * d.x);  // -i*s*d
     x[0] = cadd(x[0], t);
     x[1] = cadd(m, q);
@@ -133,10 +135,10 @@ __device__ inline void dft_nat(float2 *x) {
     const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
     const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
     const float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]), b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
-    const float2 p1 = make_float2(x[0].x + (c1 * a1.x + c2 * a2.x), x[0].y + (c1 * a1.y + c2 * a2.y));
-    const float2 p2 = make_float2(x[0].x + (c2 * a1.x + c1 * a2.x), x[0].y + (c2 * a1.y + c1 * a2.y));
-    const float2 q1 = make_float2(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
-    const float2 q2 = make_float2(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    const float2 p1 = make_float2(x[0].x + fmaf(c1, a1.x, c2 * a2.x), x[0].y + fmaf(c1, a1.y, c2 * a2.y));
+    const float2 p2 = make_float2(x[0].x + fmaf(c2, a1.x, c1 * a2.x), x[0].y + fmaf(c2, a1.y, c1 * a2.y));
+    const float2 q1 = make_float2(fmaf(s1, b1.x, s2 * b2.x), fmaf(s1, b1.y, s2 * b2.y));
+    const float2 q2 = make_float2(fmaf(s2, b1.x, -(s1 * b2.x)), fmaf(s2, b1.y, -(s1 * b2.y)));
     x[0] = cadd(x[0], cadd(a1, a2));
     x[1] = make_float2(p1.x + q1.y, p1.y - q1.x);  // p1 - i q1
     x[4] = make_float2(p1.x - q1.y, p1.y + q1.x);
@@ -365,8 +367,7 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
   const int SA = (RB << logT) + (T < 32 ? T : 0);  // pitch of one ka plane of the exchange buffer
   float2 *buf = sm;                                // staging tile [j][TP] (LAST) and exchange buffer [ka][SA], aliased
   float2 *twR = sm + (R * TP > RA * SA ? R * TP : RA * SA);
-  float2 *twK = twR + R;  // STRIDED: per-frequency inter-pass twiddles when uniform over the tile
-  bool tw_shared = false;
+  float2 *twK = twR + R;  // STRIDED: tw_sets x R inter-pass twiddles
   const int tid = threadIdx.x;
   const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
   if (RB > 1)
@@ -376,7 +377,7 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
 
   float2 v[CA * RA > CB * RB ? CA * RA : CB * RB];
   size_t base = 0, tbase = 0;
-  unsigned col0 = 0, a = 0, kt = 0, arest = 0, Ka = 0;
+  unsigned col0 = 0, a = 0, kt = 0, arest = 0, Ka = 0, n0 = 0;
   if (MODE == FFT_STRIDED) {
     const unsigned tile = bid % d.tiles;
     a = (bid / d.tiles) % d.A;
@@ -405,15 +406,17 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
                              : make_float2(0.f, 0.f);
       }
     }
-    // inter-pass twiddles: when the whole tile lies inside one n_{i+1} they depend on the output frequency only and
-    // the workgroup evaluates its R values once into LDS (under the latency of the loads just issued); otherwise
-    // every output evaluates its own while storing -- holding them in registers from here on cost 40 VGPRs and a
-    // third of the resident wavefronts
+    // inter-pass twiddles W^(n_{i+1} (Ka + k Pprev)).  n_{i+1} = col / Bnext takes tw_sets consecutive values inside a
+    // tile (1 when T divides Bnext, 2 when a tile can straddle one boundary ...): the workgroup evaluates those
+    // tw_sets * R values once into LDS, under the latency of the loads just issued.  The last strided pass
+    // (Bnext = 1: a set per column) factors them as W^(col Ka) -- one evaluation per thread -- times the table
+    // W_{R Rnext}^(col k).  Evaluating every output's own twiddle (the fallback) costs ~30 VALU instructions each,
+    // +45 % on a pass that is VALU-bound.
     Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
-    tw_shared = (d.Bnext & (unsigned)(T - 1)) == 0;  // T divides Bnext: tiles never straddle
-    if (tw_shared) {
-      const unsigned nnext = col0 / d.Bnext;
-      for (int k = tid; k < R; k += NT) twK[k] = tw_q32(phase_q32(nnext * (Ka + (unsigned)k * d.Pprev), d.ntw_hi, d.ntw_lo));
+    n0 = col0 / d.Bnext;
+    for (int e = tid; e < d.tw_sets * R; e += NT) {
+      const unsigned set = (unsigned)e / (unsigned)R, k = (unsigned)e - set * (unsigned)R;
+      twK[e] = tw_q32(phase_q32((n0 + set) * (Ka + k * d.Pprev), d.ntw_hi, d.ntw_lo));
     }
   } else {
     kt = bid % d.k1tiles;
@@ -488,14 +491,25 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
       const int t = s & (T - 1);
       if (s < no && col0 + (unsigned)t < d.B) {
         float2 *dst = out + base + t;
-        if (tw_shared) {
+        const unsigned col = col0 + (unsigned)t;
+        if (d.tw_sets) {
+          const unsigned set = d.tw_sets == 1 ? 0u : d.tw_sets == 2 ? (col >= (n0 + 1u) * d.Bnext ? 1u : 0u) : col / d.Bnext - n0;
+          const float2 *tws = twK + set * R;
 #pragma unroll
           for (int i = 0; i < RO; ++i) {
             const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
-            dst[(size_t)k * d.B] = conj_if(cmul(v[q * RO + i], twK[k]), smask);
+            dst[(size_t)k * d.B] = conj_if(cmul(v[q * RO + i], tws[k]), smask);
+          }
+        } else if (d.twg) {
+          const float2 w1 = tw_q32(phase_q32(col * Ka, d.ntw_hi, d.ntw_lo));
+          const float2 *g = d.twg + col;
+#pragma unroll
+          for (int i = 0; i < RO; ++i) {
+            const int k = RB > 1 ? ((s >> logT) + RA * i) : i;
+            dst[(size_t)k * d.B] = conj_if(cmul(v[q * RO + i], cmul(w1, g[(size_t)k * d.B])), smask);
           }
         } else {
-          const unsigned nnext = d.Bnext == 1 ? col0 + (unsigned)t : (col0 + (unsigned)t) / d.Bnext;
+          const unsigned nnext = col / d.Bnext;
           const unsigned e0 = nnext * Ka, est = nnext * d.Pprev;  // exponent of output k: nnext*(Ka + k*Pprev) < N
 #pragma unroll
           for (int i = 0; i < RO; ++i) {
@@ -548,10 +562,10 @@ static const Mix2Entry *mix2_lookup(unsigned R) {
     if (e.R == R) return &e;
   return nullptr;
 }
-static size_t mix2_lds(unsigned R, unsigned RA, int logT) {
+static size_t mix2_lds(unsigned R, unsigned RA, int logT, int tw_sets = 1) {
   const size_t T = (size_t)1 << logT, RB = R / RA;
   const size_t SA = (RB << logT) + (T < 32 ? T : 0);
-  return (std::max((size_t)R * (T + 1), (size_t)RA * SA) + 2 * (size_t)R) * sizeof(float2);
+  return (std::max((size_t)R * (T + 1), (size_t)RA * SA) + (size_t)(1 + std::max(tw_sets, 1)) * R) * sizeof(float2);
 }
 
 // ---- planning --------------------------------------------------------------------------------
@@ -704,6 +718,26 @@ static size_t mix_lds(unsigned R, int logT) {
   return ((size_t)R * ((1u << logT) + 1) + R) * sizeof(float2) + ((size_t)R * 2 + 15) / 16 * 16;
 }
 
+// W_{R*Rn}^(col*k) at [k * Rn + col], k < R, col < Rn (built once per pair in extended precision, then resident)
+static int get_twg(tsdr_ctx *ctx, unsigned R, unsigned Rn, const float2 **out) {
+  const unsigned key = (R << 16) | Rn;
+  auto it = ctx->twg.find(key);
+  if (it != ctx->twg.end()) { *out = it->second; return TSDR_OK; }
+  std::vector<float2> h((size_t)R * Rn);
+  const unsigned long long M = (unsigned long long)R * Rn;
+  for (unsigned k = 0; k < R; ++k)
+    for (unsigned c = 0; c < Rn; ++c) {
+      const long double ang = -2.0L * M_PIl * (long double)(((unsigned long long)k * c) % M) / (long double)M;
+      h[(size_t)k * Rn + c] = make_float2((float)cosl(ang), (float)sinl(ang));
+    }
+  float2 *dev = nullptr;
+  TSDR_HIP(ctx, hipMalloc((void **)&dev, h.size() * sizeof(float2)));
+  TSDR_HIP(ctx, hipMemcpy(dev, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice));
+  ctx->twg.emplace(key, dev);
+  *out = dev;
+  return TSDR_OK;
+}
+
 // in/out may alias.  Uses WS_FFT_B when more than one pass is needed (callers must not hand WS_FFT_B buffers in).
 // src_mode/src_n: fused first-pass loader (fft_dev.h), batch == 1 and p > 1 only; keep: complex outputs per
 // transform the caller will look at (0 = all).
@@ -774,8 +808,15 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     for (int j = 0; j < i; ++j) { d.Rprev[j] = pl.R[j]; d.Wprev[j] = (unsigned)wgt; wgt *= pl.R[j]; }
     const size_t grid = batch * d.A * d.tiles;
     if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
+    d.tw_sets = 0;
+    d.twg = nullptr;
     if (m2) {
-      TSDR_LAUNCH(ctx, kStridedName[i], m2->strided, dim3((unsigned)grid), dim3(m2->nt), mix2_lds(d.R, m2->RA, d.logT), src, work, d);
+      // how the two-step kernel gets its inter-pass twiddles (see the kernel): sets in LDS, or the column table
+      const unsigned T = 1u << d.logT;
+      if (d.Bnext % T == 0) d.tw_sets = 1;
+      else if (d.Bnext == 1) { const int rc = get_twg(ctx, d.R, d.B, &d.twg); if (rc) return rc; }
+      else if ((T - 1) / d.Bnext + 2 <= 4) d.tw_sets = (int)((T - 1) / d.Bnext + 2);
+      TSDR_LAUNCH(ctx, kStridedName[i], m2->strided, dim3((unsigned)grid), dim3(m2->nt), mix2_lds(d.R, m2->RA, d.logT, d.tw_sets), src, work, d);
     } else {
       TSDR_LAUNCH(ctx, kStridedName[i], k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), src, work, d);
     }
