@@ -142,11 +142,12 @@ __device__ inline unsigned long long argmax_key(float v, unsigned idx) {
 }
 
 // `key` must be zero on entry; `clear` (the slot the next launch will use) is zeroed here, so no memset launch
-// separates two searches.  The last workgroup to arrive writes the winning key into pinned host memory itself: no
-// copy launch between the kernel and the host's stream synchronisation.
+// separates two searches.  The last workgroup to arrive writes the winning key, then a sequence number, into pinned
+// host memory: no copy launch, and the host polls the sequence word instead of sleeping in hipStreamSynchronize (whose
+// interrupt wake-up costs hundreds of microseconds once a search is longer than the runtime's spin window).
 __global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, size_t n, unsigned long long *__restrict__ key,
                                                 unsigned long long *__restrict__ clear, unsigned *__restrict__ arrived,
-                                                unsigned long long *__restrict__ host_out) {
+                                                unsigned long long *__restrict__ host_out, unsigned long long seq) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *clear = 0ull;
   unsigned long long best = 0ull;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -168,8 +169,9 @@ __global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, siz
     __threadfence();
     if (atomicAdd(arrived, 1u) == gridDim.x - 1u) {
       *arrived = 0u;
-      *host_out = atomicMax(key, 0ull);  // (an atomic read: every workgroup's maximum is in)
+      host_out[0] = atomicMax(key, 0ull);  // (an atomic read: every workgroup's maximum is in)
       __threadfence_system();
+      __hip_atomic_store(&host_out[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // the host polls this word
     }
   }
 }
@@ -343,17 +345,29 @@ int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *v
   if (!ctx->amax_keys) {
     TSDR_HIP(ctx, hipMalloc((void **)&ctx->amax_keys, 32));  // two key slots + the arrival counter
     TSDR_HIP(ctx, hipMemset(ctx->amax_keys, 0, 32));
-    TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->amax_host, 64, hipHostMallocDefault));
+    TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->amax_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset(ctx->amax_host, 0, 64);
     TSDR_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->amax_host_dev, ctx->amax_host, 0));
     ctx->amax_slot = 0;
   }
   unsigned long long *key = ctx->amax_keys + ctx->amax_slot, *other = ctx->amax_keys + (ctx->amax_slot ^ 1);
   ctx->amax_slot ^= 1;
+  const unsigned long long seq = ++ctx->amax_seq;
   const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
-  // the value rides in the key's upper half (NaN canonicalised); the kernel delivers the key to pinned memory
+  // the value rides in the key's upper half (NaN canonicalised); the kernel delivers key and sequence number
   TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key, other, reinterpret_cast<unsigned *>(ctx->amax_keys + 2),
-              ctx->amax_host_dev);
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+              ctx->amax_host_dev, seq);
+  {
+    bool seen = false;
+    for (unsigned it = 1; !seen; ++it) {
+      seen = __atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) == seq;
+      if (!seen && (it & 0xFFFu) == 0 && hipStreamQuery(ctx->launch_stream) != hipErrorNotReady) break;  // finished or failed
+    }
+    if (!seen) {
+      TSDR_HIP(ctx, hipStreamSynchronize(ctx->launch_stream));
+      if (__atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) != seq) return set_err(ctx, TSDR_EHIP, "argmax: result not delivered");
+    }
+  }
   const unsigned long long h = *ctx->amax_host;
   *idx = (size_t)(0xFFFFFFFFu - (unsigned)(h & 0xFFFFFFFFull));
   if (val) {

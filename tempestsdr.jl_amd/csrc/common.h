@@ -77,6 +77,7 @@ struct tsdr_ctx {
   // tsdr_argmax_d: two device key slots (each launch clears the other one) and a pinned host word for the readback
   unsigned long long *amax_keys = nullptr, *amax_host = nullptr, *amax_host_dev = nullptr;
   int amax_slot = 0;
+  unsigned long long amax_seq = 0;
   // software-pipelined frame loop (tsdr_frames_submit_d)
   unsigned long long pipe_n = 0;  // submissions since the last flush point
   size_t pipe_nb = 0;             // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
