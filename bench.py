@@ -223,6 +223,9 @@ def spectrum_legs(env, iq, L):
         f"getWelch(fe, sig; sizeFFT=1024), sig = one capture buffer ({L} ComplexF32, {nb} segments), dB out")
     leg("waterfall", lambda: ctx.call("tsdr_waterfall_d", p(iq), 1, L, 1024, p(wf)), 8 * L + 8 * nb * 1024, 20,
         "getWaterfall: Float64 (1024 x nbSeg) out")
+    y2 = torch.empty(1000, dtype=torch.float32, device=dev)
+    leg("welch_1000", lambda: ctx.call("tsdr_welch_d", p(iq), 1, L, 1000, 0, p(y2)), 8 * L + 4 * 1000, 10,
+        "getWelch at sizeFFT = 1000: the general path (batched mixed-radix FFT through HBM + two-level accumulation)")
     ys = torch.empty(80000, dtype=torch.float32, device=dev)
     leg("spectrum", lambda: ctx.call("tsdr_spectrum_d", p(iq), 1, 80000, 0, p(ys)), 8 * 80000 + 4 * 80000, 50,
         "getSpectrum(Fs, sig[1:80_000]) (production/investigate_data.jl:44): launch-bound at this size")

@@ -32,18 +32,39 @@ __global__ __launch_bounds__(256) void k_spec_out(const float2 *__restrict__ X, 
   }
 }
 
-// S[k] = sum over segments (in order) of |X_seg[k]|^2, then fftshift and optional dB
-__global__ __launch_bounds__(256) void k_welch(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg, int lin,
-                                               float *__restrict__ y) {
-  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < sizeFFT; j += (size_t)gridDim.x * blockDim.x) {
-    const size_t k = shift_src(j, sizeFFT);
-    float S = 0.f;
-    for (size_t s = 0; s < nbSeg; ++s) {
-      const float2 c = X[s * sizeFFT + k];
-      S += c.x * c.x + c.y * c.y;
-    }
-    y[j] = lin ? S : 10.0f * log10f(S);
+// S[k] = sum over segments of |X_seg[k]|^2, then fftshift and optional dB -- in two levels so that the launch fills
+// the device: block (x, c) adds the segments of chunk c for 256 frequencies (ascending, eight loads in flight), the
+// second kernel adds the chunk sums in index order.  With one chunk (nbSeg <= chunk) this is the reference's strict
+// segment-by-segment order (GetSpectrum.jl:44); with more it is the same fixed blocked order as the 1024-point path.
+__global__ __launch_bounds__(256) void k_welch_part(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg, size_t chunk,
+                                                    float *__restrict__ part) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= sizeFFT) return;
+  const size_t s0 = (size_t)blockIdx.y * chunk, s1 = s0 + chunk < nbSeg ? s0 + chunk : nbSeg;
+  float S = 0.f;
+  size_t s = s0;
+  for (; s + 8 <= s1; s += 8) {
+    float2 c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = X[(s + u) * sizeFFT + k];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) S += c[u].x * c[u].x + c[u].y * c[u].y;
   }
+  for (; s < s1; ++s) {
+    const float2 c = X[s * sizeFFT + k];
+    S += c.x * c.x + c.y * c.y;
+  }
+  part[(size_t)blockIdx.y * sizeFFT + k] = S;
+}
+
+__global__ __launch_bounds__(256) void k_welch_sum(const float *__restrict__ part, size_t sizeFFT, unsigned nparts, int lin,
+                                                   float *__restrict__ y) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= sizeFFT) return;
+  const size_t k = shift_src(j, sizeFFT);
+  float S = 0.f;
+  for (unsigned c = 0; c < nparts; ++c) S += part[(size_t)c * sizeFFT + k];
+  y[j] = lin ? S : 10.0f * log10f(S);
 }
 
 __global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg,
@@ -318,8 +339,19 @@ int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, si
   size_t nbSeg;
   int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);
   if (rc) return rc;
-  TSDR_LAUNCH(ctx, "welch_acc", k_welch, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, (const float2 *)X, sizeFFT,
-              nbSeg, lin, y);
+  if (nbSeg == 0) {  // sum over no segments: zeros (-Inf dB), as the reference's zero-initialised accumulator gives
+    TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, (const float *)nullptr, sizeFFT, 0u, lin,
+                y);
+    return TSDR_OK;
+  }
+  const size_t chunk = std::max<size_t>(16, ceil_div(nbSeg, (size_t)256));
+  const unsigned nparts = (unsigned)ceil_div(nbSeg, chunk);
+  float *part = (float *)ctx->scratch(WS_FFT_C, (size_t)nparts * sizeFFT * sizeof(float));
+  if (!part) return TSDR_ENOMEM;
+  if (ceil_div(sizeFFT, 256) >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "welch: sizeFFT too large");
+  TSDR_LAUNCH(ctx, "welch_part", k_welch_part, dim3((unsigned)ceil_div(sizeFFT, 256), nparts), dim3(256), 0, (const float2 *)X, sizeFFT, nbSeg,
+              chunk, part);
+  TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, (const float *)part, sizeFFT, nparts, lin, y);
   return TSDR_OK;
 }
 
