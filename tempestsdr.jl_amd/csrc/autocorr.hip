@@ -21,11 +21,6 @@
 
 namespace tsdr {
 
-int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale, int src_mode,
-             size_t src_n, size_t keep);
-bool fft_mixed_ok(size_t N);
-int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep, const FftEpilogue *epi = nullptr);
 int get_tw(tsdr_ctx *ctx, int logN, TwTable **out);
 
 __device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

@@ -38,6 +38,8 @@ struct PassDesc {
   int src_mode;              // first pass loader (SRC_*); only with batch == 1
   unsigned long long src_n;  // real samples behind SRC_REAL / SRC_IQPOW
   unsigned long long keep;   // last pass: complex outputs >= keep (per transform) are not stored
+  const float2 *src_aux;     // SRC_MULH: the factor array
+  FftEpilogue epi;           // last pass: epilogue when epi.out != nullptr (fft_dev.h)
 };
 
 // K(a): a = k_1*(R_2..R_m) + ... + k_m  ->  k_1 + R_1*k_2 + R_1R_2*k_3 + ...
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in,
       const int t = s & (T - 1), j0 = s >> logT;
 #pragma unroll
       for (int m = 0; m < RA; ++m)
-        v[q * RA + m] = s < n1 ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t), smask)
+        v[q * RA + m] = s < n1 ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t, 0.0, d.src_aux), smask)
                                : make_float2(0.f, 0.f);
     }
     // inter-pass twiddles of this thread's 16 outputs: independent of the data, so they are evaluated here,
@@ -244,7 +246,10 @@ __global__ __launch_bounds__(256) void k_fft_pass(const float2 *__restrict__ in,
           const float2 x = RB > 1 ? v[q * RB + brev<RB>(i)] : v[q * RA + i];
           const size_t o = orel + ((size_t)k << d.logPprev) + t;
           // outputs past `keep` are never looked at by the caller (e.g. lags beyond the window)
-          if (o < d.keep) out[tbase + o] = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+          if (o < d.keep) {
+            const float2 y = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
+            if (d.epi.out) epilogue_store(d.epi, o, y); else out[tbase + o] = y;
+          }
         }
       }
     }
@@ -336,7 +341,7 @@ int get_tw(tsdr_ctx *ctx, int logN, TwTable **out) {
 // in/out may alias.  Uses WS_FFT_B when more than one pass is needed: callers must not hand
 // WS_FFT_B buffers to this function.
 int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale, int src_mode,
-             size_t src_n, size_t keep) {
+             size_t src_n, size_t keep, const FftEpilogue *epi, const float2 *src_aux) {
   if (logN < 0 || logN > 31) return set_err(ctx, TSDR_EINVAL, "fft: unsupported power-of-two length 2^%d", logN);
   if (batch == 0) return TSDR_OK;
   int rc = ensure_tw_small(ctx);
@@ -356,7 +361,8 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   d.src_mode = SRC_C2C;
   d.src_n = 0;
   d.keep = keep ? keep : N;
-  if (src_mode != SRC_C2C && (batch != 1 || logN <= 8)) return set_err(ctx, TSDR_EINVAL, "fft: fused loader needs one multi-pass transform");
+  if ((src_mode != SRC_C2C || epi) && (batch != 1 || logN <= 8)) return set_err(ctx, TSDR_EINVAL, "fft: fused loader / epilogue needs one multi-pass transform");
+  d.src_aux = src_aux;
   if (p == 1) {
     d.mode = FFT_ROWS;
     d.logR = logN;
@@ -399,6 +405,7 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   }
   d.mode = FFT_LAST;
   d.src_mode = SRC_C2C;
+  if (epi) d.epi = *epi;
   d.logR = bits[p - 1];
   d.logR1 = bits[0];
   d.logT = std::min(12 - bits[p - 1], bits[0]);
@@ -417,9 +424,6 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
   return TSDR_OK;
 }
 
-bool fft_mixed_ok(size_t N);
-int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep, const FftEpilogue *epi = nullptr);
 
 // ---- Bluestein ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chirp(float2 *__restrict__ chirp, unsigned long long n) {

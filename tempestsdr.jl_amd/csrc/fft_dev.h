@@ -117,14 +117,24 @@ __device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000
 //             sequence; Y is the packed spectrum whose inverse transform (times 1/2) is the real sequence with
 //             spectrum |X|^2 (see k_ac_power, which this loader replaces: one launch and a 2 x 8*Mc-byte round
 //             trip less)
-enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2, SRC_POWER = 3 };
+//   SRC_STUFF (x[g / up], 0) when up divides g, else 0: the zero-stuffed real input of the resampler (Resampler.jl:
+//             upsampling by inserting up - 1 zeros), src_n = up -- k_stuff without its pass
+//   SRC_RE0   (x[g], 0): a real f32 sequence as complex input (getSpectrum of a real signal) -- k_r2c without its pass
+//   SRC_MULH  in[g] * aux[g]: the resampler's frequency-domain filter applied while the inverse transform loads
+enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2, SRC_POWER = 3, SRC_STUFF = 4, SRC_MULH = 5, SRC_RE0 = 6 };
 
 // tw_frac below (needed by the SRC_POWER loader when M = 2*Mc is not a power of two)
 __device__ inline float2 tw_frac(unsigned e, double inv_n8);
 
 __device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g,
-                                  double inv_m8 = 0.0) {
+                                  double inv_m8 = 0.0, const float2 *__restrict__ aux = nullptr) {
   if (src_mode == SRC_C2C) return in[g];
+  if (src_mode == SRC_MULH) return cmul(in[g], aux[g]);
+  if (src_mode == SRC_RE0) return make_float2(reinterpret_cast<const float *>(in)[g], 0.f);
+  if (src_mode == SRC_STUFF) {
+    const size_t q = g / (size_t)src_n;
+    return q * (size_t)src_n == g ? make_float2(reinterpret_cast<const float *>(in)[q], 0.f) : make_float2(0.f, 0.f);
+  }
   if (src_mode == SRC_POWER) {
     const size_t Mc = (size_t)src_n;
     const float2 a = in[g], b = in[g ? Mc - g : 0];
@@ -159,17 +169,46 @@ __device__ inline float2 tw_frac(unsigned e, double inv_n8) {
   return tw_octant(o & 7u, x);
 }
 
-// Epilogue of the last pass for the autocorrelation (Autocorrelations.jl:33-36): the complex output o holds the real
-// lags (2o, 2o+1); lags k0 <= k < k0+cnt leave as abs2 (and 10log10) in f32 -- k_ac_finish without the round trip.
+// Epilogues of the last pass (o = index of the complex output x within its transform):
+//   EPI_AC     autocorrelation (Autocorrelations.jl:33-36): x holds the real lags (2o, 2o+1); lags k0 <= k < k0+cnt leave
+//              as abs2 (and 10log10) in f32 -- k_ac_finish without the round trip
+//   EPI_REAL   out[o] = gain * real(x) for o < cnt: the resampler's `2*upCoeff*real.(ifft)` (Resampler.jl) without k_real_scale
+//   EPI_SPEC   getSpectrum (GetSpectrum.jl:21-30): out[fftshift position of o] = abs2(x) or 10log10(abs2(x)); cnt = N, k0 = N div 2
+enum { EPI_NONE = 0, EPI_AC = 1, EPI_REAL = 2, EPI_SPEC = 3 };
 struct FftEpilogue {
   float *out = nullptr;
   unsigned long long k0 = 0, cnt = 0;
   int log_scale = 0;
+  int kind = EPI_AC;
+  float gain = 1.0f;
 };
 __device__ inline void epilogue_store(const FftEpilogue &e, size_t o, float2 x) {
+  if (e.kind == EPI_REAL) {
+    if (o < e.cnt) e.out[o] = e.gain * x.x;
+    return;
+  }
+  if (e.kind == EPI_SPEC) {
+    if (o < e.cnt) {
+      size_t j = o + e.k0;
+      if (j >= e.cnt) j -= e.cnt;
+      const float p = x.x * x.x + x.y * x.y;
+      e.out[j] = e.log_scale ? 10.0f * log10f(p) : p;
+    }
+    return;
+  }
   const unsigned long long i0 = 2ull * o - e.k0, i1 = i0 + 1ull;  // (wraps to huge when below k0)
   if (i0 < e.cnt) { const float p = x.x * x.x; e.out[i0] = e.log_scale ? 10.0f * log10f(p) : p; }
   if (i1 < e.cnt) { const float p = x.y * x.y; e.out[i1] = e.log_scale ? 10.0f * log10f(p) : p; }
 }
+
+// host entry points of the two engines (fft.hip, fft_mixed.hip).  src_mode / src_n / src_aux: fused loader of the first
+// pass; keep: complex outputs per transform the caller will look at (0 = all); epi: epilogue of the last pass.  Loaders
+// and epilogues need one transform (batch == 1) of more than one pass.
+int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batch, int dir, float scale, int src_mode,
+             size_t src_n, size_t keep, const FftEpilogue *epi = nullptr, const float2 *src_aux = nullptr);
+int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
+              size_t src_n, size_t keep, const FftEpilogue *epi = nullptr, const float2 *src_aux = nullptr);
+bool fft_mixed_ok(size_t N);
+int fft_passes(size_t N);  // launches a length-N transform takes (0: not a 2^a 3^b 5^c length)
 
 }  // namespace tsdr

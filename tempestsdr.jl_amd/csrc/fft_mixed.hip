@@ -47,6 +47,7 @@ struct MixDesc {
   unsigned long long src_n, keep;
   int tw_sets;                       // strided, two-step kernels: inter-pass twiddle sets held in LDS (0: none)
   const float2 *twg;                 // strided, Bnext == 1: W_{R*Rnext}^(col*k) at [k * B + col] (else nullptr)
+  const float2 *src_aux;             // SRC_MULH: the factor array
   double src_w8;                     // SRC_POWER with M = 2*src_n not a power of two: 8/M (else 0)
   FftEpilogue epi;                   // last pass: autocorrelation epilogue when epi.out != nullptr
 };
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
       for (int u = 0; u < NB; ++u) {
         const unsigned w = w0 + 256 * u;
         const unsigned t = w & (T - 1u), j = w >> logT;
-        v[u] = (w < work && col0 + t < d.B) ? fft_load(in, d.src_mode, d.src_n, base + (size_t)j * d.B + t, d.src_w8)
+        v[u] = (w < work && col0 + t < d.B) ? fft_load(in, d.src_mode, d.src_n, base + (size_t)j * d.B + t, d.src_w8, d.src_aux)
                                              : make_float2(0.f, 0.f);
       }
 #pragma unroll
@@ -402,7 +403,7 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
         const bool ok = s < n1 && col0 + (unsigned)t < d.B;
 #pragma unroll
         for (int m = 0; m < RA; ++m)
-          v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t, d.src_w8), smask)
+          v[q * RA + m] = ok ? conj_if(fft_load(in, d.src_mode, d.src_n, base + (size_t)(j0 + RB * m) * d.B + t, d.src_w8, d.src_aux), smask)
                              : make_float2(0.f, 0.f);
       }
     }
@@ -697,6 +698,12 @@ static bool fft_mixed_plan_search(size_t N, MixPlan *plan) {
   return true;
 }
 
+int fft_passes(size_t N) {
+  if (is_pow2(N)) { int l = 0; while (((size_t)1 << l) < N) ++l; return l <= 8 ? 1 : (l + 7) / 8; }
+  MixPlan pl;
+  return fft_mixed_plan(N, &pl) ? pl.p : 0;
+}
+
 bool fft_mixed_ok(size_t N) {
   MixPlan pl;
   return fft_mixed_plan(N, &pl);
@@ -742,7 +749,7 @@ static int get_twg(tsdr_ctx *ctx, unsigned R, unsigned Rn, const float2 **out) {
 // src_mode/src_n: fused first-pass loader (fft_dev.h), batch == 1 and p > 1 only; keep: complex outputs per
 // transform the caller will look at (0 = all).
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep, const FftEpilogue *epi) {
+              size_t src_n, size_t keep, const FftEpilogue *epi, const float2 *src_aux) {
   MixPlan pl;
   if (!fft_mixed_plan(N, &pl)) return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
   if (batch == 0) return TSDR_OK;
@@ -755,6 +762,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   d.src_mode = SRC_C2C;
   d.keep = keep ? keep : N;
   d.src_w8 = src_mode == SRC_POWER && !is_pow2(src_n) ? 4.0 / (double)src_n : 0.0;
+  d.src_aux = src_aux;
   if (epi && (batch != 1 || p == 1)) return set_err(ctx, TSDR_EINVAL, "fft: epilogue needs one multi-pass transform");
   auto set_radix = [&](int i) {
     d.R = pl.R[i];

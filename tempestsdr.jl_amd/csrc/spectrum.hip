@@ -276,6 +276,19 @@ static int spectrum_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N,
   if (N == 0) return TSDR_OK;
   float2 *X = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
   if (!X) return TSDR_ENOMEM;
+  if (fft_passes(N) >= 2 && (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
+    // the passes alone: a real signal enters through the first pass's loader, abs2 / 10log10 and the fftshift leave
+    // through the last pass's epilogue
+    FftEpilogue epi;
+    epi.kind = EPI_SPEC;
+    epi.out = y;
+    epi.cnt = N;
+    epi.k0 = N / 2;
+    epi.log_scale = !lin;
+    const float2 *x = reinterpret_cast<const float2 *>(sig);
+    const int sm = is_complex ? SRC_C2C : SRC_RE0;
+    return is_pow2(N) ? fft_pow2(ctx, x, X, ilog2(N), 1, -1, 1.0f, sm, 0, 0, &epi) : fft_mixed(ctx, x, X, N, 1, -1, 1.0f, sm, 0, 0, &epi);
+  }
   int rc = fft_any(ctx, sig, is_complex, X, N, 1, -1);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "spectrum_out", k_spec_out, dim3(stream_grid(ctx, N)), dim3(256), 0, (const float2 *)X, N, lin, y);
@@ -447,6 +460,24 @@ int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float 
   const size_t N = r->sizeFFT;
   float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
   if (!tmp) return TSDR_ENOMEM;
+  const int passes = fft_passes(N);
+  if (passes >= 2) {
+    // two transforms and nothing else: the zero-stuffing is the forward transform's loader, the filter the inverse
+    // transform's, 2*upCoeff*real(.) the epilogue of its last pass
+    const bool p2 = is_pow2(N);
+    const float2 *x = reinterpret_cast<const float2 *>(in);
+    int rc = p2 ? fft_pow2(ctx, x, tmp, ilog2(N), 1, -1, 1.0f, SRC_STUFF, r->up, 0)
+                : fft_mixed(ctx, x, tmp, N, 1, -1, 1.0f, SRC_STUFF, r->up, 0);
+    if (rc) return rc;
+    FftEpilogue epi;
+    epi.kind = EPI_REAL;
+    epi.out = out;
+    epi.cnt = N;
+    epi.gain = (float)(2 * r->up);
+    const float inv = (float)(1.0 / (double)N);
+    return p2 ? fft_pow2(ctx, tmp, r->work, ilog2(N), 1, +1, inv, SRC_MULH, 0, 0, &epi, (const float2 *)r->H)
+              : fft_mixed(ctx, tmp, r->work, N, 1, +1, inv, SRC_MULH, 0, 0, &epi, (const float2 *)r->H);
+  }
   TSDR_LAUNCH(ctx, "resampler_stuff", k_stuff, dim3(stream_grid(ctx, N)), dim3(256), 0, in, N, (unsigned)r->up, r->work);
   int rc = fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, tmp, N, 1, -1);
   if (rc) return rc;
