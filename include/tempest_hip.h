@@ -178,6 +178,11 @@ int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len
  * unnormalised, inverse scaled 1/n); dir<0 forward.  batch transforms, contiguous. */
 int tsdr_fft_c2c(tsdr_ctx *ctx, const float *in, float *out, size_t n, size_t batch, int dir);
 int tsdr_fft_c2c_d(tsdr_ctx *ctx, const float *in, float *out, size_t n, size_t batch, int dir);
+/* Diagnostics, host arithmetic only (no context, no device): the per-pass factors a length-n transform would be split
+ * into -- powers of two up to 256 for n = 2^k, factors 2^a 3^b 5^c <= 256 from the cost-based planner for other smooth
+ * lengths.  Returns the number of passes (factors[0 .. min(passes, cap)) filled), 0 when n takes the Bluestein route
+ * (or n < 2). */
+int tsdr_fft_plan(size_t n, unsigned *factors, int cap);
 
 /* ---- FrameSynchronisation.jl ----------------------------------------------------- */
 /* SyncXY(image) for a (y_t,x_t) image                FrameSynchronisation.jl:25-48 */

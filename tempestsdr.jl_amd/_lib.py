@@ -94,6 +94,7 @@ _SIGS = {
     "tsdr_waterfall_d": (C.c_int, [vp, vp, C.c_int, c_sz, c_sz, vp]),
     "tsdr_fft_c2c": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int]),
     "tsdr_fft_c2c_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int]),
+    "tsdr_fft_plan": (C.c_int, [c_sz, vp, C.c_int]),
     # FrameSynchronisation.jl
     "tsdr_sync_create": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
     "tsdr_sync_reset": (C.c_int, [vp]),

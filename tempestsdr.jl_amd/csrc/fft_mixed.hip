@@ -859,3 +859,20 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
 }
 
 }  // namespace tsdr
+
+extern "C" int tsdr_fft_plan(size_t n, unsigned *factors, int cap) {
+  using namespace tsdr;
+  if (n < 2) return 0;
+  if (is_pow2(n)) {  // fft.hip's split: the bits dealt evenly over ceil(log2 n / 8) passes
+    int l = 0;
+    while (((size_t)1 << l) < n) ++l;
+    const int p = l <= 8 ? 1 : (l + 7) / 8;
+    for (int i = 0; i < p && i < cap && factors; ++i) factors[i] = 1u << (l / p + (i < l % p ? 1 : 0));
+    return p;
+  }
+  MixPlan pl;
+  if (!fft_mixed_plan(n, &pl)) return 0;
+  for (int i = 0; i < pl.p && i < cap && factors; ++i) factors[i] = pl.R[i];
+  return pl.p;
+}
+

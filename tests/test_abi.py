@@ -60,3 +60,30 @@ def test_zoom_bounds_is_pure_host_logic(tsdr):
     assert (a.value, b.value) == (222_222, 400_000)  # 177 779 points at C2
     assert lib.tsdr_zoom_bounds(1000, 20e6, 50.0, 90.0, C.byref(a), C.byref(b)) == 0
     assert (a.value, b.value) == (1000, 1000)  # min(.,N) clamp, Autocorrelations.jl:46-47
+
+
+def test_fft_plan_is_pure_host_logic(tsdr):
+    """The pass planner of the FFT engines (host arithmetic): factors multiply back to n, none exceeds 256, at most six
+    passes; lengths with a prime factor above 5 take the Bluestein route (0 passes reported)."""
+    import random
+    lib = tsdr._lib.load()
+    f = (C.c_uint * 8)()
+    rnd = random.Random(5)
+    sizes = [2, 4, 1000, 1024, 4096, 80_000, 2_000_000, 5_000_000, 20_000_000, 4_194_304, 1 << 24, 3 ** 9, 5 ** 8, 2 * 3 * 5]
+    for _ in range(300):
+        n = (2 ** rnd.randrange(0, 20)) * (3 ** rnd.randrange(0, 8)) * (5 ** rnd.randrange(0, 7))
+        if 2 <= n < 2 ** 31:
+            sizes.append(n)
+    for n in sizes:
+        p = lib.tsdr_fft_plan(n, f, 8)
+        assert 1 <= p <= 6, (n, p)
+        prod = 1
+        for i in range(p):
+            assert 2 <= f[i] <= 256, (n, list(f)[:p])
+            prod *= f[i]
+        assert prod == n, (n, list(f)[:p])
+    # the search transforms of the three workloads: three, three and four passes
+    assert lib.tsdr_fft_plan(2_000_000, f, 8) == 3 and sorted(f[:3]) == [100, 100, 200]
+    assert lib.tsdr_fft_plan(20_000_000, f, 8) == 4
+    for n in (7, 999 * 3, 1_000_003, 2 * 7 * 11):
+        assert lib.tsdr_fft_plan(n, f, 8) == 0
