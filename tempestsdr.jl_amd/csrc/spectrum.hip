@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void k_spec_out(const float2 *__restrict__ X, 
 
 // S[k] = sum over segments of |X_seg[k]|^2, then fftshift and optional dB -- in two levels so that the launch fills
 // the device: block (x, c) adds the segments of chunk c for 256 frequencies (ascending, eight loads in flight), the
-// second kernel adds the chunk sums in index order.  With one chunk (nbSeg <= chunk) this is the reference's strict
-// segment-by-segment order (GetSpectrum.jl:44); with more it is the same fixed blocked order as the 1024-point path.
+// second kernel adds the chunk sums (sixteen interleaved partial sums, then those in order).  With one chunk
+// (nbSeg <= chunk) this is the reference's strict segment-by-segment order (GetSpectrum.jl:44); with more it is a fixed
+// blocked order like the 1024-point path's.
 __global__ __launch_bounds__(256) void k_welch_part(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg, size_t chunk,
                                                     float *__restrict__ part) {
   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -57,14 +58,26 @@ __global__ __launch_bounds__(256) void k_welch_part(const float2 *__restrict__ X
   part[(size_t)blockIdx.y * sizeFFT + k] = S;
 }
 
+// grid = ceil(sizeFFT / 16) blocks of 256 threads: thread (kq, g) adds chunk sums g, g + 16, ... of frequency
+// 16 * blockIdx.x + kq in ascending order, the 16 partial results are then added in order of g (one thread per
+// frequency looping over 256 chunk sums alone took 62 us of the general path's 152)
 __global__ __launch_bounds__(256) void k_welch_sum(const float *__restrict__ part, size_t sizeFFT, unsigned nparts, int lin,
                                                    float *__restrict__ y) {
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= sizeFFT) return;
-  const size_t k = shift_src(j, sizeFFT);
-  float S = 0.f;
-  for (unsigned c = 0; c < nparts; ++c) S += part[(size_t)c * sizeFFT + k];
-  y[j] = lin ? S : 10.0f * log10f(S);
+  __shared__ float sm[16][17];
+  const int kq = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const size_t j = (size_t)blockIdx.x * 16 + kq;
+  const size_t k = j < sizeFFT ? shift_src(j, sizeFFT) : 0;
+  float t = 0.f;
+  if (j < sizeFFT)
+    for (unsigned c = g; c < nparts; c += 16) t += part[(size_t)c * sizeFFT + k];
+  sm[g][kq] = t;
+  __syncthreads();
+  if (g == 0 && j < sizeFFT) {
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S += sm[i][kq];
+    y[j] = lin ? S : 10.0f * log10f(S);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X, size_t sizeFFT, size_t nbSeg,
@@ -96,9 +109,14 @@ __global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X,
 // bits the order cannot make the result bit-exact either way, and the blocked order has the smaller rounding error.
 // Waterfall: Float64(|X|^2) goes straight from the registers to sMatrix[:, segment] (fftshift applied to the index).
 constexpr int kSegN = 1024, kSegWaves = 4, kSegPitch = 66;
+// wavefronts per SIMD the kernel is held to, and whether segment s+1 is requested before s is transformed (32 VGPRs).
+// Measured at 9765 segments: (3, prefetch) 29.1 / 27.0 us Welch / waterfall, (4, no prefetch) 28.5 / 28.6 us -- a tie;
+// the kernel issues VALU instructions 71 % of the time either way.
+constexpr int kSegOcc = 3;
+constexpr bool kSegPrefetch = true;
 
 template <bool WATERFALL, bool CPLX>
-__global__ __launch_bounds__(64 * kSegWaves, 3) void k_seg1024(const float *__restrict__ sig, size_t nbSeg,
+__global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float *__restrict__ sig, size_t nbSeg,
                                                             unsigned nwaves, float *__restrict__ part,
                                                             double *__restrict__ wf) {
   __shared__ float2 lds[kSegWaves][16 * kSegPitch];
@@ -132,12 +150,13 @@ __global__ __launch_bounds__(64 * kSegWaves, 3) void k_seg1024(const float *__re
       for (int m = 0; m < 16; ++m) nx[m] = make_float2(x[64 * m], 0.0f);
     }
   };
-  if (seg0 < seg1) fetch(seg0);
+  if (kSegPrefetch && seg0 < seg1) fetch(seg0);
   for (size_t seg = seg0; seg < seg1; ++seg) {
     float2 v[16];
+    if (!kSegPrefetch) fetch(seg);
 #pragma unroll
     for (int m = 0; m < 16; ++m) v[m] = nx[m];
-    if (seg + 1 < seg1) fetch(seg + 1);
+    if (kSegPrefetch && seg + 1 < seg1) fetch(seg + 1);
     reg_dft<16>(v);
 #pragma unroll
     for (int ka = 0; ka < 16; ++ka) {
@@ -321,10 +340,12 @@ int tsdr_spectrum(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int
                   [&](void *i, void *o) { return spectrum_d(ctx, (const float *)i, is_complex, N, lin, (float *)o); });
 }
 
-// wavefronts of the 1024-point fast path: one per segment up to 4096 (three 4-wavefront workgroups per CU), then
-// contiguous chunks of segments per wavefront
-static unsigned seg_waves(size_t nbSeg, unsigned *blocks) {
-  const unsigned nwaves = (unsigned)std::min<size_t>(nbSeg, 4096);
+// wavefronts of the 1024-point fast path: one per segment while they all fit the device at once (three 4-wavefront
+// workgroups per CU: 154 VGPRs), else exactly that many, each walking a contiguous chunk of segments -- a launch of
+// 4/3 of the resident workgroups ran its last third alone on a mostly idle device (Welch 31 -> 24 us at 9765 segments)
+static unsigned seg_waves(tsdr_ctx *ctx, size_t nbSeg, unsigned *blocks) {
+  const size_t resident = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * kSegOcc * kSegWaves;
+  const unsigned nwaves = (unsigned)std::min<size_t>(nbSeg, resident);
   *blocks = (unsigned)ceil_div((size_t)nwaves, (size_t)kSegWaves);
   return nwaves;
 }
@@ -335,7 +356,7 @@ int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, si
       (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
     const size_t nbSeg = len / sizeFFT;
     unsigned blocks = 0;
-    const unsigned nwaves = seg_waves(nbSeg, &blocks);
+    const unsigned nwaves = seg_waves(ctx, nbSeg, &blocks);
     float *part = (float *)ctx->scratch(WS_FFT_A, (size_t)blocks * kSegN * 4);
     if (!part) return TSDR_ENOMEM;
     if (is_complex) {
@@ -353,7 +374,7 @@ int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, si
   int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);
   if (rc) return rc;
   if (nbSeg == 0) {  // sum over no segments: zeros (-Inf dB), as the reference's zero-initialised accumulator gives
-    TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, (const float *)nullptr, sizeFFT, 0u, lin,
+    TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 16)), dim3(256), 0, (const float *)nullptr, sizeFFT, 0u, lin,
                 y);
     return TSDR_OK;
   }
@@ -364,7 +385,7 @@ int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, si
   if (ceil_div(sizeFFT, 256) >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "welch: sizeFFT too large");
   TSDR_LAUNCH(ctx, "welch_part", k_welch_part, dim3((unsigned)ceil_div(sizeFFT, 256), nparts), dim3(256), 0, (const float2 *)X, sizeFFT, nbSeg,
               chunk, part);
-  TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, (const float *)part, sizeFFT, nparts, lin, y);
+  TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 16)), dim3(256), 0, (const float *)part, sizeFFT, nparts, lin, y);
   return TSDR_OK;
 }
 
@@ -380,7 +401,7 @@ int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len
       (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
     const size_t nbSeg = len / sizeFFT;
     unsigned blocks = 0;
-    const unsigned nwaves = seg_waves(nbSeg, &blocks);
+    const unsigned nwaves = seg_waves(ctx, nbSeg, &blocks);
     if (is_complex) {
       TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<true, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
                   (float *)nullptr, sMatrix);
