@@ -92,12 +92,13 @@ __global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X,
 
 // ---- 1024-point segments without leaving the chip (getWelch / getWaterfall at their default sizeFFT) -------------
 // One WAVEFRONT transforms one segment: 64 lanes x 16 complex values in registers, two exchanges through a private
-// 8.25 KiB LDS region, no workgroup barrier inside a transform.  With n = l + 64 m (l = lane, m < 16) and
+// 8.1 KiB LDS region, no workgroup barrier inside a transform.  With n = l + 64 m (l = lane, m < 16) and
 // k = ka + 16 (kb1 + 16 kb0):
 //   step 1   A[ka]   = sum_m x[l + 64 m] W_16^(m ka)                  16-point DFT in registers, then * W_1024^(l ka)
-//   LDS      Z1[ka][l]  (row pitch 66: the transposed read below is conflict-free)
+//   LDS      Z1[ka][l]  (row pitch 65 complex = 130 words: the 16 lanes the LDS serves per cycle of the transposed
+//            8-byte read below fall into 32 distinct banks; 66 made them collide two by two)
 //   step 2   lane = (ka, l0), l = l0 + 4 l1:  B[kb1] = sum_l1 Z1[ka][l0 + 4 l1] W_16^(l1 kb1),  then * W_64^(l0 kb1)
-//   LDS      Z2[kb1][ka][l0]
+//   LDS      Z2[kb1][l0][ka]  (ka innermost: both the write and the read below touch consecutive words)
 //   step 3   lane l' reads, for j < 4, the four l0 of (ka = l' & 15, kb1 = 4 j + (l' >> 4)): 4-point DFT over l0
 //            -> X[l' + 64 j + 256 kb0]: for a fixed register the 64 lanes hold 64 consecutive frequencies, so
 //            every global access of the kernel -- loads included -- is one contiguous run per wave-instruction.
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_waterfall(const float2 *__restrict__ X,
 // strictly segment by segment (GetSpectrum.jl:44); with f32 FFT outputs that already differ from FFTW's in the last
 // bits the order cannot make the result bit-exact either way, and the blocked order has the smaller rounding error.
 // Waterfall: Float64(|X|^2) goes straight from the registers to sMatrix[:, segment] (fftshift applied to the index).
-constexpr int kSegN = 1024, kSegWaves = 4, kSegPitch = 66;
+constexpr int kSegN = 1024, kSegWaves = 4, kSegPitch = 65;
 // wavefronts per SIMD the kernel is held to, and whether segment s+1 is requested before s is transformed (32 VGPRs).
 // Measured at 9765 segments: (3, prefetch) 29.1 / 27.0 us Welch / waterfall, (4, no prefetch) 28.5 / 28.6 us -- a tie;
 // the kernel issues VALU instructions 71 % of the time either way.
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float
     for (int kb1 = 0; kb1 < 16; ++kb1) {
       float2 t = v[brev<16>(kb1)];
       if (kb1) t = cmul(t, tw2t[l0 * 16 + kb1]);
-      z[(kb1 * 16 + ka2) * 4 + l0] = t;
+      z[kb1 * 64 + l0 * 16 + ka2] = t;  // [kb1][l0][ka2]: the 16 lanes of a bank cycle write consecutive words
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float
     for (int j = 0; j < 4; ++j) {
       float2 d[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) d[q] = z[(64 * j + lane) * 4 + q];
+      for (int q = 0; q < 4; ++q) d[q] = z[(4 * j + l0) * 64 + q * 16 + ka2];  // element (kb1 = 4j + lane/16, l0 = q, ka2 = lane%16)
       reg_dft<4>(d);
 #pragma unroll
       for (int kb0 = 0; kb0 < 4; ++kb0) {
