@@ -1,4 +1,6 @@
-"""Child of tests/test_multi_gpu.py: one process per GPU (torch.distributed.run), RCCL backend.
+"""Child of tests/test_multi_gpu.py: one process per GPU (torch.distributed.run), RCCL backend -- or, with
+MGPU_SHARE_ONE_GPU=1, every rank on cuda:0 and the collectives staged through the host over gloo (the sharded product
+kernels then run on a real GPU at world size > 1 even where only one GPU exists; only the transport differs).
 Checks, at the launched world size, that
   * HipFrames (frames of ONE buffer sharded over the ranks, all-gather, replicated combine) returns bit for bit what a
     single tsdr_frames call returns on rank 0's GPU: sync indices, every frame, the IIR state -- on every rank;
@@ -19,9 +21,15 @@ def main():
     import torch
     import torch.distributed as dist
     rank, local, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    share = os.environ.get("MGPU_SHARE_ONE_GPU") == "1"  # every rank on cuda:0, collectives over gloo (host-staged)
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from tempest_loader import load_package
     tsdr = load_package()
     import importlib
@@ -65,7 +73,7 @@ def main():
         if not (err < 2e-4 and pos == pos1):
             print(f"rank {rank}: HipSearch route={route} err {err:.3e} dB argmax {pos} vs {pos1}", flush=True)
             ok = False
-    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device="cpu" if share else dev)
     dist.all_reduce(flag)
     dist.destroy_process_group()
     if rank == 0:

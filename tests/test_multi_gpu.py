@@ -38,3 +38,18 @@ def test_hipframes_and_hipsearch_over_rccl(world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"world {world} failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     assert "mgpu_child: OK" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_paths_with_several_ranks_on_one_gpu(world):
+    """The same child with every rank on cuda:0 and gloo (host-staged) collectives: scan / all-gather / combine and
+    segment+halo partial sums / all-reduce / finish run through the product kernels at world size > 1 on any GPU box.
+    What it cannot show is RCCL itself -- that is the test above."""
+    if _ngpu() < 1:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGPU_SHARE_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(HERE, "mgpu_child.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"world {world} (one GPU) failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    assert "mgpu_child: OK" in r.stdout
