@@ -283,11 +283,19 @@ def main():
     api = importlib.import_module("tempestsdr_jl_amd.api")
     par = importlib.import_module("tempestsdr_jl_amd.parallel")
 
+    # test mode (tests/test_multi_gpu.py): every rank on cuda:0, host-staged collectives over gloo -- exercises the N > 1
+    # code paths of this file on a 1-GPU box; its numbers mean nothing and the JSON line says so
+    share = world > 1 and os.environ.get("TSDR_BENCH_SHARE_ONE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx = tsdr.Context(local_rank)  # raises if the HIP library / device is missing: no fallback
     info = ctx.device_info()
@@ -302,7 +310,7 @@ def main():
     def reduce_max(vals):
         if world == 1:
             return list(vals)
-        t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+        t = torch.tensor(list(vals), dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
 
@@ -427,6 +435,7 @@ def main():
     if rank == 0:
         line = {
             "metric": METRIC, "value": res["value"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            **({"shared_gpu_test_mode": "every rank on cuda:0 over gloo: code-path test, numbers meaningless"} if share else {}),
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: synthetic {x_t}x{y_t}@{fv:g}Hz leak, Fs={Fs/1e6:g} MS/s, "

@@ -53,3 +53,24 @@ def test_sharded_paths_with_several_ranks_on_one_gpu(world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, f"world {world} (one GPU) failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
     assert "mgpu_child: OK" in r.stdout
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it, except that both ranks share cuda:0 (gloo): the weak-scaling leg,
+    the max-over-ranks timing, the strong leg and the search route choice must run to a well-formed JSON line."""
+    import json
+    if _ngpu() < 1:
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TSDR_BENCH_SHARE_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--repeats", "2", "--search-steps", "2", "--no-cpu", "--no-ingest", "--no-extra"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"bench --gpus 2 failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak" and "shared_gpu_test_mode" in d
+    assert d["strong"] and "error" not in d["strong"] and d["strong"]["value"] > 0, d["strong"]
+    assert d["search"] and "error" not in d["search"], d["search"]
+    assert "replicated" in d["search"]["mode"]  # the reference's window: sharding cannot pay (DESIGN 5)
