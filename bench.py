@@ -40,14 +40,14 @@ METRIC = "reconstructed frames/sec + MS/s IQ ingest, 1080p60 leak @ 20 MS/s, 1/2
 NPX = 600 * 800
 
 
-def measured_traffic(workload, kernel):
+def measured_traffic(workload, kernel, key="hbm_bytes_per_launch"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE
     doubled per the gfx950 note + WRITE_SIZE, collected on this bench command by tools/collect_profiles.sh).  PMC
     counters cannot be read from inside the process being profiled, so this is the one number of the line that is
     not measured live; None if the file has no entry."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return t.get(workload, {}).get(kernel, {}).get("hbm_bytes_per_launch")
+        return t.get(workload, {}).get(kernel, {}).get(key)
     except Exception:
         return None
 
@@ -352,6 +352,10 @@ def main():
     k_hi = int(round(0.1 * Fs))
     try:
         search = par.bench_search(ctx, iq0, n_ac, k_hi, Fs, args.search_steps, world, rank, dev)
+        tr = measured_traffic(args.workload, "search", key="hbm_bytes_per_search")
+        if tr:
+            search["traffic"] = tr
+            search["traffic_over_algorithmic"] = round(tr / search["algorithmic_bytes"], 2)
     except Exception as e:  # the frame number above stays valid; say what failed
         search = {"error": f"{type(e).__name__}: {e}"}
 

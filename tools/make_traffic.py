@@ -29,6 +29,22 @@ def collect(d, counter):
     return {k: statistics.median(v) for k, v in out.items()}
 
 
+def search_totals(d, counter):
+    """HBM-side bytes of ONE configuration search: every FFT / autocorrelation / argmax launch of the run summed, divided
+    by the number of searches (= k_argmax launches).  --quick runs only the headline workload's search."""
+    tot, n = 0.0, 0
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"]
+            if "k_fft_" in k or "k_ac_" in k or "k_argmax" in k:
+                tot += float(r["Counter_Value"])
+            if "k_argmax" in k:
+                n += 1
+    return (tot / n if n else 0.0), n
+
+
 def main():
     fdir, wdir, tag = sys.argv[1:4]
     wl = sys.argv[4] if len(sys.argv) > 4 else "C2"
@@ -47,6 +63,11 @@ def main():
     for k in sorted(set(f) | set(w)):
         fk, wk = f.get(k, 0.0), w.get(k, 0.0)
         doc[wl][k] = {"fetch_size_kb": round(fk), "write_size_kb": round(wk), "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)}
+    fs, ns = search_totals(fdir, "FETCH_SIZE")
+    ws, _ = search_totals(wdir, "WRITE_SIZE")
+    if ns:
+        doc[wl]["search"] = {"fetch_size_kb": round(fs), "write_size_kb": round(ws), "hbm_bytes_per_search": int(fs * 1024 * 2 + ws * 1024),
+                             "searches": ns, "note": "all FFT passes + argmax of one configuration search (fused loaders / epilogue: no other kernels)"}
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc[wl], indent=1))
 
