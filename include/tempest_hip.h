@@ -160,7 +160,11 @@ int tsdr_autocorr_partial_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, 
 int tsdr_autocorr_finish_d(tsdr_ctx *ctx, const float *corr, size_t k0, size_t cnt, int log_scale, float *out);
 /* zoom_autocorr index window (1-based, inclusive)           Autocorrelations.jl:42-53 */
 int tsdr_zoom_bounds(size_t N, double Fs, double rate_min, double rate_max, size_t *pmin, size_t *pmax);
-/* findmax over a device vector: first maximum, 0-based index   GUI.jl:79 */
+/* findmax over a device vector: first maximum, 0-based index   GUI.jl:79
+ * Blocking: returns when the result has arrived.  It arrives in pinned host memory, written by the kernel itself, and
+ * the calling thread polls for it (a few microseconds after the kernel's last store) instead of sleeping in a stream
+ * synchronisation, whose wake-up costs 0.1-0.4 ms once the work queued before it is longer than a few hundred
+ * microseconds; everything enqueued on the context's stream before the call has completed when it returns. */
 int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *val);
 
 /* ---- GetSpectrum.jl --------------------------------------------------------------- */
