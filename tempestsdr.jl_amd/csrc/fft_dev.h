@@ -8,12 +8,24 @@ namespace tsdr {
 
 enum { FFT_STRIDED = 0, FFT_LAST = 1, FFT_ROWS = 2 };
 
-// (explicit FMAs: the library is built with -ffp-contract=off for the bit-exact kernels, and the passes are VALU-bound)
+// Complex arithmetic on the packed-f32 pipe (v_pk_*_f32: two f32 lanes per instruction at the rate of one): the FFT
+// kernels issue VALU instructions 70 % of the time, and a complex product is two instructions this way instead of four
+// (six without explicit FMAs -- the library is built with -ffp-contract=off for the bit-exact kernels).  The compiler
+// finds the packed add on its own but not the product's source modifiers: t = (-a.y b.y, a.y b.x) takes the high half of
+// a twice, b swapped with its new low half negated; r = (a.x, a.x) * b + t.  Same roundings as
+// (fma(a.x, b.x, -(a.y b.y)), fma(a.x, b.y, a.y b.x)).
+typedef float tsdr_v2f __attribute__((ext_vector_type(2)));
+__device__ inline tsdr_v2f c2v(float2 a) { return tsdr_v2f{a.x, a.y}; }
+__device__ inline float2 v2c(tsdr_v2f a) { return make_float2(a.x, a.y); }
 __device__ inline float2 cmul(float2 a, float2 b) {
-  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+  const tsdr_v2f av = c2v(a), bv = c2v(b);
+  tsdr_v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(av), "v"(bv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  return v2c(r);
 }
-__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cadd(float2 a, float2 b) { return v2c(c2v(a) + c2v(b)); }
+__device__ inline float2 csub(float2 a, float2 b) { return v2c(c2v(a) - c2v(b)); }
 __device__ inline float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 
 // Forward DFT of N = 2, 4, 8 or 16 points held in registers: radix-2 decimation in frequency with the
