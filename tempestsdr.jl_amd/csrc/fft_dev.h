@@ -27,6 +27,29 @@ __device__ inline float2 cmul(float2 a, float2 b) {
 __device__ inline float2 cadd(float2 a, float2 b) { return v2c(c2v(a) + c2v(b)); }
 __device__ inline float2 csub(float2 a, float2 b) { return v2c(c2v(a) - c2v(b)); }
 __device__ inline float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// p - i q = (p.x + q.y, p.y - q.x) and p + i q = (p.x - q.y, p.y + q.x): one packed add with q's halves swapped and one
+// of them negated by source modifiers
+__device__ inline float2 cadd_mi(float2 p, float2 q) {
+  tsdr_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c2v(p)), "v"(c2v(q)));
+  return v2c(r);
+}
+__device__ inline float2 cadd_pi(float2 p, float2 q) {
+  tsdr_v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(c2v(p)), "v"(c2v(q)));
+  return v2c(r);
+}
+// a * s and a * s + c for a real s (both halves by the same factor)
+__device__ inline float2 cscale(float2 a, float s) { return v2c(c2v(a) * tsdr_v2f{s, s}); }
+__device__ inline float2 cfma_s(float2 a, float s, float2 c) { return v2c(__builtin_elementwise_fma(c2v(a), tsdr_v2f{s, s}, c2v(c))); }
+// a * (kr + i ki) for a compile-time constant: the constant sits in a scalar register pair (no VGPRs, no per-use moves)
+__device__ inline float2 cmul_k(float2 a, float kr, float ki) {
+  const tsdr_v2f av = c2v(a), kv = tsdr_v2f{kr, ki};
+  tsdr_v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(av), "s"(kv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(av), "s"(kv), "v"(t));
+  return v2c(r);
+}
 
 // Forward DFT of N = 2, 4, 8 or 16 points held in registers: radix-2 decimation in frequency with the
 // twiddles as literals (trivial ones special-cased), result in bit-reversed order (X[k] at v[brev<N>(k)]).
@@ -43,11 +66,11 @@ __device__ inline float2 mul_w(float2 d) {  // d * exp(-2*pi*i*I/N), 0 <= I < N/
   } else if constexpr (E == 4) {
     return make_float2(d.y, -d.x);
   } else if constexpr (E == 2) {
-    return make_float2((d.x + d.y) * kCos16[2], (d.y - d.x) * kCos16[2]);
+    return cscale(cadd_mi(d, d), kCos16[2]);    // ((d.x + d.y), (d.y - d.x)) / sqrt 2
   } else if constexpr (E == 6) {
-    return make_float2((d.y - d.x) * kCos16[2], -(d.x + d.y) * kCos16[2]);
+    return cscale(cadd_pi(d, d), -kCos16[2]);   // ((d.y - d.x), -(d.x + d.y)) / sqrt 2
   } else {
-    return make_float2(fmaf(d.x, kCos16[E], d.y * kSin16[E]), fmaf(d.y, kCos16[E], -(d.x * kSin16[E])));
+    return cmul_k(d, kCos16[E], -kSin16[E]);
   }
 }
 

@@ -86,7 +86,7 @@ __device__ inline float2 mul_c(float2 x) {
   } else {
     constexpr float c = N == 25 ? kCos25[K] : N == 20 ? kCos20[K] : N == 10 ? kCos10[K] : kCos9[K];
     constexpr float sn = N == 25 ? kSin25[K] : N == 20 ? kSin20[K] : N == 10 ? kSin10[K] : kSin9[K];
-    return make_float2(fmaf(x.x, c, x.y * sn), fmaf(x.y, c, -(x.x * sn)));
+    return cmul_k(x, c, -sn);
   }
 }
 
@@ -127,24 +127,25 @@ __device__ inline void dft_nat(float2 *x) {
   if constexpr (r == 3) {
     const float s = 0.86602540378443865f;
     const float2 t = cadd(x[1], x[2]), d = csub(x[1], x[2]);
-    const float2 m = make_float2(fmaf(-0.5f, t.x, x[0].x), fmaf(-0.5f, t.y, x[0].y));
-    const float2 q = make_float2(s * d.y, -s * d.x);  // -i*s*d
+    const float2 m = cfma_s(t, -0.5f, x[0]);
+    const float2 q = cscale(d, s);
     x[0] = cadd(x[0], t);
-    x[1] = cadd(m, q);
-    x[2] = csub(m, q);
+    x[1] = cadd_mi(m, q);  // m - i s d
+    x[2] = cadd_pi(m, q);
   } else if constexpr (r == 5) {
     const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
     const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
     const float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]), b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
-    const float2 p1 = make_float2(x[0].x + fmaf(c1, a1.x, c2 * a2.x), x[0].y + fmaf(c1, a1.y, c2 * a2.y));
-    const float2 p2 = make_float2(x[0].x + fmaf(c2, a1.x, c1 * a2.x), x[0].y + fmaf(c2, a1.y, c1 * a2.y));
-    const float2 q1 = make_float2(fmaf(s1, b1.x, s2 * b2.x), fmaf(s1, b1.y, s2 * b2.y));
-    const float2 q2 = make_float2(fmaf(s2, b1.x, -(s1 * b2.x)), fmaf(s2, b1.y, -(s1 * b2.y)));
+    // (packed: every line below is one instruction per complex value)
+    const float2 p1 = cadd(x[0], cfma_s(a1, c1, cscale(a2, c2)));
+    const float2 p2 = cadd(x[0], cfma_s(a1, c2, cscale(a2, c1)));
+    const float2 q1 = cfma_s(b1, s1, cscale(b2, s2));
+    const float2 q2 = cfma_s(b1, s2, cscale(b2, -s1));
     x[0] = cadd(x[0], cadd(a1, a2));
-    x[1] = make_float2(p1.x + q1.y, p1.y - q1.x);  // p1 - i q1
-    x[4] = make_float2(p1.x - q1.y, p1.y + q1.x);
-    x[2] = make_float2(p2.x + q2.y, p2.y - q2.x);
-    x[3] = make_float2(p2.x - q2.y, p2.y + q2.x);
+    x[1] = cadd_mi(p1, q1);  // p1 - i q1
+    x[4] = cadd_pi(p1, q1);
+    x[2] = cadd_mi(p2, q2);
+    x[3] = cadd_pi(p2, q2);
   } else if constexpr (r == 25) {
     dft_two_step<5, 5>(x);
   } else if constexpr (r == 20) {
