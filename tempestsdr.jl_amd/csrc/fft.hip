@@ -299,7 +299,7 @@ static fft_pass_fn pass_fn(int logR) {
 static const size_t kPassLds = (4096 + 256 + 16 + 256 + 256) * sizeof(float2);
 
 // ---- twiddle tables ------------------------------------------------------------------------
-static int ensure_tw_small(tsdr_ctx *ctx) {
+int ensure_tw_small(tsdr_ctx *ctx) {  // W_4096^e, e < 4096 (ctx->tw_small)
   if (ctx->tw_small) return TSDR_OK;
   std::vector<float2> h(4096);
   for (int e = 0; e < 4096; ++e) {

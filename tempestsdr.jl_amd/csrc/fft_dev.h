@@ -244,6 +244,7 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
               size_t src_n, size_t keep, const FftEpilogue *epi = nullptr, const float2 *src_aux = nullptr);
 bool fft_mixed_ok(size_t N);
-int fft_passes(size_t N);  // launches a length-N transform takes (0: not a 2^a 3^b 5^c length)
+int fft_passes(size_t N);
+int ensure_tw_small(tsdr_ctx *ctx);  // builds ctx->tw_small: W_4096^e for e < 4096  // launches a length-N transform takes (0: not a 2^a 3^b 5^c length)
 
 }  // namespace tsdr

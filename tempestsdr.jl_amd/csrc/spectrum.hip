@@ -292,6 +292,76 @@ __global__ __launch_bounds__(256) void k_real_scale(const float2 *__restrict__ c
     out[k] = g * c[k].x;
 }
 
+// ---- resampler! at sizeFFT = 4096 (the size production/test_resampler.jl times: 1024 samples, upCoeff 4) in ONE
+// workgroup: zero-stuffed load, 4096-point transform, filter, inverse transform and 2*up*real(.) without leaving the
+// CU -- four launches of a few microseconds each become one.
+// 4096 = 16 x 16 x 16 over 256 threads x 16 values.  With n = t0 + 16 t1 + 256 m (t = t0 + 16 t1 the thread) and
+// k = ka + 16 kb + 256 kc:
+//   A  thread t:        DFT16 over m,  * W_4096^(t ka)          -> Z1[ka][t]
+//   B  thread (ka, t0): DFT16 over t1, * W_256^(t0 kb)          -> Z2[ka][kb][t0]   (rows padded to 17: conflict-free)
+//   C  thread (ka, kb): DFT16 over t0  -> X[ka + 16 kb + 256 kc] -> natural order in LDS -> thread t takes X[t + 256 m]
+// so input and output have the same distribution and the routine runs twice (the inverse as conj . forward . conj).
+__device__ inline void wg_fft4096(float2 (&v)[16], float2 *z, const float2 (&twA)[16], const float2 (&twB)[16], int tid) {
+  reg_dft<16>(v);
+#pragma unroll
+  for (int ka = 0; ka < 16; ++ka) {
+    float2 x = v[brev<16>(ka)];
+    if (ka) x = cmul(x, twA[ka]);
+    z[ka * 256 + tid] = x;
+  }
+  __syncthreads();
+  const int hi = tid >> 4, lo = tid & 15;  // stage B: (ka, t0)
+#pragma unroll
+  for (int t1 = 0; t1 < 16; ++t1) v[t1] = z[hi * 256 + lo + 16 * t1];
+  reg_dft<16>(v);
+  __syncthreads();
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {
+    float2 x = v[brev<16>(kb)];
+    if (kb) x = cmul(x, twB[kb]);
+    z[(hi * 16 + kb) * 17 + lo] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t0 = 0; t0 < 16; ++t0) v[t0] = z[tid * 17 + t0];  // stage C: thread = (ka, kb) = (tid >> 4, tid & 15)
+  reg_dft<16>(v);
+  __syncthreads();
+#pragma unroll
+  for (int kc = 0; kc < 16; ++kc) z[hi + 16 * lo + 256 * kc] = v[brev<16>(kc)];  // k = ka + 16 kb + 256 kc
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 16; ++m) v[m] = z[tid + 256 * m];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_resample4096(const float *__restrict__ in, unsigned up, const float2 *__restrict__ H,
+                                                      const float2 *__restrict__ tw4096, float gain, float *__restrict__ out) {
+  __shared__ float2 z[256 * 17];
+  const int tid = threadIdx.x;
+  float2 twA[16], twB[16];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    twA[k] = tw4096[tid * k];               // W_4096^(t ka)
+    twB[k] = tw4096[((tid & 15) * k) << 4];  // W_256^(t0 kb)
+  }
+  float2 v[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {  // zero-stuffed input: x[n] = in[n / up] when up divides n
+    const unsigned n = (unsigned)tid + 256u * (unsigned)m, q = n / up;
+    v[m] = q * up == n ? make_float2(in[q], 0.0f) : make_float2(0.0f, 0.0f);
+  }
+  wg_fft4096(v, z, twA, twB, tid);
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {  // filter, and conj for the inverse transform
+    const float2 y = cmul(v[m], H[tid + 256 * m]);
+    v[m] = make_float2(y.x, -y.y);
+  }
+  wg_fft4096(v, z, twA, twB, tid);
+  const float inv = 1.0f / 4096.0f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) out[tid + 256 * m] = gain * (v[m].x * inv);  // real(conj(.)) = real(.): ifft scale, then 2*up
+}
+
 static int spectrum_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int lin, float *y) {
   if (N == 0) return TSDR_OK;
   float2 *X = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
@@ -482,6 +552,13 @@ int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float 
   const size_t N = r->sizeFFT;
   float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
   if (!tmp) return TSDR_ENOMEM;
+  if (N == 4096) {  // one workgroup, one launch
+    int rc = ensure_tw_small(ctx);
+    if (rc) return rc;
+    TSDR_LAUNCH(ctx, "resampler_4096", k_resample4096, dim3(1), dim3(256), 0, in, (unsigned)r->up, (const float2 *)r->H,
+                (const float2 *)ctx->tw_small, (float)(2 * r->up), out);
+    return TSDR_OK;
+  }
   const int passes = fft_passes(N);
   if (passes >= 2) {
     // two transforms and nothing else: the zero-stuffing is the forward transform's loader, the filter the inverse

@@ -248,7 +248,8 @@ def test_welch_waterfall_c2_buffer(ctx):
 # ------------------------------------------------------------------ init_resampler
 # (1000, 4) / (100000, 5): mixed-radix passes with fused loaders and epilogue; (1024, 2) / (4096, 8): the power-of-two
 # engine's; (64, 2): one pass, separate kernels; (999, 3): Bluestein
-@pytest.mark.parametrize("bufferSize,up", [(1000, 4), (1024, 2), (999, 3), (64, 2), (4096, 8), (100000, 5), (625, 3)])
+@pytest.mark.parametrize("bufferSize,up", [(1000, 4), (1024, 2), (999, 3), (64, 2), (4096, 8), (100000, 5), (625, 3), (1024, 4), (512, 8),
+                                           (2048, 2)])  # the last three: sizeFFT = 4096, one workgroup
 def test_init_resampler(ctx, bufferSize, up):
     r, o = ctx.init_resampler(np.float32, bufferSize, up), O.Resampler(bufferSize, up)
     H, Ho = r.lpf(), o.lpf()
