@@ -223,13 +223,19 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
                   float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                   int *sync_idx, int *n_frames);
 
-/* The same per-buffer body as a two-stage pipeline for callers that stream successive buffers (the GUI loop of
- * GUI.jl:150-178 does: one buffer after the other from the SDR): the raster stage of buffer k+1 runs while the
- * vsync/shift/IIR stage of buffer k is still in flight.  submit only enqueues (on two internal streams, ordered
- * after everything already enqueued on the context's stream); the outputs of every submitted buffer are complete,
- * in stream order, after tsdr_frames_flush (or tsdr_synchronize).  Results are identical to calling tsdr_frames_d
- * once per buffer.  Until the flush, the caller must not touch iq, the state or the output buffers of submitted
- * work, and each in-flight buffer needs its own frames_out / raster_out / sync_idx. */
+/* The same per-buffer body software-pipelined for callers that stream successive buffers (the GUI loop of
+ * GUI.jl:150-178 does: one buffer after the other from the SDR).  ONE stream, no internal streams or events:
+ * submit(k) enqueues the raster stage of buffer k and then ONE launch that carries the vsync statistics of buffer k
+ * together with shift + IIR of buffer k-1; the shift + IIR stage of the LAST submitted buffer stays deferred until
+ * the next submission, tsdr_frames_flush or tsdr_synchronize enqueues it.  So the outputs of every submitted buffer
+ * are complete, in stream order, after tsdr_frames_flush -- which only enqueues -- and on the host after
+ * tsdr_synchronize, which drains the deferred stage itself.  Any other entry point that uses the same SyncXY state or
+ * image slots (tsdr_frames_d, tsdr_frames_scan_d / _combine_d, tsdr_vsync_d, tsdr_sync_reset / _free, tsdr_set_stream,
+ * tsdr_dev_free, tsdr_destroy) enqueues the deferred stage first, so results never depend on the mix of calls.
+ * Results are identical to calling tsdr_frames_d once per buffer.
+ * Lifetime: until the deferred stage has been enqueued AND has completed, the caller must not touch or free iq, the
+ * SyncXY state, imageOut_state, frames_out / raster_out / sync_idx of submitted work (the library keeps the pointers
+ * of the last submission), and each in-flight buffer needs its own frames_out / raster_out / sync_idx. */
 int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                          int *sync_idx, int *n_frames);

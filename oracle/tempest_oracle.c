@@ -541,8 +541,8 @@ const float *orc_sync_beta_y(const orc_sync *s) { return s->beta_y; }
  *                         => sum_rows() below, and the GPU reproduces it operation for operation.
  *                         (Compile with -DORC_ROWSUM_CHUNK8 for the round-1 order -- 8 column chunks
  *                         accumulated in order and added left to right -- kept only so that the
- *                         effect of the choice can be measured; build flag of the same name in
- *                         tempestsdr.jl_amd/build.py selects the matching GPU order.)
+ *                         effect of the choice can be measured; TSDR_BUILD_DEFINES=TSDR_ROWSUM_CHUNK8
+ *                         in the environment of tempestsdr.jl_amd/build.py selects the matching GPU order.)
  *   sum(image;dims=1)  -> the `reducedim1` branch: per column, `@simd for i; r = r + A[i,j]`.  Here
  *                         @simd licenses re-association of the single accumulator, so the order
  *                         depends on the vector width LLVM picks for the host CPU: no order is "the"
@@ -618,7 +618,8 @@ static void project_sums(const float *img, int y, int x, float *cv, float *ch) {
  * with zero initial state and length(out) == length(x)].  muladd on Float32 lowers to a fused
  * multiply-add on every CPU Julia supports with FMA hardware (x86-64 Haswell+, AArch64), so the
  * chain is restated with fmaf.  -DORC_FIR_NOFMA gives the unfused form (DSP.jl <= 0.6, or a
- * machine without FMA); the build flag of the same name selects the matching GPU code. */
+ * machine without FMA); TSDR_BUILD_DEFINES=TSDR_FIR_NOFMA (tempestsdr.jl_amd/build.py) selects the
+ * matching GPU code. */
 static void fir_filt(const float *h, int nh, const float *x, int n, float *y) {
   float si[8] = {0};
   for (int i = 0; i < n; i++) {

@@ -18,6 +18,10 @@ LIB = os.path.join(HERE, "libtempest_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
+# Measurement-only alternatives of two reduction orders (see oracle/tempest_oracle.c "summation orders"; the oracle is
+# built with -DORC_ROWSUM_CHUNK8 / -DORC_FIR_NOFMA to match):
+#   TSDR_BUILD_DEFINES="TSDR_ROWSUM_CHUNK8 TSDR_FIR_NOFMA" python tempestsdr.jl_amd/build.py --force
+FLAGS += ["-D" + d for d in os.environ.get("TSDR_BUILD_DEFINES", "").split()]
 
 
 def _stale(target, deps):

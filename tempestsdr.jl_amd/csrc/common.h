@@ -99,6 +99,8 @@ namespace tsdr {
 
 int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...);
 int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what);
+// frames.hip: enqueue the deferred shift + IIR of the software pipeline (tsdr_frames_submit_d), if any
+int pipe_drain(tsdr_ctx *ctx);
 void prof_begin(tsdr_ctx *ctx, const char *name);
 void prof_end(tsdr_ctx *ctx);
 

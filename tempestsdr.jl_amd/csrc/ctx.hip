@@ -130,6 +130,7 @@ tsdr_ctx *tsdr_create(int device) {
 void tsdr_destroy(tsdr_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  (void)tsdr::pipe_drain(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
   for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -148,6 +149,10 @@ void tsdr_destroy(tsdr_ctx *ctx) {
 
 int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream) {
   if (!ctx) return TSDR_EINVAL;
+  {  // the pipeline's deferred stage belongs to the old stream
+    int rc = tsdr::pipe_drain(ctx);
+    if (rc) return rc;
+  }
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (hip_stream) {
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -179,6 +184,10 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
 
 int tsdr_synchronize(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;
+  {  // outputs of every submitted buffer are complete after this call (header contract)
+    int rc = tsdr::pipe_drain(ctx);
+    if (rc) return rc;
+  }
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TSDR_OK;
 }
@@ -205,7 +214,12 @@ void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes) {
 
 int tsdr_dev_free(tsdr_ctx *ctx, void *dev) {
   if (!ctx) return TSDR_EINVAL;
-  if (dev) { TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream)); TSDR_HIP(ctx, hipFree(dev)); }
+  if (dev) {
+    int rc = tsdr::pipe_drain(ctx);  // the deferred pipeline stage may still have to write into this buffer
+    if (rc) return rc;
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TSDR_HIP(ctx, hipFree(dev));
+  }
   return TSDR_OK;
 }
 

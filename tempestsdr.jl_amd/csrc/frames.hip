@@ -39,8 +39,6 @@ using namespace tsdr;
 
 extern "C" {
 
-static int pipe_drain(tsdr_ctx *ctx);
-
 static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
   if (!do_align) return TSDR_OK;
   if (!sync) return set_err(ctx, TSDR_EINVAL, "do_align needs a SyncXY state");
@@ -91,6 +89,8 @@ int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t n
   if (nEch && !iq) return TSDR_EINVAL;
   int rc = frames_check(ctx, sync, do_align);
   if (rc) return rc;
+  rc = pipe_drain(ctx);  // a pipelined submission on this context comes first (its SyncXY / image slots are in use)
+  if (rc) return rc;
   const size_t nb = nEch / S;
   if (nb > (size_t)1 << 20) return set_err(ctx, TSDR_EINVAL, "too many frames in one buffer");
   if (n_frames) *n_frames = (int)nb;
@@ -105,6 +105,8 @@ int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, cons
                           float alpha, int do_align, float *imageOut_state, float *frames_out, int *sync_idx) {
   if (!ctx || !imageOut_state || n_frames < 0) return TSDR_EINVAL;
   int rc = frames_check(ctx, sync, do_align);
+  if (rc) return rc;
+  rc = pipe_drain(ctx);
   if (rc) return rc;
   if (n_frames == 0) return TSDR_OK;
   if (!img || (do_align && !keys)) return TSDR_EINVAL;
@@ -149,6 +151,9 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
 // Tried on MI355X and dropped: R on one stream with B + C (0.198 vs 0.183 ms per buffer: the two memory-bound
 // launches slow each other down) or B alone (0.196 vs 0.175 ms) on a second stream -- an event hand-over between two
 // HIP streams costs 6-13 us on this stack, more than B is long.
+}  // extern "C"
+
+namespace tsdr {
 static int pipe_combine_pending(tsdr_ctx *ctx) {
   tsdr_ctx::PipePending &p = ctx->pipe_pending;
   if (!p.valid) return TSDR_OK;
@@ -159,14 +164,19 @@ static int pipe_combine_pending(tsdr_ctx *ctx) {
   return TSDR_OK;
 }
 
-// everything submitted so far is enqueued; the stream then holds all of it
-static int pipe_drain(tsdr_ctx *ctx) {
-  if (ctx->pipe_n == 0) return TSDR_OK;
+// everything submitted so far is enqueued; the stream then holds all of it.  Every entry point that synchronises,
+// retargets or destroys the context, or that touches a SyncXY state / the IIR state outside the pipeline, calls this
+// first, so the deferred shift + IIR never runs out of order or on freed memory.
+int pipe_drain(tsdr_ctx *ctx) {
+  if (!ctx || ctx->pipe_n == 0) return TSDR_OK;
   int rc = pipe_combine_pending(ctx);
   if (rc) return rc;
   ctx->pipe_n = 0;
   return TSDR_OK;
 }
+}  // namespace tsdr
+
+extern "C" {
 
 int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,

@@ -743,6 +743,10 @@ int tsdr_sync_create(tsdr_ctx *ctx, int y_t, int x_t, tsdr_sync **out) {
 int tsdr_sync_reset(tsdr_sync *s) {
   if (!s) return TSDR_EINVAL;
   tsdr_ctx *ctx = s->ctx;
+  {  // a pipelined submission still owes this state its shift + IIR stage
+    int rc = pipe_drain(ctx);
+    if (rc) return rc;
+  }
   const size_t nbx = (size_t)(1 + s->wmax_x - s->wmin_x) * s->x_t, nby = (size_t)(1 + s->wmax_y - s->wmin_y) * s->y_t;
   TSDR_HIP(ctx, hipMemsetAsync(s->beta_x, 0, nbx * 4, ctx->stream));
   TSDR_HIP(ctx, hipMemsetAsync(s->beta_y, 0, nby * 4, ctx->stream));
@@ -755,7 +759,10 @@ int tsdr_sync_reset(tsdr_sync *s) {
 
 void tsdr_sync_free(tsdr_sync *s) {
   if (!s) return;
-  if (s->ctx) (void)hipStreamSynchronize(s->ctx->stream);
+  if (s->ctx) {
+    (void)pipe_drain(s->ctx);  // the deferred stage reads this state's pending s_y: enqueue it before the state goes
+    (void)hipStreamSynchronize(s->ctx->stream);
+  }
   if (s->beta_x) (void)hipFree(s->beta_x);
   if (s->beta_y) (void)hipFree(s->beta_y);
   if (s->pending) (void)hipFree(s->pending);
@@ -771,6 +778,10 @@ int tsdr_sync_bounds(const tsdr_sync *s, int b[4]) {
 int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   if (!s || !img) return TSDR_EINVAL;
   tsdr_ctx *ctx = s->ctx;
+  {
+    int rc = pipe_drain(ctx);
+    if (rc) return rc;
+  }
   float *proj = nullptr;
   unsigned long long *keys = nullptr;
   int rc = sync_workspace(s, 1, 0, 1, nullptr, &proj, &keys);

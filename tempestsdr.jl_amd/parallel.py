@@ -82,9 +82,15 @@ def _is_235_smooth(v):
     return v == 1
 
 
-def single_route_points(n):
-    """complex points per transform of the single-GPU autocorrelation of n real samples (autocorr.hip): the native
-    length-n/2 mixed-radix route when n/2 = 2^a 3^b 5^c, else the zero-padded power of two (real-packed)."""
+def single_route_points(n, n_lags=None):
+    """complex points per transform of the route HipSearch.run takes on ONE GPU for n real samples and n_lags lags.
+    n <= 2 n_lags (the reference's own window, Autocorrelations.jl:27) runs the fused circular autocorrelation
+    (autocorr.hip): the native length-n/2 mixed-radix route when n/2 = 2^a 3^b 5^c, else the zero-padded power of two
+    (real-packed).  Longer windows run the partial-sum kernel over the whole range: a zero-padded cross-correlation of
+    n + n_lags - 1 points."""
+    n = int(n)
+    if n_lags is not None and n > 2 * int(n_lags):
+        return _pow2_at_least(n + int(n_lags) - 1)
     if n % 2 == 0 and n > 1024 and _is_235_smooth(n // 2):
         return n // 2
     return _pow2_at_least(2 * n) // 2
@@ -103,7 +109,7 @@ def search_route(n, n_lags, world):
     single-GPU route on its own copy (no collective, identical results on all ranks)."""
     if world <= 1:
         return "single"
-    return "sharded" if sharded_route_points(n, n_lags, world) < single_route_points(n) else "replicated"
+    return "sharded" if sharded_route_points(n, n_lags, world) < single_route_points(n, n_lags) else "replicated"
 
 
 class HipSearch:
@@ -199,13 +205,15 @@ def bench_search(ctx, iq, n, n_lags, Fs, steps, world, rank, dev):
     alg = 8 * n + 4 * n_lags                  # SURVEY 8d B_ac
     return {"ms_per_search": round(ms, 4), "n": int(n), "lags": int(n_lags), "fv_found_hz": round(fv, 4),
             "algorithmic_bytes": alg, "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
-            "transform_points": single_route_points(n),
-            "mode": (("single-GPU, native length-n/2 mixed-radix transform" if single_route_points(n) == n // 2 else
-                      "single-GPU, zero-padded power-of-two real FFT") if world == 1 else
+            "transform_points": single_route_points(n, n_lags),
+            "mode": ((("single-GPU, native length-n/2 mixed-radix transform" if single_route_points(n, n_lags) == n // 2 else
+                       "single-GPU, zero-padded power-of-two real FFT") if n <= 2 * n_lags else
+                      "single-GPU, partial-sum cross-correlation of the whole range (window longer than twice the lag range)")
+                     if world == 1 else
                      (f"sharded over {world} GPUs: segment+halo partial sums ({sharded_route_points(n, n_lags, world)}-point "
                       f"transforms), all-reduce of {4 * n_lags} B" if route == "sharded" else
                       f"replicated on {world} GPUs: a rank's segment+halo transform ({sharded_route_points(n, n_lags, world)} points) "
-                      f"would not be smaller than the single-GPU one ({single_route_points(n)} points), so no collective is used")),
+                      f"would not be smaller than the single-GPU one ({single_route_points(n, n_lags)} points), so no collective is used")),
             "includes": "abs2, FFT autocorrelation, 10log10(abs2), zoom argmax with host readback"}
 
 

@@ -122,7 +122,7 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
     P, npx = x_t * y_t, 600 * 800
     bufs = [synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 7, n0=b * (S * nfr + 7)) for b in range(nbuf)]
 
-    def run(pipelined):
+    def run(pipelined, flush=True):
         sync = tsdr.SyncXY(ctx, 600, 800)
         d_state = ctx.upload(np.zeros(npx, np.float32))
         d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
@@ -134,20 +134,58 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
                 f = api.frames_submit_d if pipelined else api.frames_d
                 n = f(ctx, sync, d_iq[b], bufs[b].size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr[b], d_ra[b], d_ix[b])
                 assert n == nfr
-            if pipelined:
+            if pipelined and flush:
                 api.frames_flush(ctx)
-            ctx.synchronize()
+            ctx.synchronize()  # header contract: complete after tsdr_synchronize even without a flush
             return ([ctx.download(p, (nfr * npx,), np.uint32) for p in d_fr], [ctx.download(p, (nfr * P,), np.uint32) for p in d_ra],
                     [ctx.download(p, (nfr * 2,), np.int32) for p in d_ix], ctx.download(d_state, (npx,), np.uint32))
         finally:
             for p in [d_state] + d_iq + d_fr + d_ra + d_ix:
                 ctx.dev_free(p)
 
+    a = run(False)
+    for b in (run(True), run(True, flush=False)):
+        for k in range(3):
+            for x, y in zip(a[k], b[k]):
+                assert np.array_equal(x, y)
+        assert np.array_equal(a[3], b[3])
+
+
+def test_pipeline_pending_stage_is_drained_by_other_entry_points(ctx, tsdr, synth):
+    """The shift + IIR stage of the last submitted buffer is deferred.  Entry points that use the same SyncXY / IIR
+    state outside the pipeline (tsdr_vsync_d here, tsdr_frames_d) and tsdr_sync_free must enqueue it first: the results
+    equal the strictly sequential ones and nothing runs on freed memory."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y_t, fv, nfr = 2.0e6, 1056, 628, 60.0, 3
+    S = synth.samples_per_frame(Fs, fv)
+    npx = 600 * 800
+    buf = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr)
+    img = np.asfortranarray(rng.random((600, 800)).astype(np.float32))
+
+    def run(pipelined):
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_iq = ctx.upload(buf.view(np.float32))
+        d_fr, d_ix = ctx.dev_alloc(nfr * npx * 4), ctx.dev_alloc(nfr * 8)
+        try:
+            f = api.frames_submit_d if pipelined else api.frames_d
+            f(ctx, sync, d_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, None, d_ix)
+            s_yx = sync.vsync(img)          # consumes the pending s_y of the submitted buffer: must come after its stage
+            ctx.synchronize()
+            out = (ctx.download(d_fr, (nfr * npx,), np.uint32), ctx.download(d_ix, (nfr * 2,), np.int32),
+                   ctx.download(d_state, (npx,), np.uint32), tuple(int(v) for v in s_yx))
+            f(ctx, sync, d_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, None, d_ix)
+            sync.close()                    # frees the state with a stage still deferred
+            ctx.synchronize()
+            return out
+        finally:
+            for p in (d_state, d_iq, d_fr, d_ix):
+                ctx.dev_free(p)
+
     a, b = run(False), run(True)
-    for k in range(3):
-        for x, y in zip(a[k], b[k]):
-            assert np.array_equal(x, y)
-    assert np.array_equal(a[3], b[3])
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert a[3] == b[3]
 
 
 @pytest.mark.parametrize("seed", [11, 12])

@@ -282,3 +282,9 @@ def test_search_route_choice():
     # a window much longer than the lag range does shard
     assert par.search_route(16_000_000, 500_000, 8) == "sharded"
     assert par.sharded_route_points(16_000_000, 500_000, 8) == 4_194_304
+    # the model follows the route HipSearch.run actually takes: a window longer than 2 * n_lags runs the partial-sum
+    # cross-correlation over the whole range on one GPU (pow2(n + n_lags - 1) points), so sharding it does pay
+    assert par.single_route_points(240_000, 60_000) == 524_288
+    assert par.sharded_route_points(240_000, 60_000, 2) == 262_144
+    for world in (2, 4, 8):
+        assert par.search_route(240_000, 60_000, world) == "sharded"
