@@ -69,7 +69,12 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
  *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp): pixels within ~3 ulp
  *               (4e-7 relative) of TSDR_EXACT; ~2.5x fewer VALU cycles.  Default.  The images' projection
  *               sums are then formed inside the raster kernel (per-tile partial sums, added in tile order)
- *               instead of by a second pass over the images in the reference's row order.
+ *               instead of by a second pass over the images in the reference's row order, so beta differs from
+ *               the reference's at the 1e-7 level.  FRAME-SYNC INDICES ARE NEVERTHELESS THE REFERENCE'S: the
+ *               sync guard re-evaluates, in the TSDR_EXACT operation sequence (image, projections, beta scan),
+ *               every frame whose best blank-band column leads the best other column by less than the guard
+ *               threshold (relative; default 2e-5, option "sync_guard_ppb") on either axis; such a frame
+ *               carries TSDR_EXACT pixels.  tsdr_sync_guard_stats reports how often that happened.
  * The mode applies ONLY to tsdr_frames / _d / _submit_d / _scan_d.  The per-function entry points
  * (tsdr_sig_to_image, tsdr_resize1d/2d, tsdr_downgrade, tsdr_vsync, ... and their _d forms) always run
  * the TSDR_EXACT operation sequence.  Shift + IIR are evaluated identically in both modes. */
@@ -80,8 +85,17 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *   "ac_mixed"    1 (default): calculate_autocorrelation of n = 2*(2^a 3^b 5^c) samples runs the native length-n/2
  *                 mixed-radix transform; 0: zero-padded power-of-two transform + fold.
  *   "fft_no_mix2" 1: every mixed-radix factor goes through the generic LDS-stage kernel.  Default 0.
- * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 preset them, read once in tsdr_create. */
+ *   "sync_guard_ppb"  sync-guard threshold of the TSDR_FAST frame loop in parts per billion (default 20000 = 2e-5;
+ *                 0 switches the guard off: indices may then differ from the reference's where beta is tied at 1e-7).
+ * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB preset them, read once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
+/* running totals of the sync guard on this context: frames whose margins were checked / frames re-evaluated in the
+ * TSDR_EXACT sequence.  Synchronises; reset != 0 zeroes the totals. */
+int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, unsigned long long *frames_reevaluated, int reset);
+/* relative top-2 margins (best column vs best OTHER column) the guard saw in the most recent TSDR_FAST frame-loop call
+ * on this context, BEFORE any re-evaluation: margins[2f] = beta_x of frame f (decides s_x of frame f), margins[2f+1] =
+ * beta_y of frame f (decides s_y of frame f+1).  Fills min(*n_frames, max_frames) frames.  Synchronises. */
+int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *n_frames);
 
 /* resident buffers for callers without their own device allocator */
 void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes);

@@ -80,8 +80,24 @@ class Context:
         return "exact" if self.lib.tsdr_get_precision(self.h) == _lib.EXACT else "fast"
 
     def set_option(self, name, value):
-        """development switches ("ac_mixed", "fft_no_mix2") -- tsdr_set_option"""
+        """switches ("ac_mixed", "fft_no_mix2", "sync_guard_ppb") -- tsdr_set_option"""
         self.call("tsdr_set_option", name.encode(), int(value))
+
+    def sync_guard_stats(self, reset=False):
+        """running totals of the FAST frame loop's sync guard: (frames checked, frames re-evaluated exactly)"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self.call("tsdr_sync_guard_stats", C.byref(a), C.byref(b), int(bool(reset)))
+        return int(a.value), int(b.value)
+
+    def sync_guard_margins(self, max_frames=1 << 16):
+        """(frames, 2) relative top-2 margins (x, y) the guard saw in the last FAST frame-loop call"""
+        n = C.c_int(0)
+        self.call("tsdr_sync_guard_margins", 0, None, C.byref(n))
+        nf = min(n.value, int(max_frames))
+        m = np.zeros((nf, 2), np.float32)
+        if nf:
+            self.call("tsdr_sync_guard_margins", nf, _ptr(m), C.byref(n))
+        return m
 
     def set_stream(self, stream_ptr):
         self.call("tsdr_set_stream", C.c_void_p(stream_ptr or 0))

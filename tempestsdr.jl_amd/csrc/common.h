@@ -28,6 +28,7 @@ enum Slot {
   WS_FFT_C,       // Bluestein / correlation scratch
   WS_FFT_D,
   WS_MISC,
+  WS_GUARD,       // sync guard: flags + per-workgroup top-2 column maxima (guard.h)
   WS_COUNT
 };
 
@@ -61,6 +62,12 @@ struct tsdr_ctx {
   // development switches (tsdr_set_option; environment variables of the same upper-case names are read ONCE, in tsdr_create)
   int opt_ac_mixed = 1;     // autocorrelation of n = 2*(2^a3^b5^c) samples: native mixed-radix route (0: zero-padded power of two)
   int opt_fft_no_mix2 = 0;  // 1: every mixed-radix factor through the generic LDS-stage kernel
+  // sync guard of the FAST frame loop (guard.h): relative top-2 margin below which a frame is re-evaluated exactly
+  // (0: off); running totals {frames checked, frames re-evaluated} on the device
+  float guard_thr = 2e-5f;
+  unsigned long long *guard_stats = nullptr;
+  const uint2 *guard_last_top2 = nullptr;  // the top-2 records of the most recent guarded call (tsdr_sync_guard_margins)
+  int guard_last_frames = 0, guard_last_nbx = 0, guard_last_nby = 0;
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];
   // profiling
   bool prof_on = false;

@@ -124,6 +124,7 @@ tsdr_ctx *tsdr_create(int device) {
   // development switches: the environment is consulted here and nowhere else
   if (const char *e = getenv("TSDR_AC_MIXED")) ctx->opt_ac_mixed = atoi(e) != 0;
   if (const char *e = getenv("TSDR_FFT_NO_MIX2")) ctx->opt_fft_no_mix2 = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_SYNC_GUARD_PPB")) ctx->guard_thr = (float)atoi(e) * 1e-9f;
   return ctx;
 }
 
@@ -138,6 +139,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->amax_keys) (void)hipFree(ctx->amax_keys);
+  if (ctx->guard_stats) (void)hipFree(ctx->guard_stats);
   if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
@@ -178,7 +180,55 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return TSDR_EINVAL;
   if (!strcmp(name, "ac_mixed")) ctx->opt_ac_mixed = value != 0;
   else if (!strcmp(name, "fft_no_mix2")) ctx->opt_fft_no_mix2 = value != 0;
+  else if (!strcmp(name, "sync_guard_ppb")) {
+    if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");
+    ctx->guard_thr = (float)value * 1e-9f;
+  }
   else return tsdr::set_err(ctx, TSDR_EINVAL, "unknown option '%s'", name);
+  return TSDR_OK;
+}
+
+int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, unsigned long long *frames_reevaluated, int reset) {
+  if (!ctx) return TSDR_EINVAL;
+  unsigned long long h[2] = {0ull, 0ull};
+  int rc = tsdr::pipe_drain(ctx);
+  if (rc) return rc;
+  if (ctx->guard_stats) {
+    TSDR_HIP(ctx, hipMemcpyAsync(h, ctx->guard_stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_stats, 0, 16, ctx->stream));
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (frames_checked) *frames_checked = h[0];
+  if (frames_reevaluated) *frames_reevaluated = h[1];
+  return TSDR_OK;
+}
+
+int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *n_frames) {
+  if (!ctx || max_frames < 0 || (max_frames && !margins)) return TSDR_EINVAL;
+  int rc = tsdr::pipe_drain(ctx);
+  if (rc) return rc;
+  const int F = ctx->guard_last_top2 ? ctx->guard_last_frames : 0;
+  if (n_frames) *n_frames = F;
+  const int nf = F < max_frames ? F : max_frames;
+  if (nf == 0) return TSDR_OK;
+  const int nbx = ctx->guard_last_nbx, nby = ctx->guard_last_nby, nbb = nbx + nby;
+  std::vector<uint2> h((size_t)nf * nbb);
+  TSDR_HIP(ctx, hipMemcpyAsync(h.data(), ctx->guard_last_top2, h.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int f = 0; f < nf; ++f)
+    for (int axis = 0; axis < 2; ++axis) {  // the same top-2 merge as guard_eval (guard.h)
+      const uint2 *e = h.data() + (size_t)f * nbb + (axis ? nbx : 0);
+      const int nb = axis ? nby : nbx;
+      unsigned gb = 0, gs = 0;
+      int holders = 0;
+      for (int i = 0; i < nb; ++i) gb = e[i].x > gb ? e[i].x : gb;
+      for (int i = 0; i < nb; ++i) holders += e[i].x == gb;
+      if (holders >= 2) gs = gb;
+      else for (int i = 0; i < nb; ++i) { const unsigned c = e[i].x == gb ? e[i].y : e[i].x; gs = c > gs ? c : gs; }
+      float b, s2;
+      memcpy(&b, &gb, 4); memcpy(&s2, &gs, 4);
+      margins[2 * f + axis] = b != 0.f ? (b - s2) / b : 0.f;
+    }
   return TSDR_OK;
 }
 

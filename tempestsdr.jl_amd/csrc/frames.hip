@@ -10,6 +10,7 @@
 // recurrence -- are resolved inside shift_iir/sync_publish, so everything upstream is parallel
 // over frames.  No host synchronisation happens in the _d entry point.
 #include "common.h"
+#include "guard.h"
 #include "sync_layout.h"
 
 struct tsdr_sync;
@@ -24,12 +25,15 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
                       float *proj = nullptr, ProjLayout *got = nullptr, bool plan_only = false,
                       unsigned long long *keys = nullptr);
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
-                const ProjLayout *have);
+                const ProjLayout *have, uint2 *top2, const int *flags);
+void sync_beta_blocks(const tsdr_sync *s, int *nbx, int *nby);
+int down_frames_guarded_d(tsdr_ctx *ctx, const float *iq, size_t in_stride, size_t S, int y_t, int x_t, int h_out, int w_out,
+                          int frames, float *out, size_t out_stride, const GuardArgs &g, bool *can, bool plan_only);
 int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys);
 int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
                           const ProjLayout *have, const float *img_c, int frames_c, const unsigned long long *keys_c, int do_align,
-                          float alpha, float *state, float *frames_out, int *sync_idx);
+                          float alpha, float *state, float *frames_out, int *sync_idx, uint2 *top2);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx);
@@ -49,18 +53,75 @@ static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
   return TSDR_OK;
 }
 
+// ---- sync guard (guard.h) ---------------------------------------------------------------------------------------
+// FAST-mode calls with do_align: k_beta reports every workgroup's top-2 column maxima, and three more launches
+// re-evaluate -- in the reference's exact operation sequence -- the frames whose decision was closer than
+// ctx->guard_thr.  For geometries without the fused exact image kernel the whole call runs in TSDR_EXACT instead.
+struct GuardPlan {
+  bool on = false;
+  GuardArgs g;
+  uint2 *top2 = nullptr;
+};
+
+struct PrecisionScope {  // a call that has to run in TSDR_EXACT restores the caller's mode on every exit path
+  tsdr_ctx *ctx; int saved;
+  explicit PrecisionScope(tsdr_ctx *c) : ctx(c), saved(c->precision) {}
+  ~PrecisionScope() { ctx->precision = saved; }
+};
+
+static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int x_t, int do_align, int F, int slot, int nslots,
+                         GuardPlan *gp) {
+  *gp = GuardPlan{};
+  if (!do_align || ctx->precision != TSDR_FAST || !(ctx->guard_thr > 0.f)) return TSDR_OK;
+  int nbx = 0, nby = 0;
+  sync_beta_blocks(sync, &nbx, &nby);
+  GuardArgs g;
+  g.nbx = nbx; g.nby = nby; g.thr = ctx->guard_thr;
+  bool can = false;
+  int rc = down_frames_guarded_d(ctx, nullptr, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, nullptr, 0, g, &can, true);
+  if (rc) return rc;
+  if (!can) { ctx->precision = TSDR_EXACT; return TSDR_OK; }  // (the caller holds a PrecisionScope)
+  if (!ctx->guard_stats) {
+    TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_stats, 16));
+    TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_stats, 0, 16, ctx->stream));
+  }
+  const size_t per = ((size_t)F * 4 + 15) / 16 * 16 + (size_t)F * (size_t)(nbx + nby) * 8;
+  char *w = (char *)ctx->scratch(WS_GUARD, (size_t)nslots * per);
+  if (!w) return TSDR_ENOMEM;
+  w += (size_t)slot * per;
+  g.flags = (int *)w;
+  gp->top2 = (uint2 *)(w + ((size_t)F * 4 + 15) / 16 * 16);
+  g.top2 = gp->top2;
+  g.stats = ctx->guard_stats;
+  gp->g = g;
+  gp->on = true;
+  ctx->guard_last_top2 = gp->top2; ctx->guard_last_frames = F; ctx->guard_last_nbx = nbx; ctx->guard_last_nby = nby;
+  return TSDR_OK;
+}
+
+static int guard_run(tsdr_ctx *ctx, tsdr_sync *sync, const GuardPlan &gp, const float *iq, size_t S, int y_t, int x_t, int F,
+                     float *img, unsigned long long *keys, float *proj) {
+  const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
+  int rc = down_frames_guarded_d(ctx, iq, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, img, npx, gp.g, nullptr, false);
+  if (rc) return rc;
+  return sync_scan_d(sync, img, npx, F, keys, proj, nullptr, nullptr, gp.g.flags);
+}
+
 // The loop body for F frames.  Stage R: raster (optional) + 600x800 image of every frame in one launch; in TSDR_FAST
 // mode the same kernel also forms the images' projection partial sums on the fly, so no kernel re-reads the images
-// for them.  Stage S: vsync statistics (two argmax keys per frame) and, with `combine`, shift + IIR.
-// slot/nslots: which half of the sync workspaces this buffer uses.  Everything goes to the context's stream
-// (tsdr_frames_submit_d schedules the same launches over two streams itself).
+// for them.  Stage S: vsync statistics (two argmax keys per frame), in TSDR_FAST mode followed by the sync guard, and,
+// with `combine`, shift + IIR.
+// slot/nslots: which half of the sync workspaces this buffer uses.  Everything goes to the context's stream.
 static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t S, int y_t, int x_t, int do_align, int F,
                         float *img, float *raster_out, unsigned long long *keys, int slot, int nslots, float alpha,
                         float *state, float *frames_out, int *sync_idx, bool combine = true) {
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   float *proj = nullptr;
   ProjLayout plan{}, got{};
-  int rc;
+  PrecisionScope scope(ctx);
+  GuardPlan gp;
+  int rc = guard_prepare(ctx, sync, S, y_t, x_t, do_align, F, slot, nslots, &gp);
+  if (rc) return rc;
   if (do_align) {
     rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx,
                            nullptr, &plan, true);
@@ -72,8 +133,12 @@ static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t 
                          proj, &got, false, keys);
   if (rc) return rc;
   if (do_align) {
-    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr);
+    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr, nullptr);
     if (rc) return rc;
+    if (gp.on) {
+      rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
+      if (rc) return rc;
+    }
   }
   if (combine) {
     rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, state, frames_out,
@@ -207,6 +272,10 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   unsigned long long *keys = keys2 + (size_t)slot * nb * 2;
   float *proj = nullptr;
   ProjLayout plan{}, got{};
+  PrecisionScope scope(ctx);
+  GuardPlan gp;
+  rc = guard_prepare(ctx, sync, S, y_t, x_t, do_align, F, (int)slot, 2, &gp);
+  if (rc) return rc;
   if (do_align) {
     rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, nullptr,
                            &plan, true);
@@ -218,19 +287,24 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
                          false, keys);
   if (rc) return rc;
   tsdr_ctx::PipePending &p = ctx->pipe_pending;
+  uint2 *top2 = gp.on ? gp.top2 : nullptr;
   if (do_align && p.valid && p.do_align && p.sync == sync) {
     // the tail launch: statistics of this buffer + shift/IIR of the previous one
     rc = sync_scan_and_shift_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, p.img, p.frames, p.keys, 1, p.alpha, p.state,
-                               p.frames_out, p.sync_idx);
+                               p.frames_out, p.sync_idx, top2);
     if (rc) return rc;
     p.valid = false;
   } else {
     rc = pipe_combine_pending(ctx);
     if (rc) return rc;
     if (do_align) {
-      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr);
+      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, top2, nullptr);
       if (rc) return rc;
     }
+  }
+  if (gp.on) {  // the guard's three launches follow the statistics of THIS buffer; its shift + IIR comes later
+    rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
+    if (rc) return rc;
   }
   p.valid = true; p.sync = sync; p.img = img; p.frames = F; p.do_align = do_align; p.slot = (int)slot; p.keys = keys;
   p.alpha = alpha; p.state = imageOut_state; p.frames_out = frames_out; p.sync_idx = sync_idx;

@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "guard.h"
 #include "sync_layout.h"
 
 namespace tsdr {
@@ -757,8 +758,8 @@ __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
 }
 
 template <bool CPLX, int MODE>
-__global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
-                                                    float *__restrict__ out, size_t out_stride) {
+__device__ inline void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
+                                       float *__restrict__ out, size_t out_stride, int tile_idx, int f) {
   constexpr bool EXACT = MODE == DM_EXACT;
   constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample
   extern __shared__ double lds_dn[];
@@ -768,9 +769,8 @@ __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in
   double *cxs = cdx + q.TC;                                                                           // [TC] sf * kx
   int *ckx = reinterpret_cast<int *>(cxs + q.TC);                                                     // [TC] kx
   int *kfirst = ckx + q.TC;                                                                           // [NL]
-  const int tr = blockIdx.x / q.tiles_c, tc = blockIdx.x - tr * q.tiles_c;
+  const int tr = tile_idx / q.tiles_c, tc = tile_idx - tr * q.tiles_c;
   const int r0 = tr * 64, c0 = tc * q.TC;
-  const int f = blockIdx.y;
   const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
   const unsigned P = (unsigned)q.y_t * (unsigned)q.x_t;
   const RsAxis ax1 = rs_axis(q.S, P);
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in
   }
   const int wave = tid >> 6, lane = tid & 63;
   const int r = r0 + lane;
-  if (r >= q.h_out) return;
+  if (r >= q.h_out) return;  // (no barrier follows in the body)
   double dy;
   const int ky = (int)rs_pos(ay, (double)(r + 1), dy);
   const int i0 = ky - ly0;
@@ -877,6 +877,48 @@ __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in
       v = (float)fma(dy, bot - top, top);
     }
     o[(size_t)c * q.h_out] = v;
+  }
+}
+
+// grid = (tiles, frames).  With a guard (guard.h) the launch is the sync guard's first: a SMALL grid of workgroups, each
+// of which works out the list of flagged frames itself (a few KB out of L2 by its first wavefront) and then walks the
+// (flagged frame, tile) items grid-strided -- when no frame is flagged, which is the rule, a few hundred workgroups
+// look and leave.  Workgroup 0 records the verdicts (flags) for the two launches that follow, and the counters.
+template <bool CPLX, int MODE>
+__global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
+                                                    float *__restrict__ out, size_t out_stride, GuardArgs guard, int frames) {
+  if (!guard.top2) {
+    down_fused_body<CPLX, MODE>(in, in_stride, q, out, out_stride, (int)blockIdx.x, (int)blockIdx.y);
+    return;
+  }
+  __shared__ int list[kGuardChunk];
+  __shared__ int cnt;
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    int n = 0;
+    for (int base = 0; base < frames; base += 64) {
+      const int f = base + lane;
+      const bool bad = f < frames && guard_eval(guard, f);
+      const unsigned long long m = __ballot(bad);
+      if (bad) list[n + (int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = f;
+      n += (int)__builtin_popcountll(m);
+      if (blockIdx.x == 0 && f < frames) guard.flags[f] = bad ? 1 : 0;
+    }
+    if (lane == 0) {
+      cnt = n;
+      if (blockIdx.x == 0) {
+        atomicAdd(&guard.stats[0], (unsigned long long)frames);
+        if (n) atomicAdd(&guard.stats[1], (unsigned long long)n);
+      }
+    }
+  }
+  __syncthreads();
+  const int tiles = ((q.h_out + 63) >> 6) * q.tiles_c;
+  const int items = cnt * tiles;
+  for (int it = (int)blockIdx.x; it < items; it += (int)gridDim.x) {
+    const int j = it / tiles;
+    down_fused_body<CPLX, MODE>(in, in_stride, q, out, out_stride, it - j * tiles, list[j]);
+    __syncthreads();  // the body's LDS is reused by the next item
   }
 }
 
@@ -1189,7 +1231,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact);
   if (pl.fused) {
     dim3 grid((unsigned)(ceil_div((size_t)h_out, 64) * (size_t)pl.q.tiles_c), (unsigned)frames);
-#define DOWNK(C, M, NAME) TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M>), grid, dim3(256), pl.lds, in, in_stride, pl.q, out, out_stride)
+#define DOWNK(C, M, NAME) TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M>), grid, dim3(256), pl.lds, in, in_stride, pl.q, out, out_stride, GuardArgs{}, frames)
     if (cplx) {
       if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, "down_fused_iq_exact"); }
       else if (pl.mode == DM_FAST_PAIR) { DOWNK(true, DM_FAST_PAIR, "down_fused_iq"); }
@@ -1208,6 +1250,32 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
     if (rc) return rc;
     rc = resize2d_d(ctx, ras, y_t, x_t, h_out, w_out, out + (size_t)f * out_stride);
     if (rc) return rc;
+  }
+  return TSDR_OK;
+}
+
+// Sync guard, first launch (guard.h): the EXACT (h_out, w_out) image of every frame the guard flags, written over the
+// FAST one; g.flags / g.stats are filled for every frame.  *can (optional): whether this geometry has the fused exact
+// kernel at all (plan_only: nothing is launched).
+int down_frames_guarded_d(tsdr_ctx *ctx, const float *iq, size_t in_stride, size_t S, int y_t, int x_t, int h_out, int w_out,
+                          int frames, float *out, size_t out_stride, const GuardArgs &g, bool *can, bool plan_only) {
+  if (can) *can = false;
+  int rc = check_geom(ctx, S, y_t, x_t);
+  if (rc) return rc;
+  if (frames <= 0 || (y_t == h_out && x_t == w_out) || y_t < 2 || x_t < 2) return TSDR_OK;
+  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, /*exact=*/true);
+  if (!pl.fused) return TSDR_OK;
+  if (can) *can = true;
+  if (plan_only) return TSDR_OK;
+  // (at most kGuardChunk frames per launch: the list of flagged frames lives in LDS)
+  const int ncu = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  for (int f0 = 0; f0 < frames; f0 += kGuardChunk) {
+    const int nf = std::min(kGuardChunk, frames - f0);
+    GuardArgs gc = g;
+    gc.top2 = g.top2 + (size_t)f0 * (size_t)(g.nbx + g.nby);
+    gc.flags = g.flags + f0;
+    TSDR_LAUNCH(ctx, "guard_image", (k_down_fused<true, DM_EXACT>), dim3((unsigned)(2 * ncu)), dim3(256), pl.lds, iq + (size_t)f0 * in_stride * 2,
+                in_stride, pl.q, out + (size_t)f0 * out_stride, out_stride, gc, nf);
   }
   return TSDR_OK;
 }

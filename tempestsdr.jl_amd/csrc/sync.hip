@@ -32,6 +32,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "guard.h"
 #include "sync_layout.h"
 
 struct tsdr_sync {
@@ -70,11 +71,12 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 // at 136 registers they ran in two rounds)
 __global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
                                                  float *__restrict__ proj, size_t proj_stride,
-                                                 unsigned long long *__restrict__ keys) {
+                                                 unsigned long long *__restrict__ keys, const int *__restrict__ flags) {
   constexpr int CH = 100, SB = 25, PITCH = SB + 1, RND = 8 * CH;  // 8 tiles of 64 x 26 floats = 52 KiB of LDS
   __shared__ float tile[8][64 * PITCH];
   __shared__ float chain[64];
   const int f = blockIdx.y, rb = blockIdx.x;
+  if (flags && !flags[f]) return;  // sync guard: only the frames it flagged are re-evaluated
   const int nrb = (y_t + 63) >> 6;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride;
@@ -147,10 +149,11 @@ static inline dim3 proj_block() { return dim3(512); }
 // column chunk); grid = (8 * nrb, frames).
 __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
                                              float *__restrict__ proj, size_t proj_stride,
-                                             unsigned long long *__restrict__ keys) {
+                                             unsigned long long *__restrict__ keys, const int *__restrict__ flags) {
   constexpr int SUB = 32, PITCH = SUB + 1;
   __shared__ float tile[64 * PITCH];
   const int f = blockIdx.y;
+  if (flags && !flags[f]) return;
   const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3;
   const int j = blockIdx.x & 7, rb = blockIdx.x >> 3;
   const float *im = img + (size_t)f * img_stride;
@@ -284,7 +287,12 @@ struct BetaArgs {
   unsigned long long *keys;
   int write_frame;
   float *bx, *by;
+  uint2 *top2;       // sync guard (or null): per (frame, workgroup of the frame) {largest column maximum, second largest among
+                     // OTHER columns} of the workgroup's 64 centres, as order-preserving words
+  const int *flags;  // sync guard re-evaluation (or null): only frames with flags[f] != 0 are processed
 };
+
+__device__ inline int gridDim_x_of_frame(const SyncGeom &g) { return ((g.x_t + 63) >> 6) + ((g.y_t + 63) >> 6); }
 
 // body of one k_beta workgroup: blk = block index within the frame (x-axis blocks first), f = frame
 template <int NWV>
@@ -296,7 +304,8 @@ __device__ inline void beta_wg(const BetaArgs &A, int blk, int f, float *sh) {
   unsigned long long *__restrict__ keys = A.keys;
   const int write_frame = A.write_frame;
   float *__restrict__ bx = A.bx, *__restrict__ by = A.by;
-  __shared__ unsigned long long wkey[NWV];
+  if (A.flags && !A.flags[f]) return;  // uniform over the workgroup
+  __shared__ unsigned colk[NWV][64];
   __shared__ float Ssh;
   const int nbx = (g.x_t + 63) >> 6;
   const int axis = blk < nbx ? 0 : 1;
@@ -432,18 +441,26 @@ __device__ inline void beta_wg(const BetaArgs &A, int blk, int f, float *sh) {
       kb = max(kb, bits);
     }
   }
-  unsigned long long key = (c0 < n && ia < ib) ? (((unsigned long long)kb << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c0)) : 0ull;
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(key, off, 64);
-    key = o > key ? o : key;
-  }
-  if (lane == 0) wkey[q] = key;
+  // per-centre maximum over the wavefronts' width shares, then the workgroup's first maximum (smallest column on ties)
+  // and -- for the sync guard -- the largest value any OTHER column of the workgroup reaches
+  colk[q][lane] = (c0 < n && ia < ib) ? kb : 0u;
   __syncthreads();
-  if (tid == 0) {
-    unsigned long long b = wkey[0];
+  if (q == 0) {
+    unsigned m = colk[0][lane];
 #pragma unroll
-    for (int j = 1; j < NWV; ++j) b = wkey[j] > b ? wkey[j] : b;
-    if (b) atomicMax(&keys[(size_t)f * 2 + axis], b);
+    for (int j = 1; j < NWV; ++j) m = max(m, colk[j][lane]);
+    unsigned long long key = c0 < n ? (((unsigned long long)m << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c0)) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(key, off, 64);
+      key = o > key ? o : key;
+    }
+    if (lane == 0 && key) atomicMax(&keys[(size_t)f * 2 + axis], key);
+    if (A.top2) {
+      const unsigned wc = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+      unsigned m2 = (c0 < n && (unsigned)c0 != wc) ? m : 0u;
+      for (int off = 32; off > 0; off >>= 1) m2 = max(m2, (unsigned)__shfl_xor((int)m2, off, 64));
+      if (lane == 0) A.top2[(size_t)f * gridDim_x_of_frame(g) + blk] = make_uint2((unsigned)(key >> 32), m2);
+    }
   }
 }
 
@@ -607,10 +624,11 @@ void sync_image_size(const tsdr_sync *s, int *y_t, int *x_t) { *y_t = s->y_t; *x
 constexpr int kBetaWaves = 8;
 
 static void beta_args(tsdr_sync *s, const float *proj, ProjLayout pl, unsigned long long *keys, int frames, BetaArgs *B,
-                      unsigned *nbb, size_t *lds) {
+                      unsigned *nbb, size_t *lds, uint2 *top2 = nullptr, const int *flags = nullptr) {
   const int y = s->y_t, x = s->x_t;
   B->proj = proj; B->proj_stride = proj_floats(y, x, pl); B->ncp = pl.ncp; B->nrp = pl.nrp; B->g = geom_of(s);
   B->keys = keys; B->write_frame = frames - 1; B->bx = s->beta_x; B->by = s->beta_y;
+  B->top2 = top2; B->flags = flags;
   const size_t nmax = (size_t)(x > y ? x : y), wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
   *nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
   *lds = (2 * nmax + 64 + 2 * wmax + 8) * 4;
@@ -624,26 +642,32 @@ static void iir_args(tsdr_sync *s, const float *img, size_t img_stride, int h, i
   I->sync_idx = sync_idx; I->do_align = do_align; I->alpha = alpha; I->state = state; I->frames_out = frames_out;
 }
 
+//   top2 (sync guard, guard.h): k_beta also leaves every workgroup's {best, best other column} pair there.
+//   flags (sync guard re-evaluation): only frames with flags[f] != 0 are processed (their keys are cleared by k_proj and
+//   rewritten); the launches carry the profiler names guard_proj / guard_beta.  have must be null then.
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
-                const ProjLayout *have) {
+                const ProjLayout *have, uint2 *top2, const int *flags) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
   if (!proj || !keys) return TSDR_ENOMEM;
+  if (flags && have) return TSDR_EINVAL;
   ProjLayout pl;
   if (have) {
     pl = *have;
   } else {
     pl = sync_proj_layout(s);
-    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames), proj_block(), 0, img, img_stride, y, x, proj,
-                proj_floats(y, x, pl), keys);
+    TSDR_LAUNCH(ctx, flags ? "guard_proj" : "sync_proj", k_proj, proj_grid(y, frames), proj_block(), 0, img, img_stride, y, x, proj,
+                proj_floats(y, x, pl), keys, flags);
   }
   BetaArgs B;
   size_t lds = 0;
   unsigned nbb = 0;
-  beta_args(s, proj, pl, keys, frames, &B, &nbb, &lds);
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
+  beta_args(s, proj, pl, keys, frames, &B, &nbb, &lds, top2, flags);
+  TSDR_LAUNCH(ctx, flags ? "guard_beta" : "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
   return TSDR_OK;
 }
+
+void sync_beta_blocks(const tsdr_sync *s, int *nbx, int *nby) { *nbx = (s->x_t + 63) >> 6; *nby = (s->y_t + 63) >> 6; }
 
 // workspace for sync_scan_d: the projection buffer (and, on request, a key buffer) for `frames` frames in slot `slot`
 // (0/1: the two-stage pipeline keeps two buffers in flight) with room for `pl` (or k_proj's layout when pl == nullptr)
@@ -681,7 +705,7 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
 // shift + IIR of the PREVIOUS buffer, one launch (k_tail)
 int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
                           const ProjLayout *have, const float *img_c, int frames_c, const unsigned long long *keys_c, int do_align,
-                          float alpha, float *state, float *frames_out, int *sync_idx) {
+                          float alpha, float *state, float *frames_out, int *sync_idx, uint2 *top2) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
   if (!proj || !keys_b) return TSDR_ENOMEM;
@@ -691,13 +715,13 @@ int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, i
   } else {
     pl = sync_proj_layout(s);
     TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames_b), proj_block(), 0, img_b, img_stride, y, x, proj,
-                proj_floats(y, x, pl), keys_b);
+                proj_floats(y, x, pl), keys_b, (const int *)nullptr);
   }
   BetaArgs B;
   IirArgs I;
   size_t lds = 0;
   unsigned nbb = 0;
-  beta_args(s, proj, pl, keys_b, frames_b, &B, &nbb, &lds);
+  beta_args(s, proj, pl, keys_b, frames_b, &B, &nbb, &lds, top2);
   iir_args(s, img_c, img_stride, y, x, frames_c, keys_c, do_align, alpha, state, frames_out, sync_idx, &I);
   const unsigned nB = nbb * (unsigned)frames_b, nC = (unsigned)ceil_div((size_t)y * x, (size_t)64 * kBetaWaves);
   TSDR_LAUNCH(ctx, "sync_beta+shift_iir", k_tail<kBetaWaves>, dim3(nB + nC), dim3(64 * kBetaWaves), lds, B, nbb, nB, I);
@@ -786,7 +810,7 @@ int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   unsigned long long *keys = nullptr;
   int rc = sync_workspace(s, 1, 0, 1, nullptr, &proj, &keys);
   if (rc) return rc;
-  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr);
+  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr, nullptr, nullptr);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
               (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);

@@ -41,14 +41,43 @@ def gaussian_complex(seed, n0, n):
     return r * np.cos(2 * np.pi * u2) + 1j * r * np.sin(2 * np.pi * u2)
 
 
-def test_card(x_t, y_t, active_w=None, active_h=None, row0=0, col0=0, seed=SEED):
-    """(y_t, x_t) float32 in [0,1]: white blanking, test card in the active area, then rolled
-    by (row0, col0) so start-of-frame sits at a known non-zero offset."""
+# Blanking profiles.  The reference's vsync scores a blank-band centre c and half-width w by the mean of the window
+# [c-w, c+w] (FrameSynchronisation.jl:101-108), w >= 5 % of the 800 columns / 1 % of the 600 rows.
+#   "plateau": the whole blanking interval at the constant level 1.0 (SURVEY 8d as first written).  Every window that
+#              fits inside the band then has the same mean, so beta is flat over dozens of centres, the winner is decided
+#              by noise at the 1e-6 level and even exact f32 ties occur: a regression input for the sync guard, not a
+#              workload with a defined answer.
+#   "box"    : porches at 0.3 and, inside the blanking interval, one bright (1.0) band exactly as wide as the narrowest
+#              window vsync tries (81 of 800 columns, 13 of 600 rows), placed off-centre.  The window sum is then a
+#              triangle in c with its apex on the band -- a clear, unique answer.  (Frames of one buffer still drift by
+#              Fs/fv - round(Fs/fv) samples each, so the apex crosses the column grid: C2's default offset is chosen so
+#              that the ten phases of its 0.9-column drift stay 0.05 columns away from a two-column tie.)
+BLANK_BOX = dict(porch=0.3, bx=0.1013, by=0.0217, px=0.35, py=0.3, row0_frac=400 / 1125, col0_frac=1101 / 2576)
+
+
+def test_card(x_t, y_t, active_w=None, active_h=None, row0=0, col0=0, seed=SEED, blank="box"):
+    """(y_t, x_t) float32 in [0,1]: test card in the active area, blanking per `blank` ("box" or "plateau", above), then
+    rolled by (row0, col0) so start-of-frame sits at a known non-zero offset."""
     if active_w is None:
         active_w = int(round(x_t * 0.78))
     if active_h is None:
         active_h = int(round(y_t * 0.955))
     img = np.ones((y_t, x_t), np.float32)
+    if blank == "box":
+        b = BLANK_BOX
+        nbx, nby = x_t - active_w, y_t - active_h
+        wx, wy = min(nbx, int(round(b["bx"] * x_t))), min(nby, int(round(b["by"] * y_t)))
+        tx = np.full(nbx, b["porch"], np.float32)
+        sx = int(round(b["px"] * (nbx - wx)))
+        tx[sx:sx + wx] = 1.0
+        ty = np.full(nby, b["porch"], np.float32)
+        sy = int(round(b["py"] * (nby - wy)))
+        ty[sy:sy + wy] = 1.0
+        img[:, active_w:] = tx[None, :]
+        img[active_h:, :] = ty[:, None]
+        img[active_h:, active_w:] = np.maximum(ty[:, None], tx[None, :])
+    elif blank != "plateau":
+        raise ValueError(f"unknown blanking profile {blank!r}")
     yy, xx = np.mgrid[0:active_h, 0:active_w]
     bars = (7 - (xx * 8) // active_w).astype(np.float32) / 7.0 * 0.8  # 8 grey bars, bright -> dark
     card = bars.copy()
@@ -65,11 +94,19 @@ def test_card(x_t, y_t, active_w=None, active_h=None, row0=0, col0=0, seed=SEED)
     return np.roll(img, (row0, col0), axis=(0, 1))
 
 
-def synth_leak(Fs, x_t, y_t, fv, n_samples, *, n0=0, card=None, seed=SEED, snr_db=20.0, amp=5e-3, df=1e3,
-               phi0=0.3, row0=37, col0=211, chunk=1 << 20):
-    """complex64 IQ[n0 : n0+n_samples] of the synthetic leak."""
+def synth_leak(Fs, x_t, y_t, fv, n_samples, *, n0=0, card="box", seed=SEED, snr_db=20.0, amp=5e-3, df=1e3,
+               phi0=0.3, row0=None, col0=None, chunk=1 << 20):
+    """complex64 IQ[n0 : n0+n_samples] of the synthetic leak.  card: a blanking profile name ("box", the default, or
+    "plateau": see test_card) or a ready (y_t, x_t) image.  row0 / col0: start-of-frame offset in raster lines / pixels
+    (defaults: 37 / 211 for "plateau", the fractions of BLANK_BOX for "box")."""
     if card is None:
-        card = test_card(x_t, y_t, row0=row0 % y_t, col0=col0 % x_t, seed=seed)
+        card = "box"
+    if isinstance(card, str):
+        if row0 is None:
+            row0 = 37 if card == "plateau" else int(round(BLANK_BOX["row0_frac"] * y_t))
+        if col0 is None:
+            col0 = 211 if card == "plateau" else int(round(BLANK_BOX["col0_frac"] * x_t))
+        card = test_card(x_t, y_t, row0=row0 % y_t, col0=col0 % x_t, seed=seed, blank=card)
     flat = card.reshape(-1).astype(np.float64)  # line-major pixel stream of one frame
     P = flat.size
     cs = np.concatenate(([0.0], np.cumsum(flat)))

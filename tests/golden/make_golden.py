@@ -83,7 +83,7 @@ def main():
     # frame loop: A = 80x50 raster with S == P (imresize copy path); B = 160x125 raster, 4x upsampling
     for tag, (Fs, x_t, y_t, fv, nfr) in {"A": (0.2e6, 80, 50, 50.0, 3), "B": (0.25e6, 160, 125, 50.0, 3)}.items():
         S = synth.samples_per_frame(Fs, fv)
-        iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 17)
+        iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 17, card="plateau")  # the card the committed vectors were made with
         st = np.zeros((600, 800), np.float32, order="F")
         o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), st, want_raster=True)
         g[f"fr{tag}_iq"] = iq

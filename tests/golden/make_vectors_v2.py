@@ -57,7 +57,7 @@ def make_inputs():
     g["up_in"] = rng.standard_normal(125).astype(np.float32)
     for tag, (Fs, x_t, y_t, fv, nfr) in FRAME_CASES.items():
         S = synth.samples_per_frame(Fs, fv)
-        g[f"fr{tag}_iq"] = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 17)
+        g[f"fr{tag}_iq"] = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 17, card="plateau")  # the card the committed vectors were made with
         g[f"fr{tag}_geom"] = np.array([S, y_t, x_t, nfr], np.int64)
     return g
 

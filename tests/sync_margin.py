@@ -24,21 +24,32 @@ def peak_margin_db(G, guard=2):
     return i, float(G[i] - np.max(G[m])) if m.any() else float("inf")
 
 
-def fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, alpha, want_raster, rtol, tie_tol=1e-5):
-    """One buffer through tsdr_frames in the context's current (FAST) mode and through the oracle, frame by frame.
+def fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, alpha, want_raster, rtol, guard=True, tie_tol=2e-6):
+    """One buffer through tsdr_frames in TSDR_FAST mode and through the oracle, frame by frame.
 
-    Pixels: rasters always, frames (the IIR output) as long as the sync indices agree -- relative error < rtol.
-    Sync indices: identical, OR the oracle's own beta values at the two columns differ by less than tie_tol
-    (relative): the decision was a tie at the level of the pixel tolerance, which a non-bit-exact evaluation cannot
-    be asked to break the same way (the synthetic leak does produce exact f32 ties between neighbouring columns).
-    After such a tie the shifted frames legitimately differ, so frame comparison stops there.
-    Returns dict(n_frames, ties=[(frame, axis, gpu, oracle, rel)], worst=max relative pixel error seen)."""
+    guard=True (the library default): the sync guard is on, and the bar is north_star's -- IDENTICAL frame-sync
+    indices on every frame, no escape; rasters and frames (the IIR output) within rtol on every frame.
+
+    guard=False ("sync_guard_ppb" = 0, kept only to show what the guard is for): an index may differ where the oracle's
+    own beta values at the two columns differ by less than tie_tol (relative) -- the decision was a tie at the level of
+    FAST's beta error (~3e-7), which a non-bit-exact evaluation cannot be asked to break the same way.  The criterion is
+    applied per frame and indices keep being compared on every later frame (they do not depend on the IIR state);
+    frames are compared up to the first divergent shift, rasters always.
+
+    Returns dict(n_frames, ties=[(frame, axis, gpu, oracle, rel)], worst, guard=(checked, re-evaluated))."""
     z = np.ascontiguousarray(iq, np.complex64)
     nb = z.size // S
     gs = np.zeros((600, 800), np.float32, order="F")
     os_ = np.zeros((600, 800), np.float32, order="F")
-    g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), z, S, y_t, x_t, np.float32(alpha), gs, want_raster=want_raster)
+    ctx.set_option("sync_guard_ppb", 20000 if guard else 0)
+    ctx.sync_guard_stats(reset=True)
+    try:
+        g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), z, S, y_t, x_t, np.float32(alpha), gs, want_raster=want_raster)
+        gstats = ctx.sync_guard_stats()
+    finally:
+        ctx.set_option("sync_guard_ppb", 20000)
     assert g["n_frames"] == nb
+    assert gstats[0] == (nb if guard else 0), gstats
     osync = O.SyncXY(600, 800)
     rel = lambda a, b: float(np.max(np.abs(np.asarray(a, np.float64) - b) / np.maximum(np.abs(np.asarray(b, np.float64)), 1e-30)))
     ties, worst, diverged = [], 0.0, False
@@ -50,7 +61,8 @@ def fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, alpha, want_raster, rtol, tie_
         gi, oi = [int(v) for v in g["sync_idx"][f]], [int(v) for v in o["sync_idx"][0]]
         if want_raster:
             worst = max(worst, rel(g["raster"][f], o["raster"][0]))
-        if gi != oi and not diverged:
+        if gi != oi:
+            assert not guard, f"frame {f}: sync indices differ with the guard on: gpu {gi} oracle {oi}"
             for axis, cm in ((1, cx), (0, prev_cy)):
                 if gi[axis] != oi[axis]:
                     assert cm is not None, f"frame {f}: first-frame s_y differs ({gi} vs {oi})"
@@ -64,4 +76,6 @@ def fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, alpha, want_raster, rtol, tie_
     assert worst < rtol, worst
     if not diverged:
         assert rel(gs, os_) < rtol
-    return {"n_frames": nb, "ties": ties, "worst": worst}
+    if ties:
+        print(f"[sync_margin] guard off: {len(ties)} of {nb} frames used the tie escape: {ties}")
+    return {"n_frames": nb, "ties": ties, "worst": worst, "guard": gstats}
