@@ -85,6 +85,8 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *   "ac_mixed"    1 (default): calculate_autocorrelation of n = 2*(2^a 3^b 5^c) samples runs the native length-n/2
  *                 mixed-radix transform; 0: zero-padded power-of-two transform + fold.
  *   "fft_no_mix2" 1: every mixed-radix factor goes through the generic LDS-stage kernel.  Default 0.
+ *   "ac_fuse_mid" 1 (default): on the mixed-radix route the autocorrelation's last forward pass, power spectrum and
+ *                 first inverse pass run as one launch; 0: two separate transforms.
  *   "sync_guard_ppb"  sync-guard threshold of the TSDR_FAST frame loop in parts per billion (default 20000 = 2e-5;
  *                 0 switches the guard off: indices may then differ from the reference's where beta is tied at 1e-7).
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB preset them, read once in tsdr_create. */
@@ -164,6 +166,12 @@ int tsdr_autocorr_d(tsdr_ctx *ctx, const float *x, size_t len, double Fs, double
 /* same, but x = abs2.(iq) is formed on the fly from complex IQ (GUI.jl:67-73 fused) */
 int tsdr_autocorr_iq_d(tsdr_ctx *ctx, const float *iq, size_t len, double Fs, double minDelay, double maxDelay,
                        int log_scale, float *out, size_t *n_out);
+/* The configuration search's inner step as ONE call (GUI.jl:73-81: calculate_autocorrelation, zoom_autocorr, findmax):
+ * the lag vector as tsdr_autocorr_d / _iq_d (is_iq != 0) writes it, plus findmax over out[win_lo .. win_lo + win_cnt)
+ * -- the zoom window from tsdr_zoom_bounds, 0-based -- found by the same launch that writes the lags (no separate pass
+ * over them).  *idx is 0-based inside the window, first maximum, NaN maximal; blocking like tsdr_argmax_d. */
+int tsdr_autocorr_search_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t len, double Fs, double minDelay, double maxDelay,
+                           int log_scale, float *out, size_t *n_out, size_t win_lo, size_t win_cnt, size_t *idx, float *val);
 /* multi-GPU building block: partial circular autocorrelation
  *   part[k] = sum_{m in [m0, m0+cnt)} x[m] * x[(m+k) mod n],  k = 0..n_lags-1
  * of the length-n sequence x (device, real f32; is_iq!=0: x = abs2 of complex IQ).

@@ -83,6 +83,8 @@ _SIGS = {
     "tsdr_autocorr": (C.c_int, [vp, vp, c_sz, C.c_double, C.c_double, C.c_double, C.c_int, vp, c_szp]),
     "tsdr_autocorr_d": (C.c_int, [vp, vp, c_sz, C.c_double, C.c_double, C.c_double, C.c_int, vp, c_szp]),
     "tsdr_autocorr_iq_d": (C.c_int, [vp, vp, c_sz, C.c_double, C.c_double, C.c_double, C.c_int, vp, c_szp]),
+    "tsdr_autocorr_search_d": (C.c_int, [vp, vp, C.c_int, c_sz, C.c_double, C.c_double, C.c_double, C.c_int, vp, c_szp, c_sz, c_sz,
+                                         c_szp, c_f]),
     "tsdr_autocorr_partial_d": (C.c_int, [vp, vp, C.c_int, c_sz, c_sz, c_sz, c_sz, vp]),
     "tsdr_autocorr_finish_d": (C.c_int, [vp, vp, c_sz, c_sz, C.c_int, vp]),
     "tsdr_zoom_bounds": (C.c_int, [c_sz, C.c_double, C.c_double, C.c_double, c_szp, c_szp]),

@@ -232,6 +232,31 @@ class Context:
         lags = np.arange(0, index_max - index_min + 1, dtype=np.float64) * (1.0 / Fs)
         return out[: n_out.value], lags
 
+    def autocorr_search(self, sig, Fs, minDelay, maxDelay, rate_min=50, rate_max=90, scale="log"):
+        """calculate_autocorrelation + zoom_autocorr + findmax as ONE library call (tsdr_autocorr_search_d; GUI.jl:73-81).
+        sig: real power samples, or complex IQ whose abs2 is formed on the fly (GUI.jl:70).
+        -> (G, pos, val): the lag vector, the 0-based findmax position inside the zoom window, its value."""
+        a = np.ascontiguousarray(sig)
+        is_iq = int(np.iscomplexobj(a))
+        a = a.astype(np.complex64 if is_iq else np.float32, copy=False)
+        index_min = 1 + int(np.round(minDelay * Fs))
+        index_max = int(np.round(maxDelay * Fs))
+        cnt = max(index_max - index_min + 1, 0)
+        pmin, pmax = C.c_size_t(0), C.c_size_t(0)
+        check(self.h, self.lib.tsdr_zoom_bounds(cnt, float(Fs), float(rate_min), float(rate_max), C.byref(pmin), C.byref(pmax)),
+              "tsdr_zoom_bounds")
+        d_in, d_out = self.upload(a), self.dev_alloc(max(cnt, 1) * 4)
+        try:
+            n_out, idx, val = C.c_size_t(0), C.c_size_t(0), C.c_float(0)
+            self.call("tsdr_autocorr_search_d", C.c_void_p(d_in), is_iq, a.size, float(Fs), float(minDelay), float(maxDelay),
+                      1 if scale == "log" else 0, C.c_void_p(d_out), C.byref(n_out), int(pmin.value - 1),
+                      int(pmax.value - pmin.value + 1), C.byref(idx), C.byref(val))
+            G = self.download(d_out, (n_out.value,), np.float32)
+        finally:
+            self.dev_free(d_in)
+            self.dev_free(d_out)
+        return G, int(idx.value), float(val.value)
+
     def zoom_autocorr(self, G, Fs, rate_min=20, rate_max=100):
         pmin, pmax = C.c_size_t(0), C.c_size_t(0)
         rc = self.lib.tsdr_zoom_bounds(len(G), float(Fs), float(rate_min), float(rate_max), C.byref(pmin), C.byref(pmax))

@@ -129,12 +129,7 @@ __global__ __launch_bounds__(256) void k_real_part(const float2 *__restrict__ c,
     out[i] = c[i].x;
 }
 
-// ---- argmax (findmax: first maximum, NaN maximal) -------------------------------------------
-__device__ inline unsigned long long argmax_key(float v, unsigned idx) {
-  unsigned u = (v != v) ? 0x7FC00000u : __float_as_uint(v);
-  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
-}
+// ---- argmax (findmax: first maximum, NaN maximal; argmax_key: fft_dev.h) ----------------------
 
 // `key` must be zero on entry; `clear` (the slot the next launch will use) is zeroed here, so no memset launch
 // separates two searches.  The last workgroup to arrive writes the winning key, then a sequence number, into pinned
@@ -171,11 +166,38 @@ __global__ __launch_bounds__(256) void k_argmax(const float *__restrict__ v, siz
   }
 }
 
+// behind a last pass with a fused findmax: fold the slot words (clearing them for the next search) and hand the winner
+// to the host like k_argmax does
+__global__ __launch_bounds__(64) void k_amax_publish(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ host_out,
+                                                     unsigned long long seq) {
+  unsigned long long b = threadIdx.x < kAmaxSlots ? slots[threadIdx.x] : 0ull;
+  if (threadIdx.x < kAmaxSlots) slots[threadIdx.x] = 0ull;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(b, off, 64);
+    b = o > b ? o : b;
+  }
+  if (threadIdx.x == 0) {
+    host_out[0] = b;
+    __threadfence_system();
+    __hip_atomic_store(&host_out[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 static inline double jl_round(double v) { return nearbyint(v); }  // Julia round(): ties to even
+
+// findmax fused into the autocorrelation's last pass: the window and where the result goes (see amax_begin / amax_wait)
+struct AmaxReq {
+  size_t lo = 0, cnt = 0;  // window out[lo .. lo + cnt)
+  unsigned long long *key = nullptr, *clear = nullptr, *slots = nullptr;
+  unsigned *arrived = nullptr;
+  unsigned long long *host = nullptr;
+  unsigned long long seq = 0;
+  bool fused = false;      // out: the last pass delivered the maximum (else the caller runs k_argmax)
+};
 
 // shared core: x (real f32, or IQ whose abs2 is taken on the fly), first n samples
 static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, size_t k0, size_t cnt, int log_scale,
-                         float *out) {
+                         float *out, AmaxReq *amax = nullptr) {
   // n = 2*Mc with Mc = 2^a 3^b 5^c (the usual case: decimal sample rates, or a power of two): the circular
   // correlation of length n is transformed natively -- no zero padding, no fold, half the bytes (or less) of the
   // padded route below, which remains for every other n.
@@ -191,13 +213,24 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
       // mixed-radix route, three fusions: the first forward pass forms abs2 and packs; the first inverse pass forms the
       // packed power spectrum from Z while loading (no k_ac_power round trip); the last inverse pass writes
       // abs2 / 10log10 of the wanted lags straight to `out` (no k_ac_finish round trip)
-      int rc = fft_mixed(ctx, reinterpret_cast<const float2 *>(x), Z, Mc, 1, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, n, 0);
-      if (rc) return rc;
       FftEpilogue epi;
       epi.out = out;
       epi.k0 = k0;
       epi.cnt = cnt;
       epi.log_scale = log_scale;
+      if (amax && amax->cnt && amax->cnt < (size_t(1) << 32)) {
+        epi.amax_keys = amax->slots; epi.amax_lo = amax->lo; epi.amax_cnt = amax->cnt;
+        amax->fused = true;
+      }
+      // one launch carries the last forward pass, the power spectrum and the first inverse pass when the split allows
+      if (ctx->opt_ac_fuse_mid) {
+        bool done = false;
+        int rc = fft_mixed_autocorr(ctx, reinterpret_cast<const float2 *>(x), is_iq ? SRC_IQPOW : SRC_REAL, n, Mc, Z, z,
+                                    (float)(0.5 / (double)Mc), (k0 + cnt + 1) / 2, &epi, &done);
+        if (rc || done) return rc;
+      }
+      int rc = fft_mixed(ctx, reinterpret_cast<const float2 *>(x), Z, Mc, 1, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, n, 0);
+      if (rc) return rc;
       return fft_mixed(ctx, Z, z, Mc, 1, +1, (float)(0.5 / (double)Mc), SRC_POWER, Mc, (k0 + cnt + 1) / 2, &epi);
     }
     int rc = fft_pow2(ctx, reinterpret_cast<const float2 *>(x), Z, ilog2(Mc), 1, -1, 1.0f, is_iq ? SRC_IQPOW : SRC_REAL, n, 0);
@@ -334,34 +367,37 @@ int tsdr_zoom_bounds(size_t N, double Fs, double rate_min, double rate_max, size
   return TSDR_OK;
 }
 
-int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *val) {
-  if (!ctx || !v || !idx || n == 0) return TSDR_EINVAL;  // findmax of an empty collection throws
-  if (n >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "argmax: vector too long");
+// one findmax request: the key slot for this search (zero), the slot to clear for the next one, the sequence number
+static int amax_begin(tsdr_ctx *ctx, AmaxReq *r) {
   if (!ctx->amax_keys) {
-    TSDR_HIP(ctx, hipMalloc((void **)&ctx->amax_keys, 32));  // two key slots + the arrival counter
-    TSDR_HIP(ctx, hipMemset(ctx->amax_keys, 0, 32));
+    TSDR_HIP(ctx, hipMalloc((void **)&ctx->amax_keys, 32 + 8 * kAmaxSlots));  // two key slots + the arrival counter + fused-findmax slots
+    TSDR_HIP(ctx, hipMemset(ctx->amax_keys, 0, 32 + 8 * kAmaxSlots));
     TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->amax_host, 64, hipHostMallocCoherent | hipHostMallocMapped));
     std::memset(ctx->amax_host, 0, 64);
     TSDR_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->amax_host_dev, ctx->amax_host, 0));
     ctx->amax_slot = 0;
   }
-  unsigned long long *key = ctx->amax_keys + ctx->amax_slot, *other = ctx->amax_keys + (ctx->amax_slot ^ 1);
+  r->key = ctx->amax_keys + ctx->amax_slot;
+  r->clear = ctx->amax_keys + (ctx->amax_slot ^ 1);
   ctx->amax_slot ^= 1;
-  const unsigned long long seq = ++ctx->amax_seq;
-  const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
-  // the value rides in the key's upper half (NaN canonicalised); the kernel delivers key and sequence number
-  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, key, other, reinterpret_cast<unsigned *>(ctx->amax_keys + 2),
-              ctx->amax_host_dev, seq);
-  {
-    bool seen = false;
-    for (unsigned it = 1; !seen; ++it) {
-      seen = __atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) == seq;
-      if (!seen && (it & 0xFFFu) == 0 && hipStreamQuery(ctx->launch_stream) != hipErrorNotReady) break;  // finished or failed
-    }
-    if (!seen) {
-      TSDR_HIP(ctx, hipStreamSynchronize(ctx->launch_stream));
-      if (__atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) != seq) return set_err(ctx, TSDR_EHIP, "argmax: result not delivered");
-    }
+  r->arrived = reinterpret_cast<unsigned *>(ctx->amax_keys + 2);
+  r->slots = ctx->amax_keys + 4;
+  r->host = ctx->amax_host_dev;
+  r->seq = ++ctx->amax_seq;
+  return TSDR_OK;
+}
+
+// the value rides in the key's upper half (NaN canonicalised); the kernel delivers key and sequence number to pinned
+// memory and the host polls the sequence word
+static int amax_wait(tsdr_ctx *ctx, unsigned long long seq, size_t *idx, float *val) {
+  bool seen = false;
+  for (unsigned it = 1; !seen; ++it) {
+    seen = __atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) == seq;
+    if (!seen && (it & 0xFFFu) == 0 && hipStreamQuery(ctx->launch_stream) != hipErrorNotReady) break;  // finished or failed
+  }
+  if (!seen) {
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->launch_stream));
+    if (__atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) != seq) return set_err(ctx, TSDR_EHIP, "argmax: result not delivered");
   }
   const unsigned long long h = *ctx->amax_host;
   *idx = (size_t)(0xFFFFFFFFu - (unsigned)(h & 0xFFFFFFFFull));
@@ -371,6 +407,48 @@ int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *v
     std::memcpy(val, &bits, 4);
   }
   return TSDR_OK;
+}
+
+static int argmax_launch(tsdr_ctx *ctx, const float *v, size_t n, const AmaxReq &r) {
+  const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
+  TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, r.key, r.clear, r.arrived, r.host, r.seq);
+  return TSDR_OK;
+}
+
+int tsdr_argmax_d(tsdr_ctx *ctx, const float *v, size_t n, size_t *idx, float *val) {
+  if (!ctx || !v || !idx || n == 0) return TSDR_EINVAL;  // findmax of an empty collection throws
+  if (n >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "argmax: vector too long");
+  AmaxReq r;
+  int rc = amax_begin(ctx, &r);
+  if (rc) return rc;
+  rc = argmax_launch(ctx, v, n, r);
+  if (rc) return rc;
+  return amax_wait(ctx, r.seq, idx, val);
+}
+
+int tsdr_autocorr_search_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t len, double Fs, double minDelay, double maxDelay,
+                           int log_scale, float *out, size_t *n_out, size_t win_lo, size_t win_cnt, size_t *idx, float *val) {
+  if (!ctx || !x || !out || !idx) return TSDR_EINVAL;
+  size_t n, k0, cnt;
+  int rc = autocorr_args(ctx, len, Fs, minDelay, maxDelay, &n, &k0, &cnt);
+  if (rc) return rc;
+  if (n_out) *n_out = cnt;
+  if (win_cnt == 0 || win_lo >= cnt || win_cnt > cnt - win_lo) return set_err(ctx, TSDR_EBOUNDS, "autocorr_search: window outside the lag vector");
+  if (win_cnt >= (size_t(1) << 32)) return set_err(ctx, TSDR_EINVAL, "argmax: vector too long");
+  AmaxReq r;
+  rc = amax_begin(ctx, &r);
+  if (rc) return rc;
+  r.lo = win_lo;
+  r.cnt = win_cnt;
+  rc = autocorr_core(ctx, x, is_iq, n, k0, cnt, log_scale, out, &r);
+  if (rc) return rc;
+  if (!r.fused) {  // routes whose last pass has no epilogue: the separate kernel
+    rc = argmax_launch(ctx, out + win_lo, win_cnt, r);
+    if (rc) return rc;
+  } else {
+    TSDR_LAUNCH(ctx, "amax_publish", k_amax_publish, dim3(1), dim3(64), 0, r.slots, r.host, r.seq);
+  }
+  return amax_wait(ctx, r.seq, idx, val);
 }
 
 }  // extern "C"

@@ -209,6 +209,12 @@ __device__ inline float2 tw_frac(unsigned e, double inv_n8) {
 //              as abs2 (and 10log10) in f32 -- k_ac_finish without the round trip
 //   EPI_REAL   out[o] = gain * real(x) for o < cnt: the resampler's `2*upCoeff*real.(ifft)` (Resampler.jl) without k_real_scale
 //   EPI_SPEC   getSpectrum (GetSpectrum.jl:21-30): out[fftshift position of o] = abs2(x) or 10log10(abs2(x)); cnt = N, k0 = N div 2
+//              With amax_keys set the same pass also finds findmax over out[amax_lo .. amax_lo + amax_cnt) (GUI.jl:79 on
+//              the zoom window, Autocorrelations.jl:42-53): every thread keeps the best packed key of what it stores and a
+//              workgroup contributes ONE relaxed atomicMax to one of kAmaxSlots words (epi_argmax_finish) -- no fence, no
+//              arrival counter: a release fence per workgroup writes its freshly stored lags back through L2 and tripled
+//              the pass (measured 12 -> 38 us at C2).  A one-wavefront launch behind the pass folds the slots and hands
+//              the result to the host (k_amax_publish); the separate pass over the lags is gone.
 enum { EPI_NONE = 0, EPI_AC = 1, EPI_REAL = 2, EPI_SPEC = 3 };
 struct FftEpilogue {
   float *out = nullptr;
@@ -216,8 +222,20 @@ struct FftEpilogue {
   int log_scale = 0;
   int kind = EPI_AC;
   float gain = 1.0f;
+  // fused findmax (EPI_AC only)
+  unsigned long long *amax_keys = nullptr;  // kAmaxSlots device words, zero on entry
+  unsigned long long amax_lo = 0, amax_cnt = 0;
 };
-__device__ inline void epilogue_store(const FftEpilogue &e, size_t o, float2 x) {
+constexpr int kAmaxSlots = 16;
+
+// findmax: first maximum, NaN maximal -- value bits made order-preserving, index complemented so the smallest wins ties
+__device__ inline unsigned long long argmax_key(float v, unsigned idx) {
+  unsigned u = (v != v) ? 0x7FC00000u : __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__device__ inline void epilogue_store(const FftEpilogue &e, size_t o, float2 x, unsigned long long &best) {
   if (e.kind == EPI_REAL) {
     if (o < e.cnt) e.out[o] = e.gain * x.x;
     return;
@@ -232,8 +250,35 @@ __device__ inline void epilogue_store(const FftEpilogue &e, size_t o, float2 x) 
     return;
   }
   const unsigned long long i0 = 2ull * o - e.k0, i1 = i0 + 1ull;  // (wraps to huge when below k0)
-  if (i0 < e.cnt) { const float p = x.x * x.x; e.out[i0] = e.log_scale ? 10.0f * log10f(p) : p; }
-  if (i1 < e.cnt) { const float p = x.y * x.y; e.out[i1] = e.log_scale ? 10.0f * log10f(p) : p; }
+  if (i0 < e.cnt) {
+    const float p = x.x * x.x, v = e.log_scale ? 10.0f * log10f(p) : p;
+    e.out[i0] = v;
+    if (i0 - e.amax_lo < e.amax_cnt) { const unsigned long long k = argmax_key(v, (unsigned)(i0 - e.amax_lo)); best = k > best ? k : best; }
+  }
+  if (i1 < e.cnt) {
+    const float p = x.y * x.y, v = e.log_scale ? 10.0f * log10f(p) : p;
+    e.out[i1] = v;
+    if (i1 - e.amax_lo < e.amax_cnt) { const unsigned long long k = argmax_key(v, (unsigned)(i1 - e.amax_lo)); best = k > best ? k : best; }
+  }
+}
+__device__ inline void epilogue_store(const FftEpilogue &e, size_t o, float2 x) {
+  unsigned long long best = 0ull;
+  epilogue_store(e, o, x, best);
+}
+
+// End of a last pass with a fused findmax: called by every thread of a workgroup (wkeys: one LDS word per wavefront).
+__device__ inline void epi_argmax_finish(const FftEpilogue &e, unsigned long long best, unsigned long long *wkeys, int nwaves) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off, 64);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) wkeys[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long b = wkeys[0];
+    for (int i = 1; i < nwaves; ++i) b = wkeys[i] > b ? wkeys[i] : b;
+    if (b) __hip_atomic_fetch_max(e.amax_keys + (blockIdx.x & (kAmaxSlots - 1)), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // host entry points of the two engines (fft.hip, fft_mixed.hip).  src_mode / src_n / src_aux: fused loader of the first
@@ -243,6 +288,8 @@ int fft_pow2(tsdr_ctx *ctx, const float2 *in, float2 *out, int logN, size_t batc
              size_t src_n, size_t keep, const FftEpilogue *epi = nullptr, const float2 *src_aux = nullptr);
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
               size_t src_n, size_t keep, const FftEpilogue *epi = nullptr, const float2 *src_aux = nullptr);
+int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_n, size_t Mc, float2 *Zbuf, float2 *zbuf,
+                       float scale, size_t keep, const FftEpilogue *epi, bool *done);
 bool fft_mixed_ok(size_t N);
 int fft_passes(size_t N);
 int ensure_tw_small(tsdr_ctx *ctx);  // builds ctx->tw_small: W_4096^e for e < 4096  // launches a length-N transform takes (0: not a 2^a 3^b 5^c length)

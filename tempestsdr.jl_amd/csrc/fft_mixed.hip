@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
     const unsigned Kp = digit_swap_g(arest, d.nprev - 1, d.Rprev + 1, d.Wprev + 1);
     const unsigned t = tid & (T - 1u);
     const unsigned k1 = kt * T + t;
+    unsigned long long best = 0ull;
     if (k1 < d.R1) {
       const size_t orel = (size_t)k1 + Kp;
       for (unsigned w = tid; w < work; w += 256) {
@@ -324,9 +325,13 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
         if (o < d.keep) {
           const float2 x = buf[p * TP + t];
           const float2 y = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
-          if (d.epi.out) epilogue_store(d.epi, o, y); else out[tbase + o] = y;
+          if (d.epi.out) epilogue_store(d.epi, o, y, best); else out[tbase + o] = y;
         }
       }
+    }
+    if (d.epi.amax_keys) {
+      __syncthreads();  // the tile is dead: its first words carry the wavefronts' keys
+      epi_argmax_finish(d.epi, best, reinterpret_cast<unsigned long long *>(sm), 4);
     }
   } else {
     for (unsigned w = tid; w < work; w += 256) {
@@ -523,6 +528,7 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
     }
   } else {
     const unsigned Kp = digit_swap_g(arest, d.nprev - 1, d.Rprev + 1, d.Wprev + 1);
+    unsigned long long best = 0ull;
 #pragma unroll
     for (int q = 0; q < CO; ++q) {
       const int s = tid + NT * q;
@@ -537,12 +543,216 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mix2(const float
           const float2 x = v[q * RO + i];
           if (o < d.keep) {
             const float2 y = conj_if(make_float2(x.x * d.scale, x.y * d.scale), smask);
-            if (d.epi.out) epilogue_store(d.epi, o, y); else out[tbase + o] = y;
+            if (d.epi.out) epilogue_store(d.epi, o, y, best); else out[tbase + o] = y;
           }
         }
       }
     }
+    if (d.epi.amax_keys) {
+      __syncthreads();  // the exchange buffer is dead: its first words carry the wavefronts' keys
+      epi_argmax_finish(d.epi, best, reinterpret_cast<unsigned long long *>(sm), NT / 64);
+    }
   }
+}
+
+
+// ---- the middle of an autocorrelation: last forward pass + power spectrum + first inverse pass in ONE launch --------
+// The forward transform's last pass leaves, per workgroup, T columns c (= the low-order digits of the output index) x all
+// R values of the top digit k: Z[c + Bc*k], Bc = N/R.  An inverse transform whose FIRST factor is the same R reads exactly
+// that set for its strided DFTs (stride Bc).  In between, the packed power spectrum (fft_load's SRC_POWER) needs
+// Z[g] and Z[N - g]: column c pairs with column Bc - c (top digit R-1-k; column 0 with itself, top digit R-k).  So a
+// workgroup takes T/2 "direct" columns d and their mirrors Bc - d, transforms their rows forward (two register steps,
+// as FFT_LAST), parks Z in LDS, forms Y from the pairs, transforms inverse (two register steps, as FFT_STRIDED) and
+// stores with the inverse's inter-pass twiddles.  Z is never written to memory and never read twice: one launch, one
+// 16-byte-per-point round trip and one doubled read less per search.
+struct MidDesc {
+  unsigned R, Bc, ndir;           // radix, columns N/R, direct columns Bc/2 + 1
+  int logT, nprev;                // tile width (direct + mirrored halves), earlier forward factors
+  unsigned Rprev[MIX_MAX_PASS];   // forward factors R_1 .. R_{p-1} (column digits, least significant first)
+  unsigned r_hi, r_lo;            // floor(2^64 / R)
+  unsigned Bnext, ntw_hi, ntw_lo; // inverse pass 2: Bc / R'_2 and floor(2^64 / (R * R'_2))
+  int tw_sets;                    // inverse inter-pass twiddle sets per half held in LDS (0: evaluated per output)
+  double w8;                      // 8 / (2N): phase unit of W_{2N}^g
+};
+
+template <int RA, int RB>
+__global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mid(const float2 *__restrict__ in, float2 *__restrict__ out, MidDesc d) {
+  using G = Mix2Geom<RA, RB>;
+  constexpr int R = G::R, CA = G::CA, CB = G::CB, NT = G::NT;
+  static_assert(RB > 1, "two register steps");
+  extern __shared__ float2 sm[];
+  const int logT = d.logT, T = 1 << logT, TP = T + 1, Th = T >> 1;
+  const int SA = (RB << logT) + (T < 32 ? T : 0);
+  float2 *buf = sm;
+  float2 *twR = sm + (R * TP > RA * SA ? R * TP : RA * SA);
+  float2 *twK = twR + R;
+  const int nsets = d.tw_sets > 0 ? d.tw_sets : 0;
+  unsigned *colinfo = reinterpret_cast<unsigned *>(twK + 2 * nsets * R);  // [T] column (~0: none), [T] source row
+  const int tid = threadIdx.x;
+  const unsigned smask = 0x80000000u;  // the second half of the kernel is an inverse transform
+  for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
+  const unsigned d0 = blockIdx.x * (unsigned)Th;
+  if (tid < T) {
+    const bool mir = tid >= Th;
+    const unsigned dcol = d0 + (unsigned)(tid & (Th - 1));
+    unsigned c = 0xFFFFFFFFu;
+    if (dcol < d.ndir && !(mir && dcol == 0)) c = mir ? d.Bc - dcol : dcol;  // (the mirror of column 0 is column 0 itself)
+    unsigned row = 0;
+    if (c != 0xFFFFFFFFu) {
+      unsigned cc = c;
+      for (int j = 0; j < d.nprev; ++j) { const unsigned q = cc / d.Rprev[j]; row = row * d.Rprev[j] + (cc - q * d.Rprev[j]); cc = q; }
+    }
+    colinfo[tid] = c;
+    colinfo[T + tid] = row;
+  }
+  __syncthreads();
+  const int n1 = RB << logT, n2 = RA << logT;
+  float2 v[CA * RA > CB * RB ? CA * RA : CB * RB];
+  {  // stage the rows (contiguous over the DFT index), then the step-1 registers
+    const int work = R << logT;
+    const float invR = 1.0f / (float)R;
+    constexpr int NL = (R * G::TM + NT - 1) / NT;
+    float2 w[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = min(tid + NT * u, work - 1);
+      const int t = (int)(((float)e + 0.5f) * invR), j = e - t * R;
+      w[u] = colinfo[t] != 0xFFFFFFFFu ? in[(size_t)colinfo[T + t] * R + j] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int e = tid + NT * u;
+      if (e < work) {
+        const int t = (int)(((float)e + 0.5f) * invR), j = e - t * R;
+        buf[j * TP + t] = w[u];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = min(tid + NT * q, n1 - 1);
+      const int t = s & (T - 1), j0 = s >> logT;
+#pragma unroll
+      for (int m = 0; m < RA; ++m) v[q * RA + m] = buf[(j0 + RB * m) * TP + t];
+    }
+  }
+  __syncthreads();
+  // two register steps of one length-R DFT per column; afterwards register i of slot q = X[ka + RA*i] of column t
+  auto two_steps = [&]() {
+#pragma unroll
+    for (int q = 0; q < CA; ++q) dft_nat<RA>(v + q * RA);
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+      const int s = tid + NT * q;
+      const int j0 = s >> logT;
+      if (s < n1) {
+#pragma unroll
+        for (int ka = 0; ka < RA; ++ka) {
+          float2 x = v[q * RA + ka];
+          if (ka) x = cmul(x, twR[j0 * ka]);
+          buf[ka * SA + s] = x;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const int s = min(tid + NT * q, n2 - 1);
+      const int t = s & (T - 1), ka = s >> logT;
+#pragma unroll
+      for (int j0 = 0; j0 < RB; ++j0) v[q * RB + j0] = buf[ka * SA + (j0 << logT) + t];
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) dft_nat<RB>(v + q * RB);
+  };
+  two_steps();
+  __syncthreads();  // exchange buffer fully read
+#pragma unroll
+  for (int q = 0; q < CB; ++q) {  // park Z[k][t]
+    const int s = tid + NT * q;
+    if (s < n2) {
+      const int t = s & (T - 1), ka = s >> logT;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) buf[(ka + RA * i) * TP + t] = v[q * RB + i];
+    }
+  }
+  // the inverse's inter-pass twiddles W_{R R'}^(n k): the columns of a half are consecutive, so n = c / Bnext takes
+  // tw_sets consecutive values there
+  unsigned n0h[2] = {0u, 0u};
+  if (nsets) {
+    const unsigned dmax = min(d0 + (unsigned)Th - 1u, d.ndir - 1u);
+    n0h[0] = d0 / d.Bnext;
+    n0h[1] = (dmax ? d.Bc - dmax : 0u) / d.Bnext;
+    for (int e = tid; e < 2 * nsets * R; e += NT) {
+      const unsigned hs = (unsigned)e / (unsigned)R, k = (unsigned)e - hs * (unsigned)R;
+      const unsigned h = hs / (unsigned)nsets, set = hs - h * (unsigned)nsets;
+      twK[e] = tw_q32(phase_q32((n0h[h] + set) * k, d.ntw_hi, d.ntw_lo));
+    }
+  }
+  __syncthreads();
+  // Y = packed power spectrum from Z[g] and Z[N-g] (fft_load's SRC_POWER arithmetic), conjugated for the inverse
+#pragma unroll
+  for (int q = 0; q < CA; ++q) {
+    const int s = min(tid + NT * q, n1 - 1);
+    const int t = s & (T - 1), j0 = s >> logT;
+    const unsigned c = colinfo[t];
+    const bool ok = tid + NT * q < n1 && c != 0xFFFFFFFFu;
+    const int tp = c == 0u ? t : (t ^ Th);
+#pragma unroll
+    for (int m = 0; m < RA; ++m) {
+      const int j = j0 + RB * m;
+      const int jm = c == 0u ? (j ? R - j : 0) : R - 1 - j;
+      const float2 a = buf[j * TP + t], b = buf[jm * TP + tp];
+      const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+      const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+      const float2 O = make_float2(D.y, -D.x);
+      const float2 W = tw_frac(ok ? c + d.Bc * (unsigned)j : 0u, d.w8);
+      const float2 WO = cmul(W, O);
+      const float2 X0 = make_float2(E.x + WO.x, E.y + WO.y), X1 = make_float2(E.x - WO.x, E.y - WO.y);
+      const float P0 = X0.x * X0.x + X0.y * X0.y, P1 = X1.x * X1.x + X1.y * X1.y;
+      const float sum = P0 + P1, dif = P0 - P1;
+      v[q * RA + m] = ok ? conj_if(make_float2(sum + dif * W.y, dif * W.x), smask) : make_float2(0.f, 0.f);
+    }
+  }
+  __syncthreads();  // Z fully read before the exchange buffer overwrites it
+  two_steps();
+#pragma unroll
+  for (int q = 0; q < CB; ++q) {
+    const int s = tid + NT * q;
+    const int t = s & (T - 1), ka = s >> logT;
+    const unsigned c = s < n2 ? colinfo[t] : 0xFFFFFFFFu;
+    if (c != 0xFFFFFFFFu) {
+      float2 *dst = out + c;
+      const unsigned nn = c / d.Bnext;
+      if (nsets) {
+        const unsigned h = t >= Th ? 1u : 0u;
+        const float2 *tws = twK + (h * (unsigned)nsets + (nn - n0h[h])) * R;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int k = ka + RA * i;
+          dst[(size_t)k * d.Bc] = conj_if(cmul(v[q * RB + i], tws[k]), smask);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int k = ka + RA * i;
+          dst[(size_t)k * d.Bc] = conj_if(cmul(v[q * RB + i], tw_q32(phase_q32(nn * (unsigned)k, d.ntw_hi, d.ntw_lo))), smask);
+        }
+      }
+    }
+  }
+}
+
+typedef void (*mid_fn)(const float2 *, float2 *, MidDesc);
+struct MidEntry { unsigned R, RA; int tm, nt; mid_fn fn; };
+#define MID(RA_, RB_) { RA_ * RB_, RA_, Mix2Geom<RA_, RB_>::TM, Mix2Geom<RA_, RB_>::NT, k_fft_mid<RA_, RB_> }
+// last forward factors that have the fused kernel (the planner puts the factor with the most twos last)
+static const MidEntry kMid[] = {MID(10, 20), MID(10, 10), MID(16, 16), MID(16, 10), MID(16, 9), MID(16, 8), MID(16, 5), MID(8, 8), MID(8, 5)};
+#undef MID
+static const MidEntry *mid_lookup(unsigned R) {
+  for (const MidEntry &e : kMid)
+    if (e.R == R) return &e;
+  return nullptr;
 }
 
 typedef void (*mix2_fn)(const float2 *, float2 *, MixDesc);
@@ -749,10 +959,16 @@ static int get_twg(tsdr_ctx *ctx, unsigned R, unsigned Rn, const float2 **out) {
 // in/out may alias.  Uses WS_FFT_B when more than one pass is needed (callers must not hand WS_FFT_B buffers in).
 // src_mode/src_n: fused first-pass loader (fft_dev.h), batch == 1 and p > 1 only; keep: complex outputs per
 // transform the caller will look at (0 = all).
-int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
-              size_t src_n, size_t keep, const FftEpilogue *epi, const float2 *src_aux) {
+//   force: run this pass split instead of the planner's.  first_pass > 0: `in` already holds the output of pass
+//   first_pass - 1 of that split (the fused autocorrelation middle wrote it); the remaining strided passes then run in
+//   place in `in`.  work_out != nullptr: stop before the last pass and hand back the buffer the strided passes left
+//   their result in.
+static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
+                        size_t src_n, size_t keep, const FftEpilogue *epi, const float2 *src_aux, const MixPlan *force,
+                        int first_pass, float2 **work_out) {
   MixPlan pl;
-  if (!fft_mixed_plan(N, &pl)) return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
+  if (force) pl = *force;
+  else if (!fft_mixed_plan(N, &pl)) return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
   if (batch == 0) return TSDR_OK;
   if (N * batch >= (size_t(1) << 40)) return set_err(ctx, TSDR_EINVAL, "fft: batch too large");
   const int p = pl.p;
@@ -784,14 +1000,15 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     TSDR_LAUNCH(ctx, "fftm_rows", k_fft_mix, dim3(grid), dim3(256), mix_lds(d.R, d.logT), in, out, d);
     return TSDR_OK;
   }
-  float2 *work = (float2 *)ctx->scratch(WS_FFT_B, N * batch * sizeof(float2));
+  float2 *work = first_pass > 0 ? const_cast<float2 *>(in) : (float2 *)ctx->scratch(WS_FFT_B, N * batch * sizeof(float2));
   if (!work) return TSDR_ENOMEM;
   size_t P = 1;  // R_1..R_{i-1}
   size_t B = N;
   const float2 *src = in;
+  for (int i = 0; i < first_pass && i < p - 1; ++i) { B /= pl.R[i]; P *= pl.R[i]; }
   static const char *const kStridedName[MIX_MAX_PASS] = {"fftm_strided1", "fftm_strided2", "fftm_strided3",
                                                          "fftm_strided4", "fftm_strided5", "fftm_strided6"};
-  for (int i = 0; i < p - 1; ++i) {
+  for (int i = first_pass; i < p - 1; ++i) {
     set_radix(i);
     B /= d.R;
     d.mode = FFT_STRIDED;
@@ -832,6 +1049,7 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
     src = work;
     P *= d.R;
   }
+  if (work_out) { *work_out = work; return TSDR_OK; }
   set_radix(p - 1);
   d.mode = FFT_LAST;
   d.src_mode = SRC_C2C;
@@ -856,6 +1074,79 @@ int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t bat
   } else {
     TSDR_LAUNCH(ctx, "fftm_last", k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), (const float2 *)work, out, d);
   }
+  return TSDR_OK;
+}
+
+
+int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
+              size_t src_n, size_t keep, const FftEpilogue *epi, const float2 *src_aux) {
+  return fft_mixed_ex(ctx, in, out, N, batch, dir, scale, src_mode, src_n, keep, epi, src_aux, nullptr, 0, nullptr);
+}
+
+// The circular autocorrelation of n = 2*Mc real samples (x, or abs2 of IQ formed while loading) as
+//   forward passes 1..p-1  ->  [last forward pass + power spectrum + first inverse pass] (k_fft_mid)  ->  inverse passes 2..p
+// with the epilogue (abs2 / 10log10 of the wanted lags, optional findmax) on the last one.  *done = false (nothing
+// launched) when this length has no fused middle: the caller then runs the two transforms separately.
+int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_n, size_t Mc, float2 *Zbuf, float2 *zbuf,
+                       float scale, size_t keep, const FftEpilogue *epi, bool *done) {
+  *done = false;
+  MixPlan F;
+  if (!fft_mixed_plan(Mc, &F) || F.p < 2 || Mc >= (size_t(1) << 31)) return TSDR_OK;
+  const int p = F.p;
+  const MidEntry *me = mid_lookup(F.R[p - 1]);
+  if (!me || ctx->opt_fft_no_mix2) return TSDR_OK;
+  // inverse split: the forward's last factor first; of the others the one with the most twos last, the rest largest first
+  MixPlan I;
+  I.p = p;
+  I.R[0] = F.R[p - 1];
+  I.rad[0] = F.rad[p - 1];
+  {
+    std::vector<int> rest;
+    for (int i = 0; i < p - 1; ++i) rest.push_back(i);
+    auto twos = [&](int i) { unsigned v = F.R[i], t = 0; while (v % 2 == 0 && t < 4) { v /= 2; ++t; } return t; };
+    int last = rest[0];
+    for (int i : rest)
+      if (twos(i) > twos(last) || (twos(i) == twos(last) && F.R[i] > F.R[last])) last = i;
+    std::vector<int> order;
+    for (int i : rest) if (i != last) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return F.R[a] > F.R[b]; });
+    order.push_back(last);
+    for (int o = 0; o < (int)order.size(); ++o) { I.R[o + 1] = F.R[order[o]]; I.rad[o + 1] = F.rad[order[o]]; }
+  }
+  MidDesc m{};
+  m.R = F.R[p - 1];
+  m.Bc = (unsigned)(Mc / m.R);
+  m.ndir = m.Bc / 2 + 1;
+  m.logT = floor_log2((unsigned)me->tm);
+  if (m.logT < 1) return TSDR_OK;
+  m.nprev = p - 1;
+  for (int j = 0; j < p - 1; ++j) m.Rprev[j] = F.R[j];
+  {
+    const unsigned __int128 inv = ((unsigned __int128)1 << 64) / m.R;
+    m.r_hi = (unsigned)(inv >> 32);
+    m.r_lo = (unsigned)inv;
+    const unsigned __int128 inv2 = ((unsigned __int128)1 << 64) / ((unsigned __int128)m.R * I.R[1]);
+    m.ntw_hi = (unsigned)(inv2 >> 32);
+    m.ntw_lo = (unsigned)inv2;
+  }
+  m.Bnext = m.Bc / I.R[1];
+  const unsigned Th = 1u << (m.logT - 1);
+  const unsigned sets = (Th - 1) / m.Bnext + 2;
+  m.tw_sets = sets <= 4 ? (int)sets : 0;
+  m.w8 = 4.0 / (double)Mc;
+  float2 *w = nullptr;
+  int rc = fft_mixed_ex(ctx, x, nullptr, Mc, 1, -1, 1.0f, src_mode, src_n, 0, nullptr, nullptr, &F, 0, &w);
+  if (rc) return rc;
+  {
+    const size_t T = (size_t)1 << m.logT, RB = m.R / me->RA;
+    const size_t SA = (RB << m.logT) + (T < 32 ? T : 0);
+    const size_t lds = (std::max((size_t)m.R * (T + 1), (size_t)me->RA * SA) + (size_t)(1 + 2 * m.tw_sets) * m.R) * sizeof(float2) + 2 * T * 4;
+    const unsigned grid = (unsigned)ceil_div((size_t)m.ndir, (size_t)Th);
+    TSDR_LAUNCH(ctx, "fftm_mid", me->fn, dim3(grid), dim3(me->nt), lds, (const float2 *)w, Zbuf, m);
+  }
+  rc = fft_mixed_ex(ctx, Zbuf, zbuf, Mc, 1, +1, scale, SRC_C2C, 0, keep, epi, nullptr, &I, 1, nullptr);
+  if (rc) return rc;
+  *done = true;
   return TSDR_OK;
 }
 

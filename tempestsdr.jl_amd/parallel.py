@@ -131,10 +131,9 @@ class HipSearch:
             torch.cuda.synchronize()
             n_out = C.c_size_t(0)
             # lags k0 .. n_lags-1 of the first n samples: minDelay/maxDelay chosen so that indexMin-1 = k0, indexMax = n_lags
-            ctx.call("tsdr_autocorr_iq_d", C.c_void_p(iq.data_ptr()), int(n), float(n_lags), float(k0) / float(n_lags), 1.0,
-                     int(log_scale), C.c_void_p(out.data_ptr()), C.byref(n_out))
             idx, val = C.c_size_t(0), C.c_float(0)
-            ctx.call("tsdr_argmax_d", C.c_void_p(out.data_ptr()), int(out.numel()), C.byref(idx), C.byref(val))
+            ctx.call("tsdr_autocorr_search_d", C.c_void_p(iq.data_ptr()), 1, int(n), float(n_lags), float(k0) / float(n_lags), 1.0,
+                     int(log_scale), C.c_void_p(out.data_ptr()), C.byref(n_out), 0, int(out.numel()), C.byref(idx), C.byref(val))
             return out, idx.value, val.value
         part = torch.empty(n_lags, dtype=torch.float32, device=self.dev)
 
@@ -175,11 +174,11 @@ def bench_search(ctx, iq, n, n_lags, Fs, steps, world, rank, dev):
         n_out = C.c_size_t(0)
 
         def once():
-            ctx.call("tsdr_autocorr_iq_d", C.c_void_p(iq.data_ptr()), int(n), float(Fs), 0.0, float(n_lags) / float(Fs), 1,
-                     C.c_void_p(out.data_ptr()), C.byref(n_out))
+            # one call: lags + findmax over the zoom window (found by the launch that writes the lags)
             idx, val = C.c_size_t(0), C.c_float(0)
-            zoom = out.data_ptr() + 4 * (pmin.value - 1)
-            ctx.call("tsdr_argmax_d", C.c_void_p(zoom), int(pmax.value - pmin.value + 1), C.byref(idx), C.byref(val))
+            ctx.call("tsdr_autocorr_search_d", C.c_void_p(iq.data_ptr()), 1, int(n), float(Fs), 0.0, float(n_lags) / float(Fs), 1,
+                     C.c_void_p(out.data_ptr()), C.byref(n_out), int(pmin.value - 1), int(pmax.value - pmin.value + 1),
+                     C.byref(idx), C.byref(val))
             return idx.value
     else:
         hs = HipSearch(ctx, dev, world, rank)
@@ -214,7 +213,8 @@ def bench_search(ctx, iq, n, n_lags, Fs, steps, world, rank, dev):
                       f"transforms), all-reduce of {4 * n_lags} B" if route == "sharded" else
                       f"replicated on {world} GPUs: a rank's segment+halo transform ({sharded_route_points(n, n_lags, world)} points) "
                       f"would not be smaller than the single-GPU one ({single_route_points(n, n_lags)} points), so no collective is used")),
-            "includes": "abs2, FFT autocorrelation, 10log10(abs2), zoom argmax with host readback"}
+            "includes": "abs2, FFT autocorrelation, 10log10(abs2), zoom argmax with host readback (tsdr_autocorr_search_d: "
+                        "one call; on the mixed-radix route 5 launches for 3+3 passes)"}
 
 
 # ---------------------------------------------------------------------------------------------

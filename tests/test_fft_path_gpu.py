@@ -133,6 +133,37 @@ def test_autocorr_vs_oracle(ctx, n, Fs, maxd, mind, mixed):
         ctx.set_option("ac_mixed", 1)
 
 
+@pytest.mark.parametrize("n,Fs", [(80_000, 1e5), (200_000, 1e6), (180_000, 1e6), (60_000, 1e5), (3000, 30_000.0), (1_000_000, 5e6),
+                                  (8192, 4096.0), (100_003, 1e6)])
+def test_autocorr_fused_middle_and_fused_findmax(ctx, n, Fs):
+    """The autocorrelation with its last forward pass, power spectrum and first inverse pass in one launch (k_fft_mid:
+    two-pass splits, odd column counts, ragged tiles) against the two-transform route and the oracle; and
+    tsdr_autocorr_search_d's findmax -- found by the launch that writes the lags -- against numpy on the lags it
+    returned, on IQ input (abs2 formed while loading).  The power-of-two and zero-padded lengths take the routes
+    without a fused middle / epilogue and must answer the same way."""
+    z = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 3e-3).astype(np.complex64)
+    z *= (1.0 + 0.5 * np.cos(2 * np.pi * np.arange(n) / 977.0)).astype(np.float32)   # a period for the zoom window to find
+    x = O.abs2(z)
+    maxd = (n // 2) / Fs
+    o, _ = O.calculate_autocorrelation(x, Fs, 0, maxd)
+    res = {}
+    for fuse in (1, 0):
+        ctx.set_option("ac_fuse_mid", fuse)
+        try:
+            g, _ = ctx.calculate_autocorrelation(x, Fs, 0, maxd)
+            G, pos, val = ctx.autocorr_search(z, Fs, 0, maxd, rate_min=Fs / 3000, rate_max=Fs / 300)
+        finally:
+            ctx.set_option("ac_fuse_mid", 1)
+        assert g.shape == o.shape == G.shape
+        assert np.max(np.abs(g - o)) < 2e-4, (fuse, np.max(np.abs(g - o)))
+        assert np.max(np.abs(G - o)) < 2e-4, (fuse, np.max(np.abs(G - o)))
+        lo, hi = int(round(Fs / (Fs / 300))), min(int(round(Fs / (Fs / 3000))), G.size)   # zoom_autocorr bounds, 1-based
+        win = G[lo - 1: hi]
+        assert pos == int(np.argmax(win)) and val == win[pos], (fuse, pos, int(np.argmax(win)))
+        res[fuse] = G
+    assert np.max(np.abs(res[0] - res[1])) < 2e-4
+
+
 def test_autocorr_bounds_error(ctx):
     x = np.ones(100, np.float32)
     with pytest.raises(IndexError):  # BoundsError at Autocorrelations.jl:33

@@ -13,8 +13,17 @@ g = torch.Generator().manual_seed(1)
 iq = torch.view_as_real(torch.randn(n, dtype=torch.complex64, generator=g)).contiguous().cuda()
 out = torch.empty(k_hi, dtype=torch.float32, device="cuda")
 n_out = C.c_size_t(0)
+mode = sys.argv[2] if len(sys.argv) > 2 else "search"   # "search": tsdr_autocorr_search_d (lags + fused findmax); "lags": lags only
+if len(sys.argv) > 3:
+    ctx.set_option("ac_fuse_mid", int(sys.argv[3]))
+lo, cnt = k_hi // 9, k_hi - k_hi // 9
+idx, val = C.c_size_t(0), C.c_float(0)
 def once():
-    ctx.call("tsdr_autocorr_iq_d", C.c_void_p(iq.data_ptr()), n, Fs, 0.0, k_hi / Fs, 1, C.c_void_p(out.data_ptr()), C.byref(n_out))
+    if mode == "lags":
+        ctx.call("tsdr_autocorr_iq_d", C.c_void_p(iq.data_ptr()), n, Fs, 0.0, k_hi / Fs, 1, C.c_void_p(out.data_ptr()), C.byref(n_out))
+    else:
+        ctx.call("tsdr_autocorr_search_d", C.c_void_p(iq.data_ptr()), 1, n, Fs, 0.0, k_hi / Fs, 1, C.c_void_p(out.data_ptr()), C.byref(n_out),
+                 lo, cnt, C.byref(idx), C.byref(val))
 for _ in range(3): once()
 ctx.synchronize()
 ctx.profile(True); ctx.profile_reset()
@@ -33,4 +42,4 @@ ctx.synchronize()
 t0 = time.perf_counter()
 for _ in range(50): once()
 ctx.synchronize()
-print("back-to-back, no readback:", round((time.perf_counter() - t0) / 50 * 1e6, 1), "us per search")
+print("back-to-back (search mode: with the findmax readback):", round((time.perf_counter() - t0) / 50 * 1e6, 1), "us per search")
