@@ -252,42 +252,77 @@ def timed(ctx, fn, reps, warm=3):
     return (time.perf_counter() - t0) / reps
 
 
-def spectrum_legs(env, iq, L):
+SPECTRA_LEGS = ("welch", "waterfall", "welch_1000", "spectrum", "resampler_1024x4", "resampler_1000000x4")
+
+
+def spectrum_legs(env, iqs, L, only=None, reps_scale=1.0, warm=3):
     """GetSpectrum.jl / init_resampler on device-resident data; algorithmic bytes = input read once + API output
-    written once (8*L + output)."""
+    written once (8*L + output).
+
+    Cold-cache discipline: successive calls of a leg cycle through `iqs` -- at least four distinct capture buffers, more
+    than the 256 MiB Infinity Cache between two uses of the same one -- and through as many distinct output buffers as
+    it takes to exceed it as well, so no call finds its input (or its previous output) on-die; the resampler cycles 16
+    input/output pairs.  `traffic` beside each leg: HBM-side bytes per call from the committed rocprofv3 --pmc passes of
+    `bench.py --spectra-only <leg>` (profiles/traffic.json, "spectra")."""
     torch, ctx, dev = env["torch"], env["ctx"], env["dev"]
     p = lambda t: C.c_void_p(t.data_ptr())
     out = {}
     nb = L // 1024
-    y = torch.empty(1024, dtype=torch.float32, device=dev)
-    wf = torch.empty(nb * 1024, dtype=torch.float64, device=dev)
+    assert len(iqs) * 8 * L > 256 * 2**20, "spectrum legs need more than 256 MiB of distinct input"
+    counter = [0]
+
+    def nxt(lst):
+        counter[0] += 1
+        return lst[counter[0] % len(lst)]
 
     def leg(name, fn, nbytes, reps, note):
-        dt = timed(ctx, fn, reps)
+        if only and name not in only:
+            return
+        reps = max(1, int(reps * reps_scale))
+        dt = timed(ctx, fn, reps, warm=warm)
+        tr = measured_traffic("spectra", name, key="hbm_bytes_per_call")
         out[name] = {"us_per_call": round(dt * 1e6, 2), "algorithmic_bytes": int(nbytes), "achieved_GBs": round(nbytes / dt / 1e9, 1),
-                     "frac_of_hbm_peak": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4), "note": note}
+                     "frac_of_hbm_peak": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 4), "calls_timed": reps,
+                     "traffic": tr, "traffic_over_algorithmic": round(tr / nbytes, 2) if tr else None, "note": note}
 
-    leg("welch", lambda: ctx.call("tsdr_welch_d", p(iq), 1, L, 1024, 0, p(y)), 8 * L + 4 * 1024, 20,
-        f"getWelch(fe, sig; sizeFFT=1024), sig = one capture buffer ({L} ComplexF32, {nb} segments), dB out")
-    leg("waterfall", lambda: ctx.call("tsdr_waterfall_d", p(iq), 1, L, 1024, p(wf)), 8 * L + 8 * nb * 1024, 20,
-        "getWaterfall: Float64 (1024 x nbSeg) out")
+    y = torch.empty(1024, dtype=torch.float32, device=dev)
+    leg("welch", lambda: ctx.call("tsdr_welch_d", p(nxt(iqs)), 1, L, 1024, 0, p(y)), 8 * L + 4 * 1024, 20,
+        f"getWelch(fe, sig; sizeFFT=1024), sig = one capture buffer ({L} ComplexF32, {nb} segments), dB out; {len(iqs)} buffers cycled")
+    if not only or "waterfall" in only:
+        wfs = [torch.empty(nb * 1024, dtype=torch.float64, device=dev) for _ in range(4)]
+        leg("waterfall", lambda: ctx.call("tsdr_waterfall_d", p(nxt(iqs)), 1, L, 1024, p(wfs[counter[0] % 4])), 8 * L + 8 * nb * 1024, 20,
+            "getWaterfall: Float64 (1024 x nbSeg) out; inputs and outputs cycled")
+        del wfs
     y2 = torch.empty(1000, dtype=torch.float32, device=dev)
-    leg("welch_1000", lambda: ctx.call("tsdr_welch_d", p(iq), 1, L, 1000, 0, p(y2)), 8 * L + 4 * 1000, 10,
+    leg("welch_1000", lambda: ctx.call("tsdr_welch_d", p(nxt(iqs)), 1, L, 1000, 0, p(y2)), 8 * L + 4 * 1000, 10,
         "getWelch at sizeFFT = 1000: the general path (batched mixed-radix FFT through HBM + two-level accumulation)")
     ys = torch.empty(80000, dtype=torch.float32, device=dev)
-    leg("spectrum", lambda: ctx.call("tsdr_spectrum_d", p(iq), 1, 80000, 0, p(ys)), 8 * 80000 + 4 * 80000, 50,
-        "getSpectrum(Fs, sig[1:80_000]) (production/investigate_data.jl:44): launch-bound at this size")
+    leg("spectrum", lambda: ctx.call("tsdr_spectrum_d", C.c_void_p(nxt(iqs).data_ptr() + 8 * 80000 * (counter[0] % 64)), 1, 80000, 0, p(ys)),
+        8 * 80000 + 4 * 80000, 50,
+        "getSpectrum(Fs, sig[1:80_000]) (production/investigate_data.jl:44): launch-bound at this size; a different 80 000-sample "
+        "slice of a different buffer per call")
     for bs, up, reps in ((1024, 4, 50), (1_000_000, 4, 20)):
+        name = f"resampler_{bs}x{up}"
+        if only and name not in only:
+            continue
         h = C.c_void_p(0)
         ctx.call("tsdr_resampler_init", bs, up, C.byref(h))
-        xin = torch.randn(bs, dtype=torch.float32, device=dev)
-        xo = torch.empty(bs * up, dtype=torch.float32, device=dev)
+        npair = 16
+        xin = [torch.randn(bs, dtype=torch.float32, device=dev) for _ in range(npair)]
+        xo = [torch.empty(bs * up, dtype=torch.float32, device=dev) for _ in range(npair)]
         torch.cuda.synchronize()
         lib = ctx.lib
-        leg(f"resampler_{bs}x{up}", lambda: lib.tsdr_resampler_run_d(h, p(xin), bs, p(xo)), 4 * bs + 4 * bs * up, reps,
-            "resampler!(out, in) of init_resampler(Float32, bufferSize, upCoeff)" +
-            (" -- the size production/test_resampler.jl:49-51 times" if bs == 1024 else ""))
+
+        def run():
+            counter[0] += 1
+            i = counter[0] % npair
+            lib.tsdr_resampler_run_d(h, p(xin[i]), bs, p(xo[i]))
+        leg(name, run, 4 * bs + 4 * bs * up, reps,
+            "resampler!(out, in) of init_resampler(Float32, bufferSize, upCoeff); 16 input/output pairs cycled" +
+            (" -- the size production/test_resampler.jl:49-51 times; 20 KB per call stays cache-resident whatever is cycled" if bs == 1024
+             else " (320 MB between two uses of a pair)"))
         lib.tsdr_resampler_free(h)
+        del xin, xo
     return out
 
 
@@ -303,6 +338,9 @@ def main():
     ap.add_argument("--no-ingest", action="store_true", help="skip the host-ingest (staging ring) leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the exact / C3 / C5 / spectrum sub-legs")
     ap.add_argument("--quick", action="store_true", help="main leg only (= --no-cpu --no-ingest --no-extra), 5 repeats")
+    ap.add_argument("--spectra-only", default=None, metavar="LEG[,LEG]",
+                    help="run only the named GetSpectrum / resampler legs (--warmup + --steps calls each) and print their JSON: "
+                         "the command the rocprofv3 --pmc passes of tools/collect_profiles.sh profile.  Legs: " + ", ".join(SPECTRA_LEGS))
     ap.add_argument("--cpu-buffers", type=int, default=24, help="buffers the CPU oracle is timed on (rank 0, N=1)")
     ap.add_argument("--search-steps", type=int, default=10)
     ap.add_argument("--pipeline", choices=["on", "off"], default="off",
@@ -365,6 +403,20 @@ def main():
     env = dict(torch=torch, tsdr=tsdr, synth=synth, api=api, par=par, ctx=ctx, dev=dev, rank=rank, world=world,
                barrier=barrier, reduce_max=reduce_max)
     solo = rank == 0 and world == 1
+
+    if args.spectra_only:
+        wl = synth.WORKLOADS[args.workload]
+        L = int(round(wl["acquisition"] * wl["Fs"]))
+        g = torch.Generator().manual_seed(7)
+        iqs = [torch.view_as_real(torch.randn(L, dtype=torch.complex64, generator=g) * 3e-3).contiguous().to(dev) for _ in range(4)]
+        legs = args.spectra_only.split(",")
+        # exactly --steps calls per leg, nothing else: the PMC passes divide the counters by this number
+        base = {"welch": 20, "waterfall": 20, "welch_1000": 10, "spectrum": 50, "resampler_1024x4": 50, "resampler_1000000x4": 20}
+        r = {}
+        for lg in legs:
+            r.update(spectrum_legs(env, iqs, L, only=[lg], reps_scale=max(1, args.steps) / base[lg], warm=args.warmup))
+        print(json.dumps({"spectra_only": r, "calls_per_leg": max(1, args.steps), "warmup_calls_per_leg": args.warmup}))
+        return
 
     # ---- headline: the named workload, raster materialised unless --no-raster
     main_leg = FramesLeg(env, args.workload, args.precision, raster=not args.no_raster, pipeline=args.pipeline == "on")
@@ -437,7 +489,10 @@ def main():
     spectra = None
     if solo and not args.no_extra:
         try:
-            spectra = spectrum_legs(env, iq0, nEch)
+            g4 = torch.Generator().manual_seed(7)
+            extra_iq = torch.view_as_real(torch.randn(nEch, dtype=torch.complex64, generator=g4) * 3e-3).contiguous().to(dev)
+            spectra = spectrum_legs(env, list(main_leg.iq) + [extra_iq], nEch)
+            del extra_iq
         except Exception as e:
             spectra = {"error": f"{type(e).__name__}: {e}"}
 

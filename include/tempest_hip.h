@@ -152,6 +152,8 @@ int tsdr_resampler_run(tsdr_resampler *r, const float *in, size_t n_in, float *o
 int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float *out);
 /* initLPF's H (ComplexF32 here; sizeFFT interleaved pairs)  Resampler.jl:83-99 */
 int tsdr_resampler_lpf(tsdr_resampler *r, float *H_host);
+/* the same filter at the precision the closure applies it: ComplexF64 (the Float64 window promotes h and H, Resampler.jl:93-97) */
+int tsdr_resampler_lpf64(tsdr_resampler *r, double *H_host /* 2*sizeFFT doubles */);
 void tsdr_resampler_free(tsdr_resampler *r);
 
 /* ---- Autocorrelations.jl ------------------------------------------------------- */
@@ -204,6 +206,9 @@ int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len
  * unnormalised, inverse scaled 1/n); dir<0 forward.  batch transforms, contiguous. */
 int tsdr_fft_c2c(tsdr_ctx *ctx, const float *in, float *out, size_t n, size_t batch, int dir);
 int tsdr_fft_c2c_d(tsdr_ctx *ctx, const float *in, float *out, size_t n, size_t batch, int dir);
+/* complex f64 FFT of arbitrary length (host pointers, interleaved re/im; same conventions): the transform initLPF's
+ * ComplexF64 filter is built with (csrc/fft64.hip).  Set-up-time code, not a streaming path. */
+int tsdr_fft_z2z(tsdr_ctx *ctx, const double *in, double *out, size_t n, int dir);
 /* Diagnostics, host arithmetic only (no context, no device): the per-pass factors a length-n transform would be split
  * into -- powers of two up to 256 for n = 2^k, factors 2^a 3^b 5^c <= 256 from the cost-based planner for other smooth
  * lengths.  Returns the number of passes (factors[0 .. min(passes, cap)) filled), 0 when n takes the Bluestein route

@@ -78,6 +78,8 @@ _SIGS = {
     "tsdr_resampler_run": (C.c_int, [vp, vp, c_sz, vp]),
     "tsdr_resampler_run_d": (C.c_int, [vp, vp, c_sz, vp]),
     "tsdr_resampler_lpf": (C.c_int, [vp, vp]),
+    "tsdr_resampler_lpf64": (C.c_int, [vp, vp]),
+    "tsdr_fft_z2z": (C.c_int, [vp, vp, vp, c_sz, C.c_int]),
     "tsdr_resampler_free": (None, [vp]),
     # Autocorrelations.jl
     "tsdr_autocorr": (C.c_int, [vp, vp, c_sz, C.c_double, C.c_double, C.c_double, C.c_int, vp, c_szp]),

@@ -306,6 +306,13 @@ class Context:
         self.call("tsdr_fft_c2c", _ptr(a), _ptr(out), n, batch, 1 if inverse else -1)
         return out
 
+    def fft64(self, x, inverse=False):
+        """complex f64 FFT (tsdr_fft_z2z): the transform initLPF's ComplexF64 filter is built with"""
+        a = np.ascontiguousarray(x).astype(np.complex128)
+        out = np.empty_like(a)
+        self.call("tsdr_fft_z2z", _ptr(a), _ptr(out), a.size, 1 if inverse else -1)
+        return out
+
     # -- FrameSynchronisation.jl ------------------------------------------------------------
     def SyncXY(self, image):
         a = np.asarray(image)
@@ -509,6 +516,12 @@ class Resampler:
     def lpf(self):
         H = np.empty(self.bufferSize * self.upCoeff, np.complex64)
         check(self.ctx.h, self.ctx.lib.tsdr_resampler_lpf(self.h, _ptr(H)), "tsdr_resampler_lpf")
+        return H
+
+    def lpf64(self):
+        """H as the closure applies it: ComplexF64 (Resampler.jl:93-97)"""
+        H = np.empty(self.bufferSize * self.upCoeff, np.complex128)
+        check(self.ctx.h, self.ctx.lib.tsdr_resampler_lpf64(self.h, _ptr(H)), "tsdr_resampler_lpf64")
         return H
 
     def close(self):

@@ -155,7 +155,8 @@ __device__ inline float2 conj_if(float2 v, unsigned smask) {  // smask = 0x80000
 //   SRC_STUFF (x[g / up], 0) when up divides g, else 0: the zero-stuffed real input of the resampler (Resampler.jl:
 //             upsampling by inserting up - 1 zeros), src_n = up -- k_stuff without its pass
 //   SRC_RE0   (x[g], 0): a real f32 sequence as complex input (getSpectrum of a real signal) -- k_r2c without its pass
-//   SRC_MULH  in[g] * aux[g]: the resampler's frequency-domain filter applied while the inverse transform loads
+//   SRC_MULH  in[g] * aux[g], aux = ComplexF64 (double2 behind the float2 pointer): the resampler's frequency-domain filter
+//             applied while the inverse transform loads -- evaluated in f64 and rounded to ComplexF32 (Resampler.jl:51-53)
 enum { SRC_C2C = 0, SRC_REAL = 1, SRC_IQPOW = 2, SRC_POWER = 3, SRC_STUFF = 4, SRC_MULH = 5, SRC_RE0 = 6 };
 
 // tw_frac below (needed by the SRC_POWER loader when M = 2*Mc is not a power of two)
@@ -164,7 +165,11 @@ __device__ inline float2 tw_frac(unsigned e, double inv_n8);
 __device__ inline float2 fft_load(const float2 *__restrict__ in, int src_mode, unsigned long long src_n, size_t g,
                                   double inv_m8 = 0.0, const float2 *__restrict__ aux = nullptr) {
   if (src_mode == SRC_C2C) return in[g];
-  if (src_mode == SRC_MULH) return cmul(in[g], aux[g]);
+  if (src_mode == SRC_MULH) {
+    const float2 x = in[g];
+    const double2 h = reinterpret_cast<const double2 *>(aux)[g];
+    return make_float2((float)((double)x.x * h.x - (double)x.y * h.y), (float)((double)x.x * h.y + (double)x.y * h.x));
+  }
   if (src_mode == SRC_RE0) return make_float2(reinterpret_cast<const float *>(in)[g], 0.f);
   if (src_mode == SRC_STUFF) {
     const size_t q = g / (size_t)src_n;

@@ -10,11 +10,14 @@ struct tsdr_resampler {
   tsdr_ctx *ctx;
   size_t bufferSize, sizeFFT;
   int up;
-  float2 *H = nullptr;     // initLPF's H (ComplexF32 here), device
+  double2 *H = nullptr;    // initLPF's H: ComplexF64 as in the reference (the Float64 window promotes it, Resampler.jl:93-97)
+  double2 *Hs = nullptr;   // (H[k] + conj H[N-k]) / 2 for k <= N/2: the filter of the real part (half-size route), or null
   float2 *work = nullptr;  // containerFFT / inFFT / outFFT, device
 };
 
 namespace tsdr {
+
+int fft64_d(tsdr_ctx *ctx, double2 *data, double2 *scratch, size_t N, int dir);
 
 int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n, size_t batch, int dir);
 
@@ -252,23 +255,81 @@ __global__ __launch_bounds__(256) void k_welch_finish(const float *__restrict__ 
 }
 
 // ---- init_resampler kernels ------------------------------------------------------------------
-// h[n] = ifft(H0)[n] * blackman(n)  (window in f64, DSP.blackman: 0.42 - 0.5cos(2pi n/(N-1)) + 0.08cos(4pi n/(N-1)))
-__global__ __launch_bounds__(256) void k_window(float2 *__restrict__ h, size_t N) {
+// h[n] = ComplexF32(ifft(H0)[n]) * blackman(n): the reference's ifft runs on ComplexF32 data, the window is Float64
+// (DSP.blackman: 0.42 - 0.5cos(2pi n/(N-1)) + 0.08cos(4pi n/(N-1))), so h is ComplexF64 with f32-rounded factors
+__global__ __launch_bounds__(256) void k_window64(double2 *__restrict__ h, size_t N) {
   for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (size_t)gridDim.x * blockDim.x) {
     double w = 1.0;
     if (N > 1) {
       const double t = (double)n / (double)(N - 1);
       w = 0.42 - 0.5 * cos(2.0 * M_PI * t) + 0.08 * cos(4.0 * M_PI * t);
     }
-    const float2 v = h[n];
-    h[n] = make_float2((float)((double)v.x * w), (float)((double)v.y * w));
+    const double2 v = h[n];
+    h[n] = make_double2((double)(float)v.x * w, (double)(float)v.y * w);
   }
 }
 
 // H[k] *= (-1)^k
-__global__ __launch_bounds__(256) void k_altsign(float2 *__restrict__ H, size_t N) {
+__global__ __launch_bounds__(256) void k_altsign64(double2 *__restrict__ H, size_t N) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x)
-    if (k & 1) { float2 v = H[k]; H[k] = make_float2(-v.x, -v.y); }
+    if (k & 1) { double2 v = H[k]; H[k] = make_double2(-v.x, -v.y); }
+}
+
+// Hs[k] = (H[k] + conj H[(N-k) mod N]) / 2, k <= N/2
+__global__ __launch_bounds__(256) void k_herm_half(const double2 *__restrict__ H, size_t N, double2 *__restrict__ Hs) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= N / 2; k += (size_t)gridDim.x * blockDim.x) {
+    const double2 a = H[k], b = H[k ? N - k : 0];
+    Hs[k] = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_c64_to_c32(const double2 *__restrict__ a, size_t N, float2 *__restrict__ o) {
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x)
+    o[k] = make_float2((float)a[k].x, (float)a[k].y);
+}
+
+// ---- resampler! at its algorithmic cost (bufferSize even) ------------------------------------------------------------
+// The zero-stuffed input's spectrum is the bufferSize-point spectrum X of the input repeated upCoeff times, and only
+// real(ifft(.)) is kept (Resampler.jl:48-59), i.e. the inverse transform of the Hermitian part S[k] = X[k mod Nb] Hs[k].
+// So: P = FFT_{Nb/2}(in viewed as Nb/2 complex pairs)  ->  this kernel  ->  z = IFFT_{N/2}(Zc), out = z viewed as N reals:
+//   X[j]  = Xe + W_Nb^j Xo,  Xe = (P[j] + conj P[Nh-j]) / 2,  Xo = -i (P[j] - conj P[Nh-j]) / 2     (j <= Nh = Nb/2)
+//   S[k]  = X[k mod Nb] * Hs[k]                 -- ComplexF32 times ComplexF64 in f64, as inFFT[n] * H[n] (:51-53)
+//   A = (S[k] + conj S[M-k]) / 2,  B = conj(W_N^k) (S[k] - conj S[M-k]) / 2,   M = N/2
+//   Zc[k] = gain (A + i B),  Zc[M-k] = gain (conj A + i conj B)
+// One thread per pair (k, M-k), k <= M/2.
+__device__ inline double2 resamp_X(const float2 *__restrict__ P, size_t Nh, size_t Nb, size_t j, double w8) {
+  const bool up = j > Nh;  // X[j] = conj X[Nb - j]
+  const size_t jj = up ? Nb - j : j;
+  const float2 a = P[jj == Nh ? 0 : jj], b = P[jj == 0 || jj == Nh ? 0 : Nh - jj];
+  const double ex = 0.5 * ((double)a.x + (double)b.x), ey = 0.5 * ((double)a.y - (double)b.y);
+  const double dx = 0.5 * ((double)a.x - (double)b.x), dy = 0.5 * ((double)a.y + (double)b.y);  // (P[j] - conj P[Nh-j]) / 2
+  const double ox = dy, oy = -dx;                                                                  // times -i
+  double sn, cs;
+  sincospi(2.0 * (double)jj / (double)Nb, &sn, &cs);  // W_Nb^jj = cs - i sn
+  const double xr = ex + (cs * ox + sn * oy), xi = ey + (cs * oy - sn * ox);
+  (void)w8;
+  return make_double2(xr, up ? -xi : xi);
+}
+
+__global__ __launch_bounds__(256) void k_resamp_mid(const float2 *__restrict__ P, const double2 *__restrict__ Hs, size_t Nb, size_t N,
+                                                    double gain, float2 *__restrict__ Zc) {
+  const size_t Nh = Nb / 2, M = N / 2;
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= M / 2; k += (size_t)gridDim.x * blockDim.x) {
+    const size_t k2 = M - k;
+    const double2 x1 = resamp_X(P, Nh, Nb, k % Nb, 0.0), x2 = resamp_X(P, Nh, Nb, k2 % Nb, 0.0);
+    const double2 h1 = Hs[k], h2 = Hs[k2];
+    // the products are rounded to ComplexF32 like the reference's in-place inFFT[n] = inFFT[n] * H[n]
+    const double s1x = (double)(float)(x1.x * h1.x - x1.y * h1.y), s1y = (double)(float)(x1.x * h1.y + x1.y * h1.x);
+    const double s2x = (double)(float)(x2.x * h2.x - x2.y * h2.y), s2y = (double)(float)(x2.x * h2.y + x2.y * h2.x);
+    const double ax = 0.5 * (s1x + s2x), ay = 0.5 * (s1y - s2y);
+    const double dx = 0.5 * (s1x - s2x), dy = 0.5 * (s1y + s2y);
+    double sn, cs;
+    sincospi(2.0 * (double)k / (double)N, &sn, &cs);  // conj(W_N^k) = cs + i sn
+    const double bx = cs * dx - sn * dy, by = cs * dy + sn * dx;
+    // A + iB = (ax - by) + i (ay + bx);   conj A + i conj B = (ax + by) + i (-ay + bx)
+    Zc[k] = make_float2((float)(gain * (ax - by)), (float)(gain * (ay + bx)));
+    if (k2 < M && k2 != k) Zc[k2] = make_float2((float)(gain * (ax + by)), (float)(gain * (bx - ay)));
+  }
 }
 
 // containerFFT[1:up:end] .= in  (zero elsewhere)
@@ -279,10 +340,12 @@ __global__ __launch_bounds__(256) void k_stuff(const float *__restrict__ in, siz
   }
 }
 
-__global__ __launch_bounds__(256) void k_cmul(float2 *__restrict__ a, const float2 *__restrict__ b, size_t N) {
+// inFFT[n] = inFFT[n] * H[n]: ComplexF32 times ComplexF64, evaluated in f64 and stored back as ComplexF32 (:51-53)
+__global__ __launch_bounds__(256) void k_cmul(float2 *__restrict__ a, const double2 *__restrict__ b, size_t N) {
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (size_t)gridDim.x * blockDim.x) {
-    const float2 x = a[k], h = b[k];
-    a[k] = make_float2(x.x * h.x - x.y * h.y, x.x * h.y + x.y * h.x);
+    const float2 x = a[k];
+    const double2 h = b[k];
+    a[k] = make_float2((float)((double)x.x * h.x - (double)x.y * h.y), (float)((double)x.x * h.y + (double)x.y * h.x));
   }
 }
 
@@ -334,7 +397,7 @@ __device__ inline void wg_fft4096(float2 (&v)[16], float2 *z, const float2 (&twA
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_resample4096(const float *__restrict__ in, unsigned up, const float2 *__restrict__ H,
+__global__ __launch_bounds__(256) void k_resample4096(const float *__restrict__ in, unsigned up, const double2 *__restrict__ H,
                                                       const float2 *__restrict__ tw4096, float gain, float *__restrict__ out) {
   __shared__ float2 z[256 * 17];
   const int tid = threadIdx.x;
@@ -352,9 +415,10 @@ __global__ __launch_bounds__(256) void k_resample4096(const float *__restrict__ 
   }
   wg_fft4096(v, z, twA, twB, tid);
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {  // filter, and conj for the inverse transform
-    const float2 y = cmul(v[m], H[tid + 256 * m]);
-    v[m] = make_float2(y.x, -y.y);
+  for (int m = 0; m < 16; ++m) {  // filter (ComplexF32 x ComplexF64 in f64, stored as ComplexF32), and conj for the inverse transform
+    const double2 h = H[tid + 256 * m];
+    const double xr = v[m].x, xi = v[m].y;
+    v[m] = make_float2((float)(xr * h.x - xi * h.y), -(float)(xr * h.y + xi * h.x));
   }
   wg_fft4096(v, z, twA, twB, tid);
   const float inv = 1.0f / 4096.0f;
@@ -510,36 +574,43 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
   if (N >= (size_t(1) << 30)) return set_err(ctx, TSDR_EINVAL, "init_resampler: sizeFFT too large");
   tsdr_resampler *r = new tsdr_resampler();
   r->ctx = ctx; r->bufferSize = bufferSize; r->up = upCoeff; r->sizeFFT = N;
-  if (hipMalloc((void **)&r->H, N * sizeof(float2)) != hipSuccess || hipMalloc((void **)&r->work, N * sizeof(float2)) != hipSuccess) {
+  double2 *scratch = nullptr;
+  const bool half = (bufferSize % 2 == 0) && bufferSize >= 4;
+  if (hipMalloc((void **)&r->H, N * sizeof(double2)) != hipSuccess || hipMalloc((void **)&r->work, N * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void **)&scratch, N * sizeof(double2)) != hipSuccess ||
+      (half && hipMalloc((void **)&r->Hs, (N / 2 + 1) * sizeof(double2)) != hipSuccess)) {
+    (void)hipFree(scratch);
     tsdr_resampler_free(r);
     return set_err(ctx, TSDR_ENOMEM, "init_resampler: allocation failed");
   }
   // H0 = round.(H .* exp(im*groupDelay*pulsation)) with H[1:bound]=1  (:85-91): entries are
   // integers in {-1,0,1}; evaluated on the host in f64 like the reference's broadcast.
-  std::vector<float2> H0(N, make_float2(0.f, 0.f));
+  std::vector<double2> H0(N, make_double2(0.0, 0.0));
   const double bound_d = nearbyint((double)N / (double)upCoeff / 2.0);
   const size_t bound = bound_d < (double)N ? (size_t)bound_d : N;
   const double g = -((double)N - 1.0) / 2.0;
   for (size_t k = 0; k < bound; ++k) {
     const double om = (double)(2.0L * M_PIl * (long double)k / (long double)N);
     const double th = g * om;
-    H0[k] = make_float2((float)nearbyint(cos(th)), (float)nearbyint(sin(th)));
+    H0[k] = make_double2(nearbyint(cos(th)), nearbyint(sin(th)));
   }
-  hipError_t e = hipMemcpyAsync(r->work, H0.data(), N * sizeof(float2), hipMemcpyHostToDevice, ctx->stream);
+  hipError_t e = hipMemcpyAsync(r->H, H0.data(), N * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { tsdr_resampler_free(r); return hip_fail(ctx, e, "init_resampler upload"); }
-  // h = ifft(H0) .* blackman ; H = fft(h) .* (-1)^k
-  int rc = fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, r->H, N, 1, +1);
+  if (e != hipSuccess) { (void)hipFree(scratch); tsdr_resampler_free(r); return hip_fail(ctx, e, "init_resampler upload"); }
+  // h = ifft(H0) .* blackman  (ifft on ComplexF32 data in the reference, the window and everything after it in f64);
+  // H = fft(h) .* (-1)^k -- on the device in f64 (fft64.hip)
+  int rc = fft64_d(ctx, r->H, scratch, N, +1);
   if (!rc) {
-    hipLaunchKernelGGL(k_window, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->H, N);
-    rc = fft_any(ctx, reinterpret_cast<const float *>(r->H), 1, r->work, N, 1, -1);
+    hipLaunchKernelGGL(k_window64, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->H, N);
+    rc = fft64_d(ctx, r->H, scratch, N, -1);
   }
   if (!rc) {
-    hipLaunchKernelGGL(k_altsign, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->work, N);
-    e = hipMemcpyAsync(r->H, r->work, N * sizeof(float2), hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipLaunchKernelGGL(k_altsign64, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->H, N);
+    if (r->Hs) hipLaunchKernelGGL(k_herm_half, dim3(stream_grid(ctx, N / 2 + 1)), dim3(256), 0, ctx->stream, (const double2 *)r->H, N, r->Hs);
+    e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) rc = hip_fail(ctx, e, "init_resampler finalize");
   }
+  (void)hipFree(scratch);
   if (rc) { tsdr_resampler_free(r); return rc; }
   *out = r;
   return TSDR_OK;
@@ -550,15 +621,27 @@ int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float 
   tsdr_ctx *ctx = r->ctx;
   if (n_in != r->bufferSize) return set_err(ctx, TSDR_EINVAL, "Size of input %zu should match size used during init %zu", n_in, r->bufferSize);
   const size_t N = r->sizeFFT;
-  float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
-  if (!tmp) return TSDR_ENOMEM;
   if (N == 4096) {  // one workgroup, one launch
     int rc = ensure_tw_small(ctx);
     if (rc) return rc;
-    TSDR_LAUNCH(ctx, "resampler_4096", k_resample4096, dim3(1), dim3(256), 0, in, (unsigned)r->up, (const float2 *)r->H,
+    TSDR_LAUNCH(ctx, "resampler_4096", k_resample4096, dim3(1), dim3(256), 0, in, (unsigned)r->up, (const double2 *)r->H,
                 (const float2 *)ctx->tw_small, (float)(2 * r->up), out);
     return TSDR_OK;
   }
+  if (r->Hs && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7u) == 0) {
+    // the algorithmic cost (see k_resamp_mid): a forward transform of bufferSize/2 complex points on the input as it
+    // lies, one pointwise kernel, an inverse transform of N/2 complex points written straight into `out`
+    const size_t Nh = r->bufferSize / 2, M = N / 2;
+    float2 *P = (float2 *)ctx->scratch(WS_FFT_A, Nh * sizeof(float2));
+    if (!P) return TSDR_ENOMEM;
+    int rc = fft_any(ctx, in, 1, P, Nh, 1, -1);
+    if (rc) return rc;
+    TSDR_LAUNCH(ctx, "resampler_mid", k_resamp_mid, dim3(stream_grid(ctx, M / 2 + 1)), dim3(256), 0, (const float2 *)P,
+                (const double2 *)r->Hs, r->bufferSize, N, (double)(2 * r->up), r->work);
+    return fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, reinterpret_cast<float2 *>(out), M, 1, +1);
+  }
+  float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
+  if (!tmp) return TSDR_ENOMEM;
   const int passes = fft_passes(N);
   if (passes >= 2) {
     // two transforms and nothing else: the zero-stuffing is the forward transform's loader, the filter the inverse
@@ -574,13 +657,13 @@ int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float 
     epi.cnt = N;
     epi.gain = (float)(2 * r->up);
     const float inv = (float)(1.0 / (double)N);
-    return p2 ? fft_pow2(ctx, tmp, r->work, ilog2(N), 1, +1, inv, SRC_MULH, 0, 0, &epi, (const float2 *)r->H)
-              : fft_mixed(ctx, tmp, r->work, N, 1, +1, inv, SRC_MULH, 0, 0, &epi, (const float2 *)r->H);
+    return p2 ? fft_pow2(ctx, tmp, r->work, ilog2(N), 1, +1, inv, SRC_MULH, 0, 0, &epi, reinterpret_cast<const float2 *>(r->H))
+              : fft_mixed(ctx, tmp, r->work, N, 1, +1, inv, SRC_MULH, 0, 0, &epi, reinterpret_cast<const float2 *>(r->H));
   }
   TSDR_LAUNCH(ctx, "resampler_stuff", k_stuff, dim3(stream_grid(ctx, N)), dim3(256), 0, in, N, (unsigned)r->up, r->work);
   int rc = fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, tmp, N, 1, -1);
   if (rc) return rc;
-  TSDR_LAUNCH(ctx, "resampler_filter", k_cmul, dim3(stream_grid(ctx, N)), dim3(256), 0, tmp, (const float2 *)r->H, N);
+  TSDR_LAUNCH(ctx, "resampler_filter", k_cmul, dim3(stream_grid(ctx, N)), dim3(256), 0, tmp, (const double2 *)r->H, N);
   rc = fft_any(ctx, reinterpret_cast<const float *>(tmp), 1, r->work, N, 1, +1);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "resampler_out", k_real_scale, dim3(stream_grid(ctx, N)), dim3(256), 0, (const float2 *)r->work, N,
@@ -598,15 +681,46 @@ int tsdr_resampler_run(tsdr_resampler *r, const float *in, size_t n_in, float *o
 int tsdr_resampler_lpf(tsdr_resampler *r, float *H_host) {
   if (!r || !H_host) return TSDR_EINVAL;
   tsdr_ctx *ctx = r->ctx;
-  TSDR_HIP(ctx, hipMemcpyAsync(H_host, r->H, r->sizeFFT * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
+  float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, r->sizeFFT * sizeof(float2));
+  if (!tmp) return TSDR_ENOMEM;
+  TSDR_LAUNCH(ctx, "lpf_c32", k_c64_to_c32, dim3(stream_grid(ctx, r->sizeFFT)), dim3(256), 0, (const double2 *)r->H, r->sizeFFT, tmp);
+  TSDR_HIP(ctx, hipMemcpyAsync(H_host, tmp, r->sizeFFT * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TSDR_OK;
+}
+
+int tsdr_resampler_lpf64(tsdr_resampler *r, double *H_host) {
+  if (!r || !H_host) return TSDR_EINVAL;
+  tsdr_ctx *ctx = r->ctx;
+  TSDR_HIP(ctx, hipMemcpyAsync(H_host, r->H, r->sizeFFT * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TSDR_OK;
+}
+
+int tsdr_fft_z2z(tsdr_ctx *ctx, const double *in, double *out, size_t n, int dir) {
+  if (!ctx || (n && (!in || !out))) return TSDR_EINVAL;
+  if (n == 0) return TSDR_OK;
+  if (n >= (size_t(1) << 30)) return set_err(ctx, TSDR_EINVAL, "fft_z2z: length too large");
+  double2 *d = nullptr, *sc = nullptr;
+  if (hipMalloc((void **)&d, n * sizeof(double2)) != hipSuccess || hipMalloc((void **)&sc, n * sizeof(double2)) != hipSuccess) {
+    (void)hipFree(d); (void)hipFree(sc);
+    return set_err(ctx, TSDR_ENOMEM, "fft_z2z: allocation failed");
+  }
+  int rc = TSDR_OK;
+  hipError_t e = hipMemcpyAsync(d, in, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) rc = fft64_d(ctx, d, sc, n, dir);
+  if (e == hipSuccess && !rc) e = hipMemcpyAsync(out, d, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d); (void)hipFree(sc);
+  if (!rc && e != hipSuccess) rc = hip_fail(ctx, e, "fft_z2z");
+  return rc;
 }
 
 void tsdr_resampler_free(tsdr_resampler *r) {
   if (!r) return;
   if (r->ctx) (void)hipStreamSynchronize(r->ctx->stream);
   if (r->H) (void)hipFree(r->H);
+  if (r->Hs) (void)hipFree(r->Hs);
   if (r->work) (void)hipFree(r->work);
   delete r;
 }

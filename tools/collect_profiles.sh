@@ -14,5 +14,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmc_$c -o run -- python3 $R/bench.py --quick --steps 5 --warmup 2 --repeats 1 > /dev/null 2>&1
 done
 python3 $R/tools/make_traffic.py $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE $TAG C2 > $O/${TAG}_traffic.json
+# GetSpectrum / resampler legs: one short profiled run per leg and counter (cold-cache cycling as in the bench)
+CALLS=8
+for leg in welch waterfall welch_1000 spectrum resampler_1024x4 resampler_1000000x4; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf $O/${TAG}_pmcs_${leg}_$c
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${TAG}_pmcs_${leg}_$c -o run -- python3 $R/bench.py --spectra-only $leg --steps $CALLS --warmup 0 > /dev/null 2>&1
+  done
+  python3 $R/tools/make_traffic.py --spectra $leg $CALLS $O/${TAG}_pmcs_${leg}_FETCH_SIZE $O/${TAG}_pmcs_${leg}_WRITE_SIZE $TAG >> $O/${TAG}_traffic_spectra.txt
+  rm -rf $O/${TAG}_pmcs_${leg}_FETCH_SIZE $O/${TAG}_pmcs_${leg}_WRITE_SIZE
+done
 cp $R/profiles/traffic.json $O/${TAG}_traffic_full.json
 ls $O | grep $TAG

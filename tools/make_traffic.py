@@ -12,6 +12,7 @@ NAMES = {  # kernel-name substring -> bench.py's launch name
     "k_raster_fast<true, true, true, 32, false": "down_walk_iq",
     "k_raster_tile<true, true>": "raster_down_iq_exact",
     "k_shift_iir": "shift_iir", "k_proj": "sync_proj", "k_beta": "sync_beta", "k_tail": "sync_beta+shift_iir",
+    "k_down_fused<true, 0>": "guard_image",
     "k_seg1024<false": "welch_seg1024", "k_seg1024<true": "waterfall_seg1024",
 }
 
@@ -38,14 +39,43 @@ def search_totals(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             k = r["Kernel_Name"]
-            if "k_fft_" in k or "k_ac_" in k or "k_argmax" in k:
+            if "k_fft_" in k or "k_ac_" in k or "k_argmax" in k or "k_amax_publish" in k:
                 tot += float(r["Counter_Value"])
-            if "k_argmax" in k:
+            if "k_argmax" in k or "k_amax_publish" in k:
                 n += 1
     return (tot / n if n else 0.0), n
 
 
+def run_total(d, counter):
+    """sum of `counter` over every kernel launch of one profiled run"""
+    tot = 0.0
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and not r["Kernel_Name"].startswith("void at::") and "at::native" not in r["Kernel_Name"]:
+                tot += float(r["Counter_Value"])
+    return tot
+
+
+def spectra_main():
+    """make_traffic.py --spectra <leg> <calls> <fetch dir> <write dir> <tag>: HBM-side bytes per call of one GetSpectrum /
+    resampler leg from the PMC passes of `bench.py --spectra-only <leg> --steps <calls>` (every library kernel of the run
+    summed -- torch's own fill kernels excluded -- and divided by the number of calls)."""
+    leg, calls, fdir, wdir, tag = sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        doc = {}
+    f, w = run_total(fdir, "FETCH_SIZE") / calls, run_total(wdir, "WRITE_SIZE") / calls
+    doc.setdefault("spectra", {})[leg] = {"fetch_size_kb": round(f), "write_size_kb": round(w), "hbm_bytes_per_call": int(f * 1024 * 2 + w * 1024),
+                                          "calls": calls, "tag": tag}
+    json.dump(doc, open(path, "w"), indent=1)
+    print(leg, json.dumps(doc["spectra"][leg]))
+
+
 def main():
+    if sys.argv[1] == "--spectra":
+        return spectra_main()
     fdir, wdir, tag = sys.argv[1:4]
     wl = sys.argv[4] if len(sys.argv) > 4 else "C2"
     f, w = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
@@ -59,7 +89,10 @@ def main():
                     f"the passes tagged {tag}.  Counter unit KB, median over a kernel's launches.  gfx950 correction per "
                     "MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts coalesced reads at one half, so fetch bytes = "
                     "FETCH_SIZE*1024*2; WRITE_SIZE taken as is.  Infinity-Cache hits are included in FETCH_SIZE.")
+    spectra_keep = doc.get("spectra")
     doc[wl] = {}
+    if spectra_keep:
+        doc["spectra"] = spectra_keep
     for k in sorted(set(f) | set(w)):
         fk, wk = f.get(k, 0.0), w.get(k, 0.0)
         doc[wl][k] = {"fetch_size_kb": round(fk), "write_size_kb": round(wk), "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)}
