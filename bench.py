@@ -558,7 +558,11 @@ def main():
                        "precision": args.precision, "distinct_buffers_cycled": 3,
                        "pipeline": ("two-stage across buffers (tsdr_frames_submit_d): raster stage of buffer k+1 overlaps "
                                     "the vsync/IIR stage of buffer k" if args.pipeline == "on" else "off: one tsdr_frames_d per buffer"),
-                       "sharding": "one capture buffer per GPU, no data-path collective"},
+                       "sharding": "one capture buffer per GPU, no data-path collective",
+                       "value_contains_collective": False,
+                       "collectives_measured_elsewhere_in_this_line": ("strong (one buffer's frames sharded: all_gather / gather_root of the "
+                                                                       "600x800 images), strong.welch_sharded and search (all-reduce of "
+                                                                       "accumulators over RCCL)") if world > 1 else None},
             "timing": {"repeats": res["repeats"], "value_is": "median of the repeated K-step timed regions",
                        "ms_per_step_min": res["ms_per_step_min"], "ms_per_step_median": res["ms_per_step"],
                        "ms_per_step_max": res["ms_per_step_max"]},

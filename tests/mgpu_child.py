@@ -59,7 +59,28 @@ def main():
         if not good:
             print(f"rank {rank}: HipFrames[{precision}] at world {world} differs from the single-GPU loop", flush=True)
             ok = False
+        # gather-to-root: only the rendering rank receives the frames and runs stage 2
+        root = world - 1
+        state.zero_(); frames.zero_(); idx.zero_()
+        torch.cuda.synchronize()
+        hg = par.HipFrames(ctx, tsdr.SyncXY(ctx, 600, 800), dev, world, rank, mode="gather_root", root=root)
+        assert hg.run(t_iq, iq.size, S, y_t, x_t, np.float32(0.1), state, frames, idx) == nfr
+        if rank == root:
+            good = (np.array_equal(idx.cpu().numpy().reshape(nfr, 2), ref["sync_idx"]) and
+                    np.array_equal(state.cpu().numpy().view(np.uint32), ref_state.ravel(order="F").view(np.uint32)) and
+                    all(np.array_equal(frames.cpu().numpy()[f * 480000:(f + 1) * 480000].view(np.uint32),
+                                       ref["frames"][f].ravel(order="F").view(np.uint32)) for f in range(nfr)))
+            if not good:
+                print(f"rank {rank}: HipFrames[{precision}, gather_root] at world {world} differs from the single-GPU loop", flush=True)
+                ok = False
     ctx.set_precision("fast")
+    # ---- getWelch of one capture, segments sharded, one all-reduce of 1024 floats
+    Lw = (iq.size // 1024) * 1024
+    want = ctx.getWelch(Fs, iq[:Lw])[1]
+    got = par.HipWelch(ctx, dev, world, rank).run(t_iq, Lw).cpu().numpy()
+    if not np.max(np.abs(got - want)) < 2e-4:   # dB
+        print(f"rank {rank}: HipWelch at world {world}: {np.max(np.abs(got - want)):.3e} dB off the single-GPU getWelch", flush=True)
+        ok = False
     # ---- search: n = 4 * n_lags so that the sharded transform IS smaller and the all-reduce route is the honest choice
     n, n_lags = 240_000, 60_000
     assert par.search_route(n, n_lags, world) in ("sharded", "replicated")

@@ -183,6 +183,31 @@ def _worker_frames(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_welch(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tempest_loader import load_package
+    load_package()
+    par = importlib.import_module("tempestsdr_jl_amd.parallel")
+    rng = np.random.default_rng(9)
+    size, nb = 64, 37   # 37 segments: ragged over the ranks
+    z = (rng.standard_normal(size * nb + 5) + 1j * rng.standard_normal(size * nb + 5)).astype(np.complex64)
+
+    def partial(s0, cnt):  # numpy stand-in for tsdr_welch_d(lin = 1) on this rank's segments
+        seg = z[s0 * size:(s0 + cnt) * size].reshape(cnt, size).astype(np.complex128)
+        return torch.from_numpy(np.fft.fftshift(np.sum(np.abs(np.fft.fft(seg, axis=1)) ** 2, axis=0)))
+
+    def all_reduce(buf):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+    out = par.welch_sharded(partial, all_reduce, lambda b: 10 * np.log10(b.numpy()), nb, world, rank)
+    ref = O.getWelch(z, size)
+    q.put((rank, float(np.max(np.abs(out - ref)))))
+    dist.destroy_process_group()
+
+
 def _spawn(fn, world=2):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)
@@ -202,6 +227,12 @@ def test_sharded_autocorr_gloo_world2():
     res = _spawn(_worker_autocorr)
     for rank, err_db, am, am_ref in res:
         assert err_db < 1e-3 and am == am_ref, (rank, err_db, am, am_ref)
+
+
+def test_sharded_welch_gloo_world2():
+    """getWelch of one capture with its segments sharded: partial sums, ONE all-reduce of sizeFFT floats, 10log10 after"""
+    for rank, err_db in _spawn(_worker_welch):
+        assert err_db < 1e-4, (rank, err_db)
 
 
 def test_sharded_frames_gloo_world2():
