@@ -20,6 +20,7 @@ export calculate_autocorrelation, zoom_autocorr
 export getSpectrum, getWelch, getWaterfall
 export SyncXY, vsync
 export hip_frames!           # fused GUI.jl:163-178 loop body (optional fast path)
+export hip_extract_configuration, sync_guard_stats   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
 
 const LIB = get(ENV, "TEMPEST_HIP_LIB", joinpath(@__DIR__, "..", "libtempest_hip.so"))
 const RENDERING_SIZE = (600, 800)   # GUI.jl:10
@@ -120,8 +121,11 @@ end
 init_resampler(x::Vector{T}, upCoeff) where T = init_resampler(T, length(x), upCoeff)   # :65-68
 
 # ---- Autocorrelations.jl ------------------------------------------------------------------
-function calculate_autocorrelation(x, Fs, minDelay, maxDelay, scale = :log)   # Autocorrelations.jl:23-37
-    xv = x isa Vector{Float32} ? x : convert(Vector{Float32}, x)
+# Element types.  The reference's functions are generic in T; its own callers (GUI.jl, production/) only ever pass
+# Float32 / ComplexF32, and those are the methods this shim defines.  Anything else is a MethodError -- never a silent
+# conversion to Float32, which would compute in less precision than the reference would have (INTEGRATION.md, section 4).
+function calculate_autocorrelation(x::AbstractVector{Float32}, Fs, minDelay, maxDelay, scale = :log)   # Autocorrelations.jl:23-37
+    xv = _dense(x)
     indexMin = 1 + round(minDelay * Fs) |> Int
     indexMax = round(maxDelay * Fs) |> Int
     out = Vector{Float32}(undef, max(indexMax - indexMin + 1, 1)); n = Ref{Csize_t}(0); c = ctx()
@@ -141,8 +145,8 @@ function zoom_autocorr(Γ, Fs; rate_min = 20, rate_max = 100)                 # 
 end
 
 # ---- GetSpectrum.jl -------------------------------------------------------------------------
-_raw(sig::AbstractVector{<:Complex}) = (convert(Vector{ComplexF32}, sig), 1)
-_raw(sig::AbstractVector{<:Real}) = (convert(Vector{Float32}, sig), 0)
+_raw(sig::AbstractVector{ComplexF32}) = (_dense(sig), 1)
+_raw(sig::AbstractVector{Float32}) = (_dense(sig), 0)
 function getSpectrum(fs, sig; N = nothing)                                   # GetSpectrum.jl:21-30
     isnothing(N) && (N = length(sig))
     N <= length(sig) || throw(BoundsError(sig, N))
@@ -204,6 +208,49 @@ function hip_frames!(imageOut::Matrix{Float32}, sigId::Vector{ComplexF32}, sync:
                         (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{ComplexF32}, Csize_t, Csize_t, Cint, Cint, Cfloat, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cint}, Ptr{Cint}),
                         sync.c.h, sync.h, sigId, length(sigId), S, y_t, x_t, α, do_align ? 1 : 0, imageOut, frames, C_NULL, idx, n), "hip_frames!")
     return frames, idx
+end
+
+# ---- fused configuration search (GUI.jl:67-81) ------------------------------------------------------
+"""
+    hip_extract_configuration(sigId, Fs; delay = 0.1, rate_min = 50, rate_max = 90) -> (rates_refresh, Γ_refresh, fv)
+
+`extract_configuration`'s arithmetic (GUI.jl:67-81) as one library call on the raw IQ: `abs2.` formed while loading,
+`calculate_autocorrelation(., Fs, 0, delay)`, `zoom_autocorr(.; rate_min, rate_max)` and `findmax`, the last found by the
+launch that writes the lags.
+"""
+function hip_extract_configuration(sigId::Vector{ComplexF32}, Fs; delay = 0.1, rate_min = 50, rate_max = 90)
+    indexMax = round(delay * Fs) |> Int
+    Γ = Vector{Float32}(undef, max(indexMax, 1)); n = Ref{Csize_t}(0); c = ctx()
+    pmin = Ref{Csize_t}(0); pmax = Ref{Csize_t}(0)
+    rc = ccall((:tsdr_zoom_bounds, LIB), Cint, (Csize_t, Cdouble, Cdouble, Cdouble, Ptr{Csize_t}, Ptr{Csize_t}),
+               indexMax, Fs, rate_min, rate_max, pmin, pmax)
+    rc == 0 || throw(BoundsError(Γ, Int(pmin[]):Int(pmax[])))
+    d_in = ccall((:tsdr_dev_alloc, LIB), Ptr{Cvoid}, (Ptr{Cvoid}, Csize_t), c.h, sizeof(sigId))
+    d_out = ccall((:tsdr_dev_alloc, LIB), Ptr{Cvoid}, (Ptr{Cvoid}, Csize_t), c.h, sizeof(Γ))
+    (d_in == C_NULL || d_out == C_NULL) && throw(OutOfMemoryError())
+    idx = Ref{Csize_t}(0); val = Ref{Cfloat}(0)
+    try
+        check(c, ccall((:tsdr_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, d_in, sigId, sizeof(sigId)), "upload")
+        check(c, ccall((:tsdr_autocorr_search_d, LIB), Cint,
+                       (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t, Cdouble, Cdouble, Cdouble, Cint, Ptr{Cvoid}, Ptr{Csize_t}, Csize_t, Csize_t, Ptr{Csize_t}, Ptr{Cfloat}),
+                       c.h, d_in, 1, length(sigId), Fs, 0.0, delay, 1, d_out, n, pmin[] - 1, pmax[] - pmin[] + 1, idx, val), "extract_configuration")
+        check(c, ccall((:tsdr_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, Γ, d_out, n[] * sizeof(Float32)), "download")
+    finally
+        ccall((:tsdr_dev_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, d_in)
+        ccall((:tsdr_dev_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, d_out)
+    end
+    xAx = (Int(pmin[]):Int(pmax[])) ./ Fs
+    rates_refresh = 1 ./ xAx
+    Γ_refresh = Γ[Int(pmin[]):Int(pmax[])]
+    fv = 1 / (1 / rates_refresh[Int(idx[]) + 1])                            # GUI.jl:80-81
+    return rates_refresh, Γ_refresh, fv
+end
+
+"(frames checked, frames re-evaluated in the exact sequence) by the TSDR_FAST frame loop's sync guard on this task's context"
+function sync_guard_stats(; reset = false)
+    a = Ref{Culonglong}(0); b = Ref{Culonglong}(0); c = ctx()
+    check(c, ccall((:tsdr_sync_guard_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Culonglong}, Ptr{Culonglong}, Cint), c.h, a, b, reset ? 1 : 0), "sync_guard_stats")
+    return (Int(a[]), Int(b[]))
 end
 
 # ---- streaming ingest: the staging ring (AtomicAbstractSDRs.jl:64-190 on pinned memory) ----------

@@ -111,6 +111,15 @@ def get_refresh_rates(subdict):
     return seen
 
 
+# (height, refresh) pairs of the table that TWO modes of different width share.  For a line count nearest to one of these
+# heights the reference returns both entries and @warns (:104-106); its callers then take the first entry of the
+# sub-Dict (dict2video, investigate_data.jl:92-97), i.e. whichever comes first in Julia's hash order of the String keys
+# -- a property of Base.hash and the Dict's growth history, not of TempestSDR.jl.  Here the order is the table's own
+# (VideoConfigurations.jl:12-93, top to bottom).  Everywhere else the result does not depend on any order.
+# tests/golden/make_golden.jl dumps Julia's order so that a Julia run can pin the three picks.
+AMBIGUOUS_HEIGHT_REFRESH = ((795, 60.0), (1087, 60.0), (1500, 75.0))
+
+
 def _find_closest_configuration(y_t, d):
     """:99-108 -- every entry whose height is nearest to y_t (squared distance, exact ties kept)"""
     dist = [abs(float(y_t) - m.height) ** 2 for m in d.values()]

@@ -199,6 +199,19 @@ function main()
         save("fr$(tag)_state_sub", sub(state, 499))
         save("fr$(tag)_state_chk", chk64(state))
     end
+    # ---- VideoConfigurations.jl: the iteration order of the mode Dict.  find_closest_configuration's callers take the
+    # FIRST entry of the sub-Dict it returns (dict2video, investigate_data.jl:92-97); three (height, refresh) pairs of
+    # the table are shared by two modes of different width, so which width comes back is decided by this order.
+    try
+        include(joinpath(REF, "src", "VideoConfigurations.jl"))
+        open(joinpath(OUT, "video_dict_order.txt"), "w") do io
+            for k in keys(Main.VideoConfigurations.allVideoConfigurations)
+                println(io, k)
+            end
+        end
+    catch e
+        @warn "VideoConfigurations.jl not dumped" e
+    end
     open(joinpath(OUT, "PROVENANCE.txt"), "w") do io
         println(io, "written by tests/golden/make_golden.jl")
         println(io, "julia ", VERSION, "  reference checkout: ", REF)

@@ -299,6 +299,30 @@ def test_record_buffers_round_trip(tmp_path):
     assert np.array_equal(np.asarray(back, np.complex64), np.concatenate(bufs))
 
 
+def test_mode_table_order_matters_only_for_three_known_pairs():
+    """find_closest_configuration returns every entry at the nearest height; the caller takes the first.  Which entry is
+    first depends on the Dict's iteration order (Julia: hash order; here: table order) only when two modes share
+    (height, refresh) -- exactly the three pairs video_configurations.AMBIGUOUS_HEIGHT_REFRESH lists; for every other
+    (y_t, fv) in and around the table the sub-dict has ONE entry whatever the order, and a tie between two refresh
+    rates needs fv exactly half-way between them."""
+    import warnings
+    from collections import defaultdict
+    from tempestsdr_jl_amd import video_configurations as vc
+    groups = defaultdict(list)
+    for name, m in vc.allVideoConfigurations.items():
+        groups[(m.height, m.refresh)].append((name, m.width))
+    shared = sorted(k for k, v in groups.items() if len(v) > 1)
+    assert shared == sorted(vc.AMBIGUOUS_HEIGHT_REFRESH)
+    assert all(len({w for _, w in groups[k]}) == 2 for k in shared)   # and there the widths differ: the pick matters
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, m in vc.allVideoConfigurations.items():
+            for dy in (-0.4, 0.0, 0.4):
+                sub = vc.find_closest_configuration(m.height + dy, m.refresh)
+                assert name in sub
+                assert (len(sub) > 1) == ((m.height, m.refresh) in vc.AMBIGUOUS_HEIGHT_REFRESH), (name, sub)
+
+
 def test_search_route_choice():
     """The sharded search is used only when a rank's segment+halo transform is smaller than the single-GPU one; with
     the reference's window (n = 2 * n_lags) the halo puts the same floor under both and every rank runs the

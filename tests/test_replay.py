@@ -32,11 +32,14 @@ class OracleBackend:
         return sync.vsync(image)
 
 
-def _capture(tsdr, tmp_path):
+def _capture(tsdr, tmp_path, c1_size=False):
     synth = importlib.import_module("tempestsdr_jl_amd.synth")
     dat = importlib.import_module("tempestsdr_jl_amd.dat_files")
-    Fs, x_t, y_t, fv = 2.0e6, 1056, 628, 60.0             # "800x600 @ 60Hz" (VideoConfigurations.jl:27) at 2 MS/s
-    iq = synth.synth_leak(Fs, x_t, y_t, fv, 600_000)
+    if c1_size:   # BASELINE config 1 at its own size: a 20 MS/s capture of the 1080p60 mode (2576 x 1125 total), 0.25 s
+        Fs, x_t, y_t, fv, n = 20.0e6, 2576, 1125, 60.0, 5_000_000
+    else:
+        Fs, x_t, y_t, fv, n = 2.0e6, 1056, 628, 60.0, 600_000   # "800x600 @ 60Hz" (VideoConfigurations.jl:27) at 2 MS/s
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, n)
     path = str(tmp_path / "dumpIQ_0.dat")
     dat.writeComplexBinary(iq, path, "single")             # DatBinaryFiles.jl:15-31, the GUI's record format
     return path, Fs, (x_t, y_t, fv)
@@ -73,6 +76,38 @@ def test_replay_flow_gpu_matches_oracle(ctx, tsdr, tmp_path):
         assert g[k] == o[k], (k, g[k], o[k])
     assert g["mode"].width == o["mode"].width and g["mode"].height == o["mode"].height
     # the per-function API is EXACT: images bit for bit
+    assert np.array_equal(g["image"].view(np.uint32), o["image"].view(np.uint32))
+    assert np.array_equal(g["aligned"].view(np.uint32), o["aligned"].view(np.uint32))
+    assert np.max(np.abs(g["G"] - o["G"])) < 2e-4
+
+
+def _check_c1(r, Fs, x_t, y_t, fv):
+    assert abs(r["fv"] - fv) < 0.1, r["fv"]
+    assert abs(Fs / (r["fv"] * r["y_t"]) - Fs / (fv * y_t)) <= 1.5, r["y_t"]
+    assert r["name"] == "1920x1080 @ 60Hz" and r["mode"].width == x_t, (r["name"], r["mode"])
+    assert r["sync"][0] == 1 and 1 <= r["sync"][1] <= x_t
+    assert r["tau"] == r["sync"][1] * r["mode"].width + r["sync"][0]
+    assert r["aligned"].shape == (r["mode"].height, r["mode"].width)
+
+
+def test_replay_flow_at_c1_size_on_oracle(tsdr, tmp_path):
+    """the same flow at BASELINE config 1's own size (production/investigate_data.jl works on a 20 MS/s capture):
+    40 MB .dat, n = 4e6 autocorrelation, 1125 x 2576 rasters, vsync on the full raster -- on the oracle"""
+    replay = importlib.import_module("tempestsdr_jl_amd.replay")
+    path, Fs, (x_t, y_t, fv) = _capture(tsdr, tmp_path, c1_size=True)
+    _check_c1(replay.replay_file(OracleBackend, path, Fs, offset=420_000), Fs, x_t, y_t, fv)   # the script's own offset (:159)
+
+
+@pytest.mark.gpu
+def test_replay_flow_at_c1_size_gpu_matches_oracle(ctx, tsdr, tmp_path):
+    replay = importlib.import_module("tempestsdr_jl_amd.replay")
+    path, Fs, (x_t, y_t, fv) = _capture(tsdr, tmp_path, c1_size=True)
+    g = replay.replay_file(ctx, path, Fs, offset=420_000)
+    o = replay.replay_file(OracleBackend, path, Fs, offset=420_000)
+    _check_c1(g, Fs, x_t, y_t, fv)
+    for k in ("fv", "lag", "name", "sync", "tau", "sample_offset"):
+        assert g[k] == o[k], (k, g[k], o[k])
+    assert g["mode"].width == o["mode"].width and g["mode"].height == o["mode"].height
     assert np.array_equal(g["image"].view(np.uint32), o["image"].view(np.uint32))
     assert np.array_equal(g["aligned"].view(np.uint32), o["aligned"].view(np.uint32))
     assert np.max(np.abs(g["G"] - o["G"])) < 2e-4
