@@ -67,6 +67,7 @@ struct tsdr_ctx {
   // (0: off); running totals {frames checked, frames re-evaluated} on the device
   float guard_thr = 2e-5f;
   unsigned long long *guard_stats = nullptr;
+  unsigned *guard_sync = nullptr;           // work-queue words of the guard kernel (zero between launches)
   const uint2 *guard_last_top2 = nullptr;  // the top-2 records of the most recent guarded call (tsdr_sync_guard_margins)
   int guard_last_frames = 0, guard_last_nbx = 0, guard_last_nby = 0;
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];

@@ -141,6 +141,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->amax_keys) (void)hipFree(ctx->amax_keys);
   if (ctx->guard_stats) (void)hipFree(ctx->guard_stats);
+  if (ctx->guard_sync) (void)hipFree(ctx->guard_sync);
   if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }

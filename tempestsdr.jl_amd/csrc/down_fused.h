@@ -1,0 +1,180 @@
+// down_fused.h -- sig_to_image |> downgradeImage without the raster, as a workgroup body: shared by resample.hip's
+// k_down_fused (the raster-free frame path) and sync.hip's sync-guard kernel, which re-derives single frames in the
+// exact operation sequence.
+#pragma once
+#include "common.h"
+
+namespace tsdr {
+
+
+// ---- |IQ| -----------------------------------------------------------------------------------------------
+template <bool EXACT>
+__device__ inline float abs_iq(float re, float im) {
+  if (EXACT) return abs_c(re, im);
+  const float m = fmaf(re, re, im * im);
+  if (m > 1e-30f && m < 1e30f) return __builtin_amdgcn_sqrtf(m);  // v_sqrt_f32 (1 ulp); <= 1.5 ulp overall
+  return abs_c(re, im);                                            // tiny / huge / non-finite: the f64 form
+}
+
+// a + d*(b - a) with one f64 FMA and one rounding to f32: within 1 ulp of the value whatever |b-a| is
+__device__ inline float fast_blend(float a, float b, double d) {
+  return (float)fma(d, (double)b - (double)a, (double)a);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_down_fused: sig_to_image |> downgradeImage without the raster.  Tile = 64 output rows x TC output columns;
+// the source lines those rows touch are staged in LDS; each output pixel evaluates its four raster taps (each
+// rounded to f32 as the materialised raster would hold it) and blends them.
+// ------------------------------------------------------------------------------------------------------------
+struct DownParams {
+  unsigned S;
+  int y_t, x_t, h_out, w_out;
+  int TC, NL, W, tiles_c;
+  int lpl_log;
+};
+
+enum { DM_EXACT = 0, DM_FAST_PAIR = 1, DM_FAST_F32 = 2 };
+
+// EXACT raster value at flat index `flat` (0-based) of a staged f32 line
+__device__ inline float raster_tap_exact(const RsAxis &ax1, bool same1, unsigned flat, const float *row, int kf) {
+  double d;
+  const int j = (int)rs_pos(ax1, (double)(flat + 1u), d) - kf;
+  return same1 ? (d == 1.0 ? row[j + 1] : row[j]) : rs_blend(row[j], row[j + 1], d);
+}
+// FAST raster value at 0-based source coordinate x >= 0 (f64): staged {a, b-a} pairs or plain f32 samples
+template <int MODE>
+__device__ inline float raster_tap_fast(double x, const void *row, int kf) {
+  const double xf = floor(x);
+  const int j = (int)xf - kf;
+  if (MODE == DM_FAST_PAIR) {
+    const double2 s = reinterpret_cast<const double2 *>(row)[j];
+    return (float)fma(x - xf, s.y, s.x);
+  }
+  const float *r = reinterpret_cast<const float *>(row);
+  return fast_blend(r[j], r[j + 1], x - xf);
+}
+
+// NT: threads of the workgroup (a multiple of 64); lds_dn: its dynamic LDS region (plan_down's `lds` bytes)
+template <bool CPLX, int MODE, int NT>
+__device__ inline void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
+                                       float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn) {
+  constexpr bool EXACT = MODE == DM_EXACT;
+  constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample
+  const int Wp = q.W | 1;
+  char *base = reinterpret_cast<char *>(lds_dn);
+  double *cdx = reinterpret_cast<double *>(base + (((size_t)q.NL * Wp * SB + 15) & ~(size_t)15));  // [TC] column weight
+  double *cxs = cdx + q.TC;                                                                           // [TC] sf * kx
+  int *ckx = reinterpret_cast<int *>(cxs + q.TC);                                                     // [TC] kx
+  int *kfirst = ckx + q.TC;                                                                           // [NL]
+  const int tr = tile_idx / q.tiles_c, tc = tile_idx - tr * q.tiles_c;
+  const int r0 = tr * 64, c0 = tc * q.TC;
+  const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
+  const unsigned P = (unsigned)q.y_t * (unsigned)q.x_t;
+  const RsAxis ax1 = rs_axis(q.S, P);
+  const RsAxis ay = rs_axis((size_t)q.y_t, (size_t)q.h_out);
+  const RsAxis axx = rs_axis((size_t)q.x_t, (size_t)q.w_out);
+  const bool same1 = (q.S == P);
+  const int tid = threadIdx.x;
+  double dtmp;
+  // tile's source-line and raster-pixel ranges (uniform)
+  const int ly0 = (int)rs_pos(ay, (double)(r0 + 1), dtmp);
+  const int ly1 = (int)rs_pos(ay, (double)(min(r0 + 63, q.h_out - 1) + 1), dtmp) + 1;
+  const int nl = ly1 - ly0 + 1;
+  const int pxa = (int)rs_pos(axx, (double)(c0 + 1), dtmp);
+  for (int i = tid; i < nl; i += NT) {
+    const unsigned flat = (unsigned)(ly0 + i) * (unsigned)q.x_t + (unsigned)pxa;
+    int k;
+    if (EXACT) k = (int)rs_pos(ax1, (double)(flat + 1u), dtmp);
+    else k = max((int)floor(fmax(fma(ax1.sf, (double)flat + 0.5, -0.5), 0.0)) - 1, 0);  // one spare sample on the
+    kfirst[i] = k;                                                                        // left: tap coordinates
+  }                                                                                       // are built by additions
+  if (tid < q.TC) {  // per-column table: kx, weight, and the column's coordinate offset sf*kx
+    const int c = min(c0 + tid, q.w_out - 1);
+    double dx;
+    const int kx = (int)rs_pos(axx, (double)(c + 1), dx);
+    ckx[tid] = kx; cdx[tid] = dx; cxs[tid] = ax1.sf * (double)kx;
+  }
+  __syncthreads();
+  {  // stage the source lines: loads of up to four samples are issued before any |IQ| math
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
+    for (int i = sub; i < nl; i += nsub) {
+      const unsigned kf = (unsigned)kfirst[i];
+      for (int jb = j0; jb < q.W; jb += 4 * lpl) {
+        float re[4], im[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned k = min(kf + (unsigned)min(jb + u * lpl, q.W - 1), q.S - 1u);
+          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
+          else { re[u] = src[k]; im[u] = 0.f; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb + u * lpl;
+          if (j < q.W) {
+            const float a = CPLX ? abs_iq<EXACT>(re[u], im[u]) : re[u];
+            if (MODE == DM_FAST_PAIR) reinterpret_cast<double2 *>(base)[i * Wp + j].x = (double)a;
+            else reinterpret_cast<float *>(base)[i * Wp + j] = a;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (MODE == DM_FAST_PAIR) {  // slope towards the next sample
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
+    double2 *s2 = reinterpret_cast<double2 *>(base);
+    for (int i = sub; i < nl; i += nsub)
+      for (int j = j0; j + 1 < q.W; j += lpl) s2[i * Wp + j].y = s2[i * Wp + j + 1].x - s2[i * Wp + j].x;
+    __syncthreads();
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r = r0 + lane;
+  if (r >= q.h_out) return;  // (no barrier follows in the body)
+  double dy;
+  const int ky = (int)rs_pos(ay, (double)(r + 1), dy);
+  const int i0 = ky - ly0;
+  const char *row0 = base + (size_t)i0 * Wp * SB;
+  const char *row1 = row0 + (size_t)Wp * SB;
+  const int kf0 = kfirst[i0], kf1 = kfirst[i0 + 1];
+  const unsigned b0 = (unsigned)ky * (unsigned)q.x_t, b1 = b0 + (unsigned)q.x_t;
+  const int cend = min(c0 + q.TC, q.w_out);
+  float *o = out + (size_t)f * out_stride + (size_t)r;
+  // FAST: 0-based source coordinate of raster pixel (ky, 0) and the per-line / per-pixel increments
+  const double xrow = fma(ax1.sf, (double)b0 + 0.5, -0.5), xline = ax1.sf * (double)q.x_t;
+  for (int c = c0 + wave; c < cend; c += NT / 64) {
+    const int ct = c - c0;
+    const double dx = cdx[ct];
+    float R00, R01, R10, R11;
+    if (EXACT) {
+      const unsigned kx = (unsigned)ckx[ct];
+      const float *f0 = reinterpret_cast<const float *>(row0), *f1 = reinterpret_cast<const float *>(row1);
+      R00 = raster_tap_exact(ax1, same1, b0 + kx, f0, kf0);
+      R01 = raster_tap_exact(ax1, same1, b0 + kx + 1u, f0, kf0);
+      R10 = raster_tap_exact(ax1, same1, b1 + kx, f1, kf1);
+      R11 = raster_tap_exact(ax1, same1, b1 + kx + 1u, f1, kf1);
+    } else {
+      const double x00 = xrow + cxs[ct];
+      R00 = raster_tap_fast<MODE>(fmax(x00, 0.0), row0, kf0);
+      R01 = raster_tap_fast<MODE>(fmax(x00 + ax1.sf, 0.0), row0, kf0);
+      R10 = raster_tap_fast<MODE>(x00 + xline, row1, kf1);           // line ky+1 >= 1: coordinate > 0
+      R11 = raster_tap_fast<MODE>(x00 + xline + ax1.sf, row1, kf1);
+    }
+    float v;
+    if (EXACT) {
+      // first dimension (lines) outermost: wy0*(wx0*a00 + wx1*a01) + wy1*(wx0*a10 + wx1*a11)
+      const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
+      const double top = __dadd_rn(__dmul_rn(wx0, (double)R00), __dmul_rn(dx, (double)R01));
+      const double bot = __dadd_rn(__dmul_rn(wx0, (double)R10), __dmul_rn(dx, (double)R11));
+      v = (float)__dadd_rn(__dmul_rn(wy0, top), __dmul_rn(dy, bot));
+    } else {
+      const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
+      const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
+      v = (float)fma(dy, bot - top, top);
+    }
+    o[(size_t)c * q.h_out] = v;
+  }
+}
+
+}  // namespace tsdr

@@ -25,10 +25,10 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
                       float *proj = nullptr, ProjLayout *got = nullptr, bool plan_only = false,
                       unsigned long long *keys = nullptr);
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
-                const ProjLayout *have, uint2 *top2, const int *flags);
+                const ProjLayout *have, uint2 *top2);
 void sync_beta_blocks(const tsdr_sync *s, int *nbx, int *nby);
-int down_frames_guarded_d(tsdr_ctx *ctx, const float *iq, size_t in_stride, size_t S, int y_t, int x_t, int h_out, int w_out,
-                          int frames, float *out, size_t out_stride, const GuardArgs &g, bool *can, bool plan_only);
+int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int frames, float *img, size_t img_stride,
+                 unsigned long long *keys, float *proj, const GuardArgs &g, bool *can, bool plan_only);
 int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys);
 int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
@@ -54,8 +54,8 @@ static int frames_check(tsdr_ctx *ctx, tsdr_sync *sync, int do_align) {
 }
 
 // ---- sync guard (guard.h) ---------------------------------------------------------------------------------------
-// FAST-mode calls with do_align: k_beta reports every workgroup's top-2 column maxima, and three more launches
-// re-evaluate -- in the reference's exact operation sequence -- the frames whose decision was closer than
+// FAST-mode calls with do_align: k_beta reports every workgroup's top-2 column maxima, and ONE more launch (k_guard,
+// sync.hip) re-evaluates -- in the reference's exact operation sequence -- the frames whose decision was closer than
 // ctx->guard_thr.  For geometries without the fused exact image kernel the whole call runs in TSDR_EXACT instead.
 struct GuardPlan {
   bool on = false;
@@ -78,7 +78,7 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
   GuardArgs g;
   g.nbx = nbx; g.nby = nby; g.thr = ctx->guard_thr;
   bool can = false;
-  int rc = down_frames_guarded_d(ctx, nullptr, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, nullptr, 0, g, &can, true);
+  int rc = sync_guard_d(sync, nullptr, S, y_t, x_t, F, nullptr, 0, nullptr, nullptr, g, &can, true);
   if (rc) return rc;
   if (!can) { ctx->precision = TSDR_EXACT; return TSDR_OK; }  // (the caller holds a PrecisionScope)
   if (!ctx->guard_stats) {
@@ -102,9 +102,8 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
 static int guard_run(tsdr_ctx *ctx, tsdr_sync *sync, const GuardPlan &gp, const float *iq, size_t S, int y_t, int x_t, int F,
                      float *img, unsigned long long *keys, float *proj) {
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
-  int rc = down_frames_guarded_d(ctx, iq, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, img, npx, gp.g, nullptr, false);
-  if (rc) return rc;
-  return sync_scan_d(sync, img, npx, F, keys, proj, nullptr, nullptr, gp.g.flags);
+  (void)ctx;
+  return sync_guard_d(sync, iq, S, y_t, x_t, F, img, npx, keys, proj, gp.g, nullptr, false);
 }
 
 // The loop body for F frames.  Stage R: raster (optional) + 600x800 image of every frame in one launch; in TSDR_FAST
@@ -133,7 +132,7 @@ static int frames_stage(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t 
                          proj, &got, false, keys);
   if (rc) return rc;
   if (do_align) {
-    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr, nullptr);
+    rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr);
     if (rc) return rc;
     if (gp.on) {
       rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
@@ -298,11 +297,11 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     rc = pipe_combine_pending(ctx);
     if (rc) return rc;
     if (do_align) {
-      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, top2, nullptr);
+      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, top2);
       if (rc) return rc;
     }
   }
-  if (gp.on) {  // the guard's three launches follow the statistics of THIS buffer; its shift + IIR comes later
+  if (gp.on) {  // the guard's launch follows the statistics of THIS buffer; its shift + IIR comes later
     rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
     if (rc) return rc;
   }

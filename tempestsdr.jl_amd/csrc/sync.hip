@@ -30,8 +30,10 @@
 // patterns sort above +Inf (Julia's findmax treats NaN as maximal), and ~c makes the smallest column win
 // ties = first maximum in column-major order (only the column of the maximum is ever used, :66,:76).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
+#include "down_fused.h"
 #include "guard.h"
 #include "sync_layout.h"
 
@@ -69,14 +71,12 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 // super-round.  grid = (nrb, frames).
 // (launch bound: 128 registers, so that two workgroups share a CU and the 300 of a C2 buffer are resident at once --
 // at 136 registers they ran in two rounds)
-__global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
-                                                 float *__restrict__ proj, size_t proj_stride,
-                                                 unsigned long long *__restrict__ keys, const int *__restrict__ flags) {
-  constexpr int CH = 100, SB = 25, PITCH = SB + 1, RND = 8 * CH;  // 8 tiles of 64 x 26 floats = 52 KiB of LDS
-  __shared__ float tile[8][64 * PITCH];
-  __shared__ float chain[64];
-  const int f = blockIdx.y, rb = blockIdx.x;
-  if (flags && !flags[f]) return;  // sync guard: only the frames it flagged are re-evaluated
+constexpr size_t kProjLds = (size_t)(8 * 64 * 26 + 64) * sizeof(float);  // 8 tiles of 64 x 26 floats + the row chain: 52 KiB
+// body of one k_proj workgroup (512 threads): frame f, 64-row block rb; lds: kProjLds bytes
+__device__ inline void proj_wg(const float *__restrict__ img, size_t img_stride, int y_t, int x_t, float *__restrict__ proj,
+                               size_t proj_stride, unsigned long long *__restrict__ keys, int f, int rb, float *lds) {
+  constexpr int CH = 100, SB = 25, PITCH = SB + 1, RND = 8 * CH;
+  float *chain = lds + 8 * 64 * PITCH;
   const int nrb = (y_t + 63) >> 6;
   const float *im = img + (size_t)f * img_stride;
   float *pr = proj + (size_t)f * proj_stride;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, 
   const bool rv = r < y_t;
   const int nval = min(64, y_t - rb * 64);
   const float *p = im + (rv ? r : 0);
-  float *mytile = tile[wave];
+  float *mytile = lds + wave * (64 * PITCH);
   const int rounds = (x_t + RND - 1) / RND;
   for (int round = 0; round < rounds; ++round) {
     const int cs = round * RND + wave * CH;
@@ -140,20 +140,26 @@ __global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, 
   }
   if (wave == 0 && rv) pr[(size_t)nrb * x_t + r] = chain[lane];
 }
+__global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
+                                                 float *__restrict__ proj, size_t proj_stride,
+                                                 unsigned long long *__restrict__ keys) {
+  extern __shared__ float proj_lds[];
+  proj_wg(img, img_stride, y_t, x_t, proj, proj_stride, keys, (int)blockIdx.y, (int)blockIdx.x, proj_lds);
+}
 constexpr int kProjRowParts = 1;
 static inline dim3 proj_grid(int y_t, int frames) { return dim3((unsigned)((y_t + 63) >> 6), (unsigned)frames); }
 static inline dim3 proj_block() { return dim3(512); }
+static inline size_t proj_lds_bytes() { return kProjLds; }
 #else
 // Round-1 order (compile-time alternative, see the oracle's ORC_ROWSUM_CHUNK8): row sums in 8 column chunks, each
 // accumulated in order from 0.0f, the chunk sums added left to right by k_fold.  One wavefront per (64-row block,
 // column chunk); grid = (8 * nrb, frames).
 __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
                                              float *__restrict__ proj, size_t proj_stride,
-                                             unsigned long long *__restrict__ keys, const int *__restrict__ flags) {
+                                             unsigned long long *__restrict__ keys) {
   constexpr int SUB = 32, PITCH = SUB + 1;
   __shared__ float tile[64 * PITCH];
   const int f = blockIdx.y;
-  if (flags && !flags[f]) return;
   const int nrb = (y_t + 63) >> 6, chunk = (x_t + 7) >> 3;
   const int j = blockIdx.x & 7, rb = blockIdx.x >> 3;
   const float *im = img + (size_t)f * img_stride;
@@ -182,8 +188,10 @@ __global__ __launch_bounds__(64) void k_proj(const float *__restrict__ img, size
   if (rv) pr[(size_t)nrb * x_t + (size_t)j * y_t + r] = a;
 }
 constexpr int kProjRowParts = 8;
+// (this measurement-only build has no guard kernel: FAST-mode frame loops run in TSDR_EXACT instead)
 static inline dim3 proj_grid(int y_t, int frames) { return dim3((unsigned)(8 * ((y_t + 63) >> 6)), (unsigned)frames); }
 static inline dim3 proj_block() { return dim3(64); }
+static inline size_t proj_lds_bytes() { return 0; }
 #endif
 
 __device__ inline unsigned long long pack_key(float v, int c) {
@@ -289,7 +297,6 @@ struct BetaArgs {
   float *bx, *by;
   uint2 *top2;       // sync guard (or null): per (frame, workgroup of the frame) {largest column maximum, second largest among
                      // OTHER columns} of the workgroup's 64 centres, as order-preserving words
-  const int *flags;  // sync guard re-evaluation (or null): only frames with flags[f] != 0 are processed
 };
 
 __device__ inline int gridDim_x_of_frame(const SyncGeom &g) { return ((g.x_t + 63) >> 6) + ((g.y_t + 63) >> 6); }
@@ -304,7 +311,6 @@ __device__ inline void beta_wg(const BetaArgs &A, int blk, int f, float *sh) {
   unsigned long long *__restrict__ keys = A.keys;
   const int write_frame = A.write_frame;
   float *__restrict__ bx = A.bx, *__restrict__ by = A.by;
-  if (A.flags && !A.flags[f]) return;  // uniform over the workgroup
   __shared__ unsigned colk[NWV][64];
   __shared__ float Ssh;
   const int nbx = (g.x_t + 63) >> 6;
@@ -624,11 +630,11 @@ void sync_image_size(const tsdr_sync *s, int *y_t, int *x_t) { *y_t = s->y_t; *x
 constexpr int kBetaWaves = 8;
 
 static void beta_args(tsdr_sync *s, const float *proj, ProjLayout pl, unsigned long long *keys, int frames, BetaArgs *B,
-                      unsigned *nbb, size_t *lds, uint2 *top2 = nullptr, const int *flags = nullptr) {
+                      unsigned *nbb, size_t *lds, uint2 *top2 = nullptr) {
   const int y = s->y_t, x = s->x_t;
   B->proj = proj; B->proj_stride = proj_floats(y, x, pl); B->ncp = pl.ncp; B->nrp = pl.nrp; B->g = geom_of(s);
   B->keys = keys; B->write_frame = frames - 1; B->bx = s->beta_x; B->by = s->beta_y;
-  B->top2 = top2; B->flags = flags;
+  B->top2 = top2;
   const size_t nmax = (size_t)(x > y ? x : y), wmax = (size_t)std::max(s->wmax_x, s->wmax_y);
   *nbb = (unsigned)(ceil_div((size_t)x, 64) + ceil_div((size_t)y, 64));
   *lds = (2 * nmax + 64 + 2 * wmax + 8) * 4;
@@ -643,28 +649,202 @@ static void iir_args(tsdr_sync *s, const float *img, size_t img_stride, int h, i
 }
 
 //   top2 (sync guard, guard.h): k_beta also leaves every workgroup's {best, best other column} pair there.
-//   flags (sync guard re-evaluation): only frames with flags[f] != 0 are processed (their keys are cleared by k_proj and
-//   rewritten); the launches carry the profiler names guard_proj / guard_beta.  have must be null then.
 int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, unsigned long long *keys, float *proj,
-                const ProjLayout *have, uint2 *top2, const int *flags) {
+                const ProjLayout *have, uint2 *top2) {
   tsdr_ctx *ctx = s->ctx;
   const int y = s->y_t, x = s->x_t;
   if (!proj || !keys) return TSDR_ENOMEM;
-  if (flags && have) return TSDR_EINVAL;
   ProjLayout pl;
   if (have) {
     pl = *have;
   } else {
     pl = sync_proj_layout(s);
-    TSDR_LAUNCH(ctx, flags ? "guard_proj" : "sync_proj", k_proj, proj_grid(y, frames), proj_block(), 0, img, img_stride, y, x, proj,
-                proj_floats(y, x, pl), keys, flags);
+    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames), proj_block(), proj_lds_bytes(), img, img_stride, y, x, proj,
+                proj_floats(y, x, pl), keys);
   }
   BetaArgs B;
   size_t lds = 0;
   unsigned nbb = 0;
-  beta_args(s, proj, pl, keys, frames, &B, &nbb, &lds, top2, flags);
-  TSDR_LAUNCH(ctx, flags ? "guard_beta" : "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
+  beta_args(s, proj, pl, keys, frames, &B, &nbb, &lds, top2);
+  TSDR_LAUNCH(ctx, "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
   return TSDR_OK;
+}
+
+// ---- the sync guard's ONE launch (guard.h) ----------------------------------------------------------------------------
+// A small persistent grid.  Every workgroup works out the list of flagged frames itself (the first wavefront scans the
+// top-2 records k_beta left: a few KB out of L2) -- when the list is empty, which is the rule, all of them leave at once
+// and the launch costs one kernel boundary.  Otherwise the re-evaluation of the flagged frames runs as a queue of work
+// items in dependency order,
+//     A (flagged frame, image tile)   EXACT 600x800 tile from IQ (down_fused_body), written over the FAST image
+//     B (flagged frame, row block)    its projections in the reference's order (proj_wg)      -- needs all A of the frame
+//     C (flagged frame, centre block) beta scan + argmax key (beta_wg<8>)                      -- needs all B of the frame
+// taken by ticket (one atomicAdd per item).  A workgroup that holds ticket t waits only for items with smaller tickets,
+// all of which are held by workgroups that are running, so the queue cannot deadlock whatever the dispatch order or the
+// number of resident workgroups.  Hand-over between items of different CUs: every storing wavefront drains its stores,
+// workgroup barrier, one lane release-fences and bumps the frame's counter; the consumer polls the counter, acquire-
+// fences, barrier (MI355X_MICROARCH.md, inter-workgroup visibility).  The last workgroup to leave zeroes the queue words.
+struct GuardSync {          // device words, all zero between launches
+  unsigned ticket, exited;
+  unsigned done[1];         // [2 * frames]: items A / B finished per LIST position
+};
+
+struct GuardAllArgs {
+  GuardArgs g;
+  int frames;
+  // A
+  const float *iq; size_t in_stride; DownParams dq; float *img; size_t img_stride; int tilesA;
+  // B, C
+  int y_t, x_t; float *proj; size_t proj_stride; int ncp, nrp; BetaArgs B; int nB, nC;
+  unsigned *sync;           // GuardSync
+  size_t lds_bytes;         // A's LDS need
+  size_t lds_total;         // dynamic LDS of the launch
+};
+
+__device__ inline void guard_wait(unsigned *ctr, unsigned target) {
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+__device__ inline void guard_signal(unsigned *ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wavefront drains its own stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+#ifndef TSDR_ROWSUM_CHUNK8
+__global__ __launch_bounds__(512, 4) void k_guard(GuardAllArgs a) {
+  extern __shared__ double glds[];
+  __shared__ int list[kGuardChunk];
+  __shared__ int cnt_s;
+  __shared__ unsigned ticket_s;
+  const int tid = threadIdx.x;
+  {
+    // all top-2 records of the launch come into LDS with ONE round trip (every thread a few), then one lane per frame
+    // scans its frame's records there: a lane walking them in global memory pays the L2 latency once per record, which
+    // made this -- the whole cost of the launch when nothing is flagged -- 6 us instead of 2
+    const int nbb = a.g.nbx + a.g.nby, total = a.frames * nbb;
+    uint2 *rec = reinterpret_cast<uint2 *>(glds);
+    const bool staged = (size_t)total * sizeof(uint2) <= a.lds_total;
+    if (staged) {
+      for (int i = tid; i < total; i += 512) rec[i] = a.g.top2[i];
+      __syncthreads();
+    }
+    GuardArgs gl = a.g;
+    if (staged) gl.top2 = rec;
+    if (tid < 64) {
+      int n = 0;
+      for (int base = 0; base < a.frames; base += 64) {
+        const int f = base + tid;
+        const bool bad = f < a.frames && guard_eval(gl, f);
+        const unsigned long long m = __ballot(bad);
+        if (bad) list[n + (int)__builtin_popcountll(m & ((1ull << tid) - 1ull))] = f;
+        n += (int)__builtin_popcountll(m);
+        if (blockIdx.x == 0 && f < a.frames) a.g.flags[f] = bad ? 1 : 0;
+      }
+      if (tid == 0) {
+        cnt_s = n;
+        if (blockIdx.x == 0) {
+          atomicAdd(&a.g.stats[0], (unsigned long long)a.frames);
+          if (n) atomicAdd(&a.g.stats[1], (unsigned long long)n);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int cnt = cnt_s;
+  if (cnt == 0) return;
+  unsigned *ticket = a.sync, *exited = a.sync + 1, *doneA = a.sync + 2, *doneB = a.sync + 2 + a.frames;
+  const unsigned nA = (unsigned)cnt * (unsigned)a.tilesA, nBt = (unsigned)cnt * (unsigned)a.nB, nCt = (unsigned)cnt * (unsigned)a.nC;
+  for (;;) {
+    if (tid == 0) ticket_s = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned t = ticket_s;
+    __syncthreads();
+    if (t >= nA + nBt + nCt) break;
+    if (t < nA) {
+      const int j = (int)(t / (unsigned)a.tilesA), tile = (int)(t - (unsigned)j * (unsigned)a.tilesA);
+      down_fused_body<true, DM_EXACT, 512>(a.iq, a.in_stride, a.dq, a.img, a.img_stride, tile, list[j], glds);
+      guard_signal(doneA + j);
+    } else if (t < nA + nBt) {
+      const unsigned u = t - nA;
+      const int j = (int)(u / (unsigned)a.nB), rb = (int)(u - (unsigned)j * (unsigned)a.nB);
+      guard_wait(doneA + j, (unsigned)a.tilesA);
+      proj_wg(a.img, a.img_stride, a.y_t, a.x_t, a.proj, a.proj_stride, a.B.keys, list[j], rb, reinterpret_cast<float *>(glds));
+      guard_signal(doneB + j);
+    } else {
+      const unsigned u = t - nA - nBt;
+      const int j = (int)(u / (unsigned)a.nC), blk = (int)(u - (unsigned)j * (unsigned)a.nC);
+      guard_wait(doneB + j, (unsigned)a.nB);
+      beta_wg<8>(a.B, blk, list[j], reinterpret_cast<float *>(glds));
+    }
+    __syncthreads();  // the item's LDS is free again
+  }
+  // leave: the last workgroup out zeroes the queue words for the next launch
+  if (tid == 0) {
+    if (__hip_atomic_fetch_add(exited, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+      for (int i = 0; i < 2 + 2 * a.frames; ++i) __hip_atomic_store(a.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+#endif
+
+// Sync guard: frames whose FAST-mode decision was closer than g.thr are re-evaluated in the exact sequence (image, projections
+// in the reference's order, beta scan); img / keys of those frames are overwritten, everything else is left alone.
+// plan_only: report whether this geometry can be guarded at all.
+bool guard_image_plan(tsdr_ctx *ctx, size_t S, int y_t, int x_t, int h_out, int w_out, DownParams *q, size_t *lds);
+
+int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int frames, float *img, size_t img_stride,
+                 unsigned long long *keys, float *proj, const GuardArgs &g, bool *can, bool plan_only) {
+  tsdr_ctx *ctx = s->ctx;
+  if (can) *can = false;
+#ifdef TSDR_ROWSUM_CHUNK8
+  return TSDR_OK;
+#else
+  GuardAllArgs a{};
+  if (!guard_image_plan(ctx, S, y_t, x_t, s->y_t, s->x_t, &a.dq, &a.lds_bytes)) return TSDR_OK;
+  if (can) *can = true;
+  if (plan_only || frames <= 0) return TSDR_OK;
+  const int y = s->y_t, x = s->x_t;
+  const ProjLayout pl = sync_proj_layout(s);
+  size_t lds_beta = 0;
+  unsigned nbb = 0;
+  const int ncu = ctx->cu_count > 0 ? ctx->cu_count : 256;
+  for (int f0 = 0; f0 < frames; f0 += kGuardChunk) {   // (the list of flagged frames lives in LDS)
+    const int nf = std::min(kGuardChunk, frames - f0);
+    // queue words: zero between launches (the kernel restores that itself)
+    const size_t words = 2 + 2 * (size_t)kGuardChunk;
+    if (!ctx->guard_sync) {
+      TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_sync, words * 4));
+      TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_sync, 0, words * 4, ctx->stream));
+    }
+    a.g = g;
+    a.g.top2 = g.top2 + (size_t)f0 * (size_t)(g.nbx + g.nby);
+    a.g.flags = g.flags + f0;
+    a.frames = nf;
+    a.iq = iq + (size_t)f0 * S * 2; a.in_stride = S; a.img = img + (size_t)f0 * img_stride; a.img_stride = img_stride;
+    a.tilesA = (int)(ceil_div((size_t)y, 64) * (size_t)a.dq.tiles_c);
+    a.y_t = y; a.x_t = x;
+    a.proj_stride = proj_floats(y, x, pl); a.ncp = pl.ncp; a.nrp = pl.nrp;
+    a.proj = proj + (size_t)f0 * a.proj_stride;
+    beta_args(s, a.proj, pl, keys + (size_t)f0 * 2, nf, &a.B, &nbb, &lds_beta, nullptr);
+    a.B.write_frame = (f0 + nf == frames) ? nf - 1 : -1;
+    a.nB = (y + 63) >> 6; a.nC = (int)nbb;
+    a.sync = ctx->guard_sync;
+    const size_t lds = std::max(std::max(a.lds_bytes, kProjLds), lds_beta);
+    a.lds_total = lds;
+    static const int grid_env = getenv("TSDR_GUARD_GRID") ? atoi(getenv("TSDR_GUARD_GRID")) : 0;  // (development: A/B of the grid size)
+    const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)ncu;
+    TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
+  }
+  return TSDR_OK;
+#endif
 }
 
 void sync_beta_blocks(const tsdr_sync *s, int *nbx, int *nby) { *nbx = (s->x_t + 63) >> 6; *nby = (s->y_t + 63) >> 6; }
@@ -714,8 +894,8 @@ int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, i
     pl = *have;
   } else {
     pl = sync_proj_layout(s);
-    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames_b), proj_block(), 0, img_b, img_stride, y, x, proj,
-                proj_floats(y, x, pl), keys_b, (const int *)nullptr);
+    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames_b), proj_block(), proj_lds_bytes(), img_b, img_stride, y, x, proj,
+                proj_floats(y, x, pl), keys_b);
   }
   BetaArgs B;
   IirArgs I;
@@ -810,7 +990,7 @@ int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   unsigned long long *keys = nullptr;
   int rc = sync_workspace(s, 1, 0, 1, nullptr, &proj, &keys);
   if (rc) return rc;
-  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr, nullptr, nullptr);
+  rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr, nullptr);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
               (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);
