@@ -220,6 +220,37 @@ def test_sync_guard_is_what_makes_indices_identical(ctx, tsdr, synth):
     assert np.array_equal(gs[0].view(np.uint32), gs[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("wl,nfr", [("C2", 7), ("C3", 3), ("C5", 3)])
+def test_sync_guard_queue_under_full_load(ctx, tsdr, synth, wl, nfr):
+    """Every frame flagged (threshold 1) at the BASELINE geometries: the guard kernel's ticket queue then carries thousands
+    of dependent work items (C2: 7 x (250 image tiles + 10 row blocks + 23 centre blocks)) across all CUs, and the result
+    must be TSDR_EXACT's, bit for bit -- frames, sync indices, IIR state -- twice in a row on the same context (the queue
+    words are back at zero after a launch)."""
+    w = synth.WORKLOADS[wl]
+    Fs, x_t, y_t, fv = w["Fs"], w["x_t"], w["y_t"], w["fv"]
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 13)
+    ctx.set_precision("exact")
+    try:
+        se = np.zeros((600, 800), np.float32, order="F")
+        e = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), se)
+    finally:
+        ctx.set_precision("fast")
+    ctx.set_option("sync_guard_ppb", 100000000)
+    try:
+        for _ in range(2):
+            ctx.sync_guard_stats(reset=True)
+            sf = np.zeros((600, 800), np.float32, order="F")
+            g = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), sf)
+            assert ctx.sync_guard_stats() == (nfr, nfr)
+            assert np.array_equal(g["sync_idx"], e["sync_idx"])
+            for a, b in zip(g["frames"], e["frames"]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert np.array_equal(sf.view(np.uint32), se.view(np.uint32))
+    finally:
+        ctx.set_option("sync_guard_ppb", 20000)
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_frames_fast_random_geometries(ctx, tsdr, seed):
     """Random raster sizes and sampling ratios (0.08 .. 1.6 samples per pixel), white-noise IQ -- the hardest input
