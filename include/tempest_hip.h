@@ -211,7 +211,7 @@ int tsdr_fft_c2c_d(tsdr_ctx *ctx, const float *in, float *out, size_t n, size_t 
 int tsdr_fft_z2z(tsdr_ctx *ctx, const double *in, double *out, size_t n, int dir);
 /* Diagnostics, host arithmetic only (no context, no device): the per-pass factors a length-n transform would be split
  * into -- powers of two up to 256 for n = 2^k, factors 2^a 3^b 5^c <= 256 from the cost-based planner for other smooth
- * lengths.  Returns the number of passes (factors[0 .. min(passes, cap)) filled), 0 when n takes the Bluestein route
+ * lengths, plus 500 / 1000 / 2000 (three-register-step kernels) in multi-pass splits of transforms of at most 2^22 points.  Returns the number of passes (factors[0 .. min(passes, cap)) filled), 0 when n takes the Bluestein route
  * (or n < 2). */
 int tsdr_fft_plan(size_t n, unsigned *factors, int cap);
 

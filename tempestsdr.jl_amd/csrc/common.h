@@ -62,6 +62,7 @@ struct tsdr_ctx {
   // development switches (tsdr_set_option; environment variables of the same upper-case names are read ONCE, in tsdr_create)
   int opt_ac_mixed = 1;     // autocorrelation of n = 2*(2^a3^b5^c) samples: native mixed-radix route (0: zero-padded power of two)
   int opt_fft_no_mix2 = 0;  // 1: every mixed-radix factor through the generic LDS-stage kernel
+  int opt_fft_big = 1;      // mixed-radix planner may use factors of 500 / 1000 / 2000 (three-register-step kernels)
   int opt_ac_fuse_mid = 1;  // autocorrelation: last forward pass + power spectrum + first inverse pass as one launch
   // sync guard of the FAST frame loop (guard.h): relative top-2 margin below which a frame is re-evaluated exactly
   // (0: off); running totals {frames checked, frames re-evaluated} on the device

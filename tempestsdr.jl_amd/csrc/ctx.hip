@@ -125,6 +125,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_AC_MIXED")) ctx->opt_ac_mixed = atoi(e) != 0;
   if (const char *e = getenv("TSDR_FFT_NO_MIX2")) ctx->opt_fft_no_mix2 = atoi(e) != 0;
   if (const char *e = getenv("TSDR_AC_FUSE_MID")) ctx->opt_ac_fuse_mid = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_FFT_BIG")) ctx->opt_fft_big = atoi(e) != 0;
   if (const char *e = getenv("TSDR_SYNC_GUARD_PPB")) ctx->guard_thr = (float)atoi(e) * 1e-9f;
   return ctx;
 }
@@ -183,6 +184,7 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "ac_mixed")) ctx->opt_ac_mixed = value != 0;
   else if (!strcmp(name, "fft_no_mix2")) ctx->opt_fft_no_mix2 = value != 0;
   else if (!strcmp(name, "ac_fuse_mid")) ctx->opt_ac_fuse_mid = value != 0;
+  else if (!strcmp(name, "fft_big")) ctx->opt_fft_big = value != 0;
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");
     ctx->guard_thr = (float)value * 1e-9f;

@@ -749,10 +749,317 @@ struct MidEntry { unsigned R, RA; int tm, nt; mid_fn fn; };
 // last forward factors that have the fused kernel (the planner puts the factor with the most twos last)
 static const MidEntry kMid[] = {MID(10, 20), MID(10, 10), MID(16, 16), MID(16, 10), MID(16, 9), MID(16, 8), MID(16, 5), MID(8, 8), MID(8, 5)};
 #undef MID
+static const MidEntry *mid3_lookup(unsigned R);
 static const MidEntry *mid_lookup(unsigned R) {
   for (const MidEntry &e : kMid)
     if (e.R == R) return &e;
+  return mid3_lookup(R);
+}
+
+
+// ---- three register steps per pass: factors of 500 .. 2000 ---------------------------------------------------------------
+// R = RA * RB * RC.  With n = (n1 RB + n2) RC + n3 and k = k1 + RA k2 + RA RB k3:
+//   step 1  slot (n2, n3, t):  A[k1] = sum_n1 W_RA^(n1 k1) x[n1, n2, n3],       times W_{RA RB}^(n2 k1)
+//   step 2  slot (k1, n3, t):  B[k2] = sum_n2 W_RB^(n2 k2) A[k1, n2, n3],       times W_R^(n3 (k1 + RA k2))
+//   step 3  slot (k1, k2, t):  X[k1 + RA k2 + RA RB k3] = sum_n3 W_RC^(n3 k3) B[k1, k2, n3]
+// One slot per thread in every step (the workgroup has as many threads as the largest step has slots), two exchanges
+// through ONE LDS tile that every step overwrites in place (a slot reads and writes the same RA / RB positions), k1 planes
+// padded by T elements so that the step-3 reads of a half-wavefront fall on distinct banks.  A 2e6-point transform is TWO
+// such passes (1000 x 2000) instead of three of the two-step kernel's: the passes are latency-bound at that size (every
+// workgroup resident at once), so their number is what counts.  STRIDED loads go global -> registers in T-element runs;
+// LAST reads its rows contiguously (slot order with the column slowest).  Inter-pass twiddles W^(n (Ka + k P)) are linear
+// in k3: one evaluation for the slot's first output, one for the step, then a product per output.
+template <int RA, int RB, int RC, int LOGT>
+struct Mix3Geom {
+  static constexpr int R = RA * RB * RC, T = 1 << LOGT;
+  static constexpr int S1 = RB * RC * T, S2 = RA * RC * T, S3 = RA * RB * T;
+  static constexpr int SMAX = S1 > S2 ? (S1 > S3 ? S1 : S3) : (S2 > S3 ? S2 : S3);
+  static constexpr int NT = (SMAX + 63) / 64 * 64;
+  static constexpr int PLANE = RB * RC * T + T;
+  static constexpr int VMAX = RA > RB ? (RA > RC ? RA : RC) : (RB > RC ? RB : RC);
+  static constexpr size_t LDS = ((size_t)RA * PLANE + R) * sizeof(float2);
+};
+
+template <int RA, int RB, int RC, int LOGT, int MODE>
+__global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(const float2 *__restrict__ in, float2 *__restrict__ out, MixDesc d) {
+  using G = Mix3Geom<RA, RB, RC, LOGT>;
+  constexpr int R = G::R, T = G::T, NT = G::NT, PLANE = G::PLANE, R23 = RB * RC;
+  extern __shared__ float2 sm[];
+  float2 *buf = sm;                       // [RA][PLANE]: (k1 | n1, second digit, third digit, column)
+  float2 *twR = sm + RA * PLANE;          // W_R^e, e < R
+  const int tid = threadIdx.x;
+  const unsigned smask = d.dir > 0 ? 0x80000000u : 0u;
+  for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
+  const unsigned bid = blockIdx.x;
+  float2 v[G::VMAX];
+  size_t base = 0, tbase = 0;
+  unsigned col0 = 0, a = 0, kt = 0, arest = 0;
+  // ---- step 1 inputs
+  int t1, r23;
+  bool ok1;
+  if (MODE == FFT_STRIDED) {
+    const unsigned tile = bid % d.tiles;
+    a = (bid / d.tiles) % d.A;
+    const unsigned b = bid / (d.tiles * d.A);
+    col0 = tile << LOGT;
+    base = (size_t)b * d.N + (size_t)a * R * d.B + col0;
+    t1 = tid & (T - 1); r23 = tid >> LOGT;
+    ok1 = tid < G::S1 && col0 + (unsigned)t1 < d.B;
+    const size_t g0 = base + (size_t)r23 * d.B + t1;
+    if (d.src_mode == SRC_C2C) {
+#pragma unroll
+      for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok1 ? conj_if(in[g0 + (size_t)(n1 * R23) * d.B], smask) : make_float2(0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < RA; ++n1)
+        v[n1] = ok1 ? conj_if(fft_load(in, d.src_mode, d.src_n, g0 + (size_t)(n1 * R23) * d.B, d.src_w8, d.src_aux), smask) : make_float2(0.f, 0.f);
+    }
+  } else {
+    kt = bid % d.k1tiles;
+    arest = (bid / d.k1tiles) % d.Aprime;
+    tbase = (size_t)(bid / (d.k1tiles * d.Aprime)) * d.N;
+    t1 = tid / R23; r23 = tid - t1 * R23;  // the column slowest: a wavefront reads one row contiguously
+    const unsigned k1g = (kt << LOGT) + (unsigned)t1;
+    ok1 = tid < G::S1 && k1g < d.R1;
+    const float2 *src = in + tbase + ((size_t)k1g * d.Aprime + arest) * R + r23;
+#pragma unroll
+    for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok1 ? conj_if(src[n1 * R23], smask) : make_float2(0.f, 0.f);
+  }
+  __syncthreads();  // twR
+  if (tid < G::S1) {
+    dft_nat<RA>(v);
+    const int n2 = r23 / RC;
+#pragma unroll
+    for (int k1 = 0; k1 < RA; ++k1) {
+      float2 x = v[k1];
+      if (k1) x = cmul(x, twR[(n2 * k1) * RC]);  // W_{RA RB}^(n2 k1)
+      buf[k1 * PLANE + r23 * T + t1] = x;
+    }
+  }
+  __syncthreads();
+  // ---- step 2: slot (k1, n3, t), in place
+  if (tid < G::S2) {
+    const int t = tid & (T - 1), q = tid >> LOGT, k1 = q / RC, n3 = q - k1 * RC;
+    float2 *p = buf + k1 * PLANE + n3 * T + t;
+#pragma unroll
+    for (int n2 = 0; n2 < RB; ++n2) v[n2] = p[n2 * RC * T];
+    dft_nat<RB>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) {
+      float2 x = v[k2];
+      const int e = n3 * (k1 + RA * k2);
+      if (k2 || k1) x = cmul(x, twR[e]);  // (e = 0 gives 1 anyway)
+      p[k2 * RC * T] = x;
+    }
+  }
+  __syncthreads();
+  // ---- step 3: slot (kk = k1 + RA k2, t); outputs straight from registers
+  const int t3 = tid & (T - 1), kk = tid >> LOGT;
+  const bool ok3 = tid < G::S3;
+  if (ok3) {
+    const int k2 = kk / RA, k1 = kk - k2 * RA;
+    const float2 *p = buf + k1 * PLANE + k2 * RC * T + t3;
+#pragma unroll
+    for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T];
+    dft_nat<RC>(v);
+  }
+  if (MODE == FFT_STRIDED) {
+    const unsigned col = col0 + (unsigned)t3;
+    if (ok3 && col < d.B) {
+      const unsigned Ka = digit_swap_g(a, d.nprev, d.Rprev, d.Wprev);
+      const unsigned nn = col / d.Bnext;
+      float2 w = tw_q32(phase_q32(nn * (Ka + (unsigned)kk * d.Pprev), d.ntw_hi, d.ntw_lo));
+      const float2 ws = tw_q32(phase_q32(nn * ((unsigned)(RA * RB) * d.Pprev), d.ntw_hi, d.ntw_lo));
+      float2 *dst = out + base + (size_t)kk * d.B + t3;
+#pragma unroll
+      for (int k3 = 0; k3 < RC; ++k3) {
+        dst[(size_t)(RA * RB * k3) * d.B] = conj_if(cmul(v[k3], w), smask);
+        w = cmul(w, ws);
+      }
+    }
+  } else {
+    const unsigned Kp = digit_swap_g(arest, d.nprev - 1, d.Rprev + 1, d.Wprev + 1);
+    const unsigned k1g = (kt << LOGT) + (unsigned)t3;
+    unsigned long long best = 0ull;
+    if (ok3 && k1g < d.R1) {
+      const size_t orel = (size_t)k1g + Kp;
+#pragma unroll
+      for (int k3 = 0; k3 < RC; ++k3) {
+        const size_t o = orel + (size_t)(kk + RA * RB * k3) * d.Pprev;
+        if (o < d.keep) {
+          const float2 y = conj_if(make_float2(v[k3].x * d.scale, v[k3].y * d.scale), smask);
+          if (d.epi.out) epilogue_store(d.epi, o, y, best); else out[tbase + o] = y;
+        }
+      }
+    }
+    if (d.epi.amax_keys) {
+      __syncthreads();
+      epi_argmax_finish(d.epi, best, reinterpret_cast<unsigned long long *>(sm), NT / 64);
+    }
+  }
+}
+
+typedef void (*mix3_fn)(const float2 *, float2 *, MixDesc);
+struct Mix3Entry { unsigned R; int logT, nt; size_t lds; mix3_fn strided, last; };
+#define MIX3(RA_, RB_, RC_, LT_)                                                                                              \
+  { RA_ * RB_ * RC_, LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, Mix3Geom<RA_, RB_, RC_, LT_>::LDS,                                 \
+    k_fft_mix3<RA_, RB_, RC_, LT_, FFT_STRIDED>, k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST> }
+// 8000-point tiles (64 KiB of LDS + the twiddle table): 1000 x 8 columns, 2000 x 4; 500 x 8 (4000 points)
+// (tiles half as wide -- 32-byte runs -- measured 25.8 / 22.9 us per pass against 18.5 / 19.9 at 2e6 points)
+static const Mix3Entry kMix3[] = {MIX3(10, 10, 10, 3), MIX3(20, 10, 10, 2), MIX3(5, 10, 10, 3)};
+#undef MIX3
+static const Mix3Entry *mix3_lookup(unsigned R) {
+  for (const Mix3Entry &e : kMix3)
+    if (e.R == R) return &e;
   return nullptr;
+}
+// kernels above 64 KiB of dynamic LDS have to be opted in once
+static int mix3_prepare(tsdr_ctx *ctx, const Mix3Entry *e) {
+  static std::mutex mu;
+  static std::unordered_map<const void *, bool> done;
+  std::lock_guard<std::mutex> g(mu);
+  for (mix3_fn f : {e->strided, e->last}) {
+    if (done.count((const void *)f)) continue;
+    TSDR_HIP(ctx, hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
+    done[(const void *)f] = true;
+  }
+  return TSDR_OK;
+}
+
+
+
+// ---- the fused middle (k_fft_mid) with three register steps: last forward factor = first inverse factor = 1000 or 2000 ----
+// Same pairing of direct and mirrored columns, same power-spectrum arithmetic; the two length-R DFTs are k_fft_mix3's
+// three steps.  With it a 2e6-point autocorrelation is THREE launches (1000 | 2000 + power + 2000 | 1000) and Z is never
+// written.
+template <int RA, int RB, int RC, int LOGT>
+__global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mid3(const float2 *__restrict__ in, float2 *__restrict__ out, MidDesc d) {
+  using G = Mix3Geom<RA, RB, RC, LOGT>;
+  constexpr int R = G::R, T = G::T, NT = G::NT, PLANE = G::PLANE, R23 = RB * RC, Th = T / 2;
+  extern __shared__ float2 sm[];
+  float2 *buf = sm;                       // [RA][PLANE] exchange tile; also Z[k][t] between the two transforms
+  float2 *twR = sm + RA * PLANE;
+  unsigned *colinfo = reinterpret_cast<unsigned *>(twR + R);  // [T] column (~0: none), [T] source row
+  const int tid = threadIdx.x;
+  const unsigned smask = 0x80000000u;
+  for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
+  const unsigned d0 = blockIdx.x * (unsigned)Th;
+  if (tid < T) {
+    const bool mir = tid >= Th;
+    const unsigned dcol = d0 + (unsigned)(tid & (Th - 1));
+    unsigned c = 0xFFFFFFFFu;
+    if (dcol < d.ndir && !(mir && dcol == 0)) c = mir ? d.Bc - dcol : dcol;
+    unsigned row = 0;
+    if (c != 0xFFFFFFFFu) {
+      unsigned cc = c;
+      for (int j = 0; j < d.nprev; ++j) { const unsigned q = cc / d.Rprev[j]; row = row * d.Rprev[j] + (cc - q * d.Rprev[j]); cc = q; }
+    }
+    colinfo[tid] = c;
+    colinfo[T + tid] = row;
+  }
+  __syncthreads();
+  float2 v[G::VMAX];
+  // three register steps of one length-R DFT per column; on entry v = the slot's RA inputs (slot = (r23, t1)), on exit
+  // v[k3] = X[kk + RA RB k3] of column t3 for the slot (kk, t3) = (tid >> LOGT, tid & (T-1))
+  auto three_steps = [&](int t1, int r23) {
+    if (tid < G::S1) {
+      dft_nat<RA>(v);
+      const int n2 = r23 / RC;
+#pragma unroll
+      for (int k1 = 0; k1 < RA; ++k1) {
+        float2 x = v[k1];
+        if (k1) x = cmul(x, twR[(n2 * k1) * RC]);
+        buf[k1 * PLANE + r23 * T + t1] = x;
+      }
+    }
+    __syncthreads();
+    if (tid < G::S2) {
+      const int t = tid & (T - 1), q = tid >> LOGT, k1 = q / RC, n3 = q - k1 * RC;
+      float2 *p = buf + k1 * PLANE + n3 * T + t;
+#pragma unroll
+      for (int n2 = 0; n2 < RB; ++n2) v[n2] = p[n2 * RC * T];
+      dft_nat<RB>(v);
+#pragma unroll
+      for (int k2 = 0; k2 < RB; ++k2) {
+        float2 x = v[k2];
+        if (k2 || k1) x = cmul(x, twR[n3 * (k1 + RA * k2)]);
+        p[k2 * RC * T] = x;
+      }
+    }
+    __syncthreads();
+    if (tid < G::S3) {
+      const int t = tid & (T - 1), kk = tid >> LOGT, k2 = kk / RA, k1 = kk - k2 * RA;
+      const float2 *p = buf + k1 * PLANE + k2 * RC * T + t;
+#pragma unroll
+      for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T];
+      dft_nat<RC>(v);
+    }
+  };
+  {  // forward: rows are contiguous over the DFT index (slot order with the column slowest)
+    const int t1 = tid / R23, r23 = tid - t1 * R23;
+    const bool ok = tid < G::S1 && colinfo[t1 < T ? t1 : 0] != 0xFFFFFFFFu;
+    const float2 *src = in + (size_t)colinfo[T + (t1 < T ? t1 : 0)] * R + r23;
+#pragma unroll
+    for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok ? src[n1 * R23] : make_float2(0.f, 0.f);
+    three_steps(t1, r23);
+  }
+  const int t3 = tid & (T - 1), kk = tid >> LOGT;
+  __syncthreads();  // every step-3 read of the tile is done
+  if (tid < G::S3) {
+#pragma unroll
+    for (int k3 = 0; k3 < RC; ++k3) buf[(kk + RA * RB * k3) * T + t3] = v[k3];  // park Z[k][t]
+  }
+  __syncthreads();
+  {  // Y from Z[g] and Z[N-g], conjugated for the inverse; slot (r23, t) with the column fastest
+    const int t = tid & (T - 1), r23 = tid >> LOGT;
+    const unsigned c = tid < G::S1 ? colinfo[t] : 0xFFFFFFFFu;
+    const bool ok = c != 0xFFFFFFFFu;
+    const int tp = c == 0u ? t : (t ^ Th);
+#pragma unroll
+    for (int n1 = 0; n1 < RA; ++n1) {
+      const int j = ok ? n1 * R23 + r23 : 0;
+      const int jm = c == 0u ? (j ? R - j : 0) : R - 1 - j;
+      const float2 a = buf[j * T + t], b = buf[jm * T + tp];
+      const float2 E = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+      const float2 D = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+      const float2 O = make_float2(D.y, -D.x);
+      const float2 W = tw_frac(ok ? c + d.Bc * (unsigned)j : 0u, d.w8);
+      const float2 WO = cmul(W, O);
+      const float2 X0 = make_float2(E.x + WO.x, E.y + WO.y), X1 = make_float2(E.x - WO.x, E.y - WO.y);
+      const float P0 = X0.x * X0.x + X0.y * X0.y, P1 = X1.x * X1.x + X1.y * X1.y;
+      const float sum = P0 + P1, dif = P0 - P1;
+      v[n1] = ok ? conj_if(make_float2(sum + dif * W.y, dif * W.x), smask) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();  // Z fully read before the exchange tile overwrites it
+    three_steps(t, r23);
+  }
+  if (tid < G::S3) {
+    const unsigned c = colinfo[t3];
+    if (c != 0xFFFFFFFFu) {
+      const unsigned nn = c / d.Bnext;
+      float2 w = tw_q32(phase_q32(nn * (unsigned)kk, d.ntw_hi, d.ntw_lo));
+      const float2 ws = tw_q32(phase_q32(nn * (unsigned)(RA * RB), d.ntw_hi, d.ntw_lo));
+      float2 *dst = out + c + (size_t)kk * d.Bc;
+#pragma unroll
+      for (int k3 = 0; k3 < RC; ++k3) {
+        dst[(size_t)(RA * RB * k3) * d.Bc] = conj_if(cmul(v[k3], w), smask);
+        w = cmul(w, ws);
+      }
+    }
+  }
+}
+#define MID3(RA_, RB_, RC_, LT_) { RA_ * RB_ * RC_, 0, 1 << LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, k_fft_mid3<RA_, RB_, RC_, LT_> }
+static const MidEntry kMid3[] = {MID3(20, 10, 10, 2), MID3(10, 10, 10, 3)};
+#undef MID3
+static const MidEntry *mid3_lookup(unsigned R) {
+  for (const MidEntry &e : kMid3)
+    if (e.R == R) return &e;
+  return nullptr;
+}
+static size_t mid3_lds(unsigned R, int tm) {
+  for (const Mix3Entry &e : kMix3)
+    if (e.R == R && (1 << e.logT) == tm) return e.lds + 2 * (size_t)tm * 4;
+  return 0;
 }
 
 typedef void (*mix2_fn)(const float2 *, float2 *, MixDesc);
@@ -805,6 +1112,7 @@ static void stage_radices(unsigned e2, unsigned e3, unsigned e5, std::vector<uns
 // measured on MI355X at 2e6..2e7 points): balanced two-step kernels 1, the 25 x n ones ~1.6, the generic LDS-stage
 // kernel ~2.2.
 static double factor_cost(unsigned R) {
+  if (mix3_lookup(R)) return 1.35;  // one pass through a three-step kernel (measured against the balanced two-step ones)
   const Mix2Entry *e = mix2_lookup(R);
   if (!e) return 2.2;
   return e->RA == 25 ? 1.6 : 1.0;
@@ -812,6 +1120,7 @@ static double factor_cost(unsigned R) {
 
 struct PlanSearch {
   unsigned ex[3];
+  bool allow_big = true;  // factors of 500 .. 2000 (three-step kernels)
   int best_p = 0;
   double best = 1e30;
   unsigned cur[MIX_MAX_PASS][3], out[MIX_MAX_PASS][3];
@@ -825,6 +1134,7 @@ struct PlanSearch {
   // factors in non-increasing order (the order is fixed afterwards), depth-first with a cost bound
   void go(int depth, unsigned cap, double cost) {
     if (!(ex[0] | ex[1] | ex[2])) {
+      if (depth == 1 && val(cur[0]) > 256) return;  // the three-step kernels are passes of a multi-pass transform only
       // ties: prefer a factor carrying 2^4 (it goes last: every stride a multiple of 16 elements)
       unsigned m2 = 0;
       for (int i = 0; i < depth; ++i) m2 = std::max(m2, std::min(cur[i][0], 4u));
@@ -851,7 +1161,8 @@ struct PlanSearch {
           const unsigned e[3] = {a, b, c};
           if (a > 8 || b > 5 || c > 3) continue;
           const unsigned R = val(e);
-          if (R < 2 || R > cap || R > 256) continue;
+          if (R < 2 || R > cap) continue;
+          if (R > 256 && !(allow_big && mix3_lookup(R))) continue;
           std::vector<unsigned char> rad;
           stage_radices(a, b, c, rad);
           if (rad.size() > MIX_MAX_STAGE) continue;
@@ -864,31 +1175,33 @@ struct PlanSearch {
 
 // true when N = 2^a 3^b 5^c (N >= 2) and a pass split with every factor <= 256 exists.  The split minimises the
 // summed pass costs above; the factor with the most twos goes last, the others largest first.
-static bool fft_mixed_plan_search(size_t N, MixPlan *plan);
-bool fft_mixed_plan(size_t N, MixPlan *plan) {  // the search runs once per length
+static bool fft_mixed_plan_search(size_t N, MixPlan *plan, bool allow_big);
+bool fft_mixed_plan(size_t N, MixPlan *plan, bool allow_big = true) {  // the search runs once per length
   static std::mutex mu;
-  static std::unordered_map<size_t, std::pair<bool, MixPlan>> cache;
+  static std::unordered_map<size_t, std::pair<bool, MixPlan>> cache[2];
   std::lock_guard<std::mutex> g(mu);
-  auto it = cache.find(N);
-  if (it == cache.end()) {
-    if (cache.size() > 4096) cache.clear();
+  auto &c = cache[allow_big ? 1 : 0];
+  auto it = c.find(N);
+  if (it == c.end()) {
+    if (c.size() > 4096) c.clear();
     MixPlan pl;
-    const bool ok = fft_mixed_plan_search(N, &pl);
-    it = cache.emplace(N, std::make_pair(ok, pl)).first;
+    const bool ok = fft_mixed_plan_search(N, &pl, allow_big);
+    it = c.emplace(N, std::make_pair(ok, pl)).first;
   }
   if (it->second.first) *plan = it->second.second;
   return it->second.first;
 }
-static bool fft_mixed_plan_search(size_t N, MixPlan *plan) {
+static bool fft_mixed_plan_search(size_t N, MixPlan *plan, bool allow_big) {
   if (N < 2 || N >= (size_t(1) << 31)) return false;
   PlanSearch ps;
+  ps.allow_big = allow_big;
   ps.ex[0] = ps.ex[1] = ps.ex[2] = 0;
   const unsigned pr[3] = {2, 3, 5};
   size_t m = N;
   for (int i = 0; i < 3; ++i)
     while (m % pr[i] == 0) { m /= pr[i]; ++ps.ex[i]; }
   if (m != 1) return false;
-  ps.go(0, 256, 0.0);
+  ps.go(0, allow_big ? 2000 : 256, 0.0);
   if (!ps.best_p) return false;
   const int p = ps.best_p;
   int last = 0;
@@ -956,6 +1269,14 @@ static int get_twg(tsdr_ctx *ctx, unsigned R, unsigned Rn, const float2 **out) {
   return TSDR_OK;
 }
 
+// The three-step kernels (factors of 500 .. 2000) trade pass count for narrow tiles -- 8000 points are 1000 x 8 columns,
+// i.e. 64-byte runs.  That wins while a pass is latency-bound and its data cache-resident (2e6 points, 16 MB: two passes of
+// 16 us instead of three of 12), and loses once passes stream from HBM (2e7 points: 128-174 us per pass against 75-85 us
+// for the two-step kernels' 256-byte runs).  So: only for transforms of at most 2^22 points in all.
+static bool fft_big_ok(tsdr_ctx *ctx, size_t total_points) {
+  return ctx->opt_fft_big && !ctx->opt_fft_no_mix2 && total_points <= (size_t(1) << 22);
+}
+
 // in/out may alias.  Uses WS_FFT_B when more than one pass is needed (callers must not hand WS_FFT_B buffers in).
 // src_mode/src_n: fused first-pass loader (fft_dev.h), batch == 1 and p > 1 only; keep: complex outputs per
 // transform the caller will look at (0 = all).
@@ -968,7 +1289,8 @@ static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, 
                         int first_pass, float2 **work_out) {
   MixPlan pl;
   if (force) pl = *force;
-  else if (!fft_mixed_plan(N, &pl)) return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
+  else if (!fft_mixed_plan(N, &pl, fft_big_ok(ctx, N * batch)))
+    return set_err(ctx, TSDR_EINVAL, "fft_mixed: length %zu is not 2^a*3^b*5^c", N);
   if (batch == 0) return TSDR_OK;
   if (N * batch >= (size_t(1) << 40)) return set_err(ctx, TSDR_EINVAL, "fft: batch too large");
   const int p = pl.p;
@@ -1014,10 +1336,12 @@ static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, 
     d.mode = FFT_STRIDED;
     d.src_mode = i == 0 ? src_mode : SRC_C2C;
     d.src_n = src_n;
-    const Mix2Entry *m2 = ctx->opt_fft_no_mix2 ? nullptr : mix2_lookup(d.R);
-    // (the two-step kernels keep their full tile: a narrower one leaves most threads without a step-1 DFT)
-    d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2((unsigned)B)}),
-                       m2 ? 8 : 4, batch * P, B);
+    const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : mix3_lookup(d.R);
+    const Mix2Entry *m2 = (ctx->opt_fft_no_mix2 || m3) ? nullptr : mix2_lookup(d.R);
+    // (the two- and three-step kernels keep their full tile: a narrower one leaves most threads without a step-1 DFT)
+    d.logT = m3 ? m3->logT
+                : pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2((unsigned)B)}),
+                            m2 ? 8 : 4, batch * P, B);
     d.scale = 1.0f;
     d.A = (unsigned)P;
     d.B = (unsigned)B;
@@ -1036,7 +1360,11 @@ static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, 
     if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
     d.tw_sets = 0;
     d.twg = nullptr;
-    if (m2) {
+    if (m3) {
+      int rc3 = mix3_prepare(ctx, m3);
+      if (rc3) return rc3;
+      TSDR_LAUNCH(ctx, kStridedName[i], m3->strided, dim3((unsigned)grid), dim3(m3->nt), m3->lds, src, work, d);
+    } else if (m2) {
       // how the two-step kernel gets its inter-pass twiddles (see the kernel): sets in LDS, or the column table
       const unsigned T = 1u << d.logT;
       if (d.Bnext % T == 0) d.tw_sets = 1;
@@ -1055,9 +1383,11 @@ static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, 
   d.src_mode = SRC_C2C;
   if (epi) d.epi = *epi;
   d.R1 = pl.R[0];
-  const Mix2Entry *m2 = ctx->opt_fft_no_mix2 ? nullptr : mix2_lookup(d.R);
-  d.logT = pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2(d.R1)}), m2 ? 8 : 4,
-                     batch * (P / pl.R[0]), d.R1);
+  const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : mix3_lookup(d.R);
+  const Mix2Entry *m2 = (ctx->opt_fft_no_mix2 || m3) ? nullptr : mix2_lookup(d.R);
+  d.logT = m3 ? m3->logT
+              : pick_logT(std::min({8, m2 ? floor_log2((unsigned)m2->tm) : floor_log2(4096u / d.R), ceil_log2(d.R1)}), m2 ? 8 : 4,
+                          batch * (P / pl.R[0]), d.R1);
   d.scale = scale;
   d.Pprev = (unsigned)P;
   d.nprev = p - 1;
@@ -1069,7 +1399,11 @@ static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, 
   d.k1tiles = (unsigned)ceil_div((size_t)d.R1, (size_t)1 << d.logT);
   const size_t grid = batch * d.Aprime * d.k1tiles;
   if (grid >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: grid too large");
-  if (m2) {
+  if (m3) {
+    int rc3 = mix3_prepare(ctx, m3);
+    if (rc3) return rc3;
+    TSDR_LAUNCH(ctx, "fftm_last", m3->last, dim3((unsigned)grid), dim3(m3->nt), m3->lds, (const float2 *)work, out, d);
+  } else if (m2) {
     TSDR_LAUNCH(ctx, "fftm_last", m2->last, dim3((unsigned)grid), dim3(m2->nt), mix2_lds(d.R, m2->RA, d.logT), (const float2 *)work, out, d);
   } else {
     TSDR_LAUNCH(ctx, "fftm_last", k_fft_mix, dim3((unsigned)grid), dim3(256), mix_lds(d.R, d.logT), (const float2 *)work, out, d);
@@ -1091,10 +1425,26 @@ int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_
                        float scale, size_t keep, const FftEpilogue *epi, bool *done) {
   *done = false;
   MixPlan F;
-  if (!fft_mixed_plan(Mc, &F) || F.p < 2 || Mc >= (size_t(1) << 31)) return TSDR_OK;
+  if (ctx->opt_fft_no_mix2 || !fft_mixed_plan(Mc, &F, fft_big_ok(ctx, Mc)) || F.p < 2 || Mc >= (size_t(1) << 31)) return TSDR_OK;
   const int p = F.p;
+  // the factor that goes LAST in the forward split (and first in the inverse one) must have the fused kernel: of those
+  // that do, the one with the most twos (as the planner's own rule); the others keep their order
+  {
+    auto twos = [&](int i) { unsigned v = F.R[i], t = 0; while (v % 2 == 0 && t < 4) { v /= 2; ++t; } return t; };
+    int pick = -1;
+    for (int i = 0; i < p; ++i)
+      if (mid_lookup(F.R[i]) && (pick < 0 || twos(i) > twos(pick) || (twos(i) == twos(pick) && F.R[i] > F.R[pick]))) pick = i;
+    // (2e6 points: 1000 | 2000-mid | 1000 and 2000 | 1000-mid | 2000 measured the same, 74-75 us per search)
+    if (pick < 0) return TSDR_OK;
+    if (pick != p - 1) {
+      const unsigned r = F.R[pick];
+      const std::vector<unsigned char> rd = F.rad[pick];
+      for (int i = pick; i < p - 1; ++i) { F.R[i] = F.R[i + 1]; F.rad[i] = F.rad[i + 1]; }
+      F.R[p - 1] = r;
+      F.rad[p - 1] = rd;
+    }
+  }
   const MidEntry *me = mid_lookup(F.R[p - 1]);
-  if (!me || ctx->opt_fft_no_mix2) return TSDR_OK;
   // inverse split: the forward's last factor first; of the others the one with the most twos last, the rest largest first
   MixPlan I;
   I.p = p;
@@ -1137,7 +1487,20 @@ int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_
   float2 *w = nullptr;
   int rc = fft_mixed_ex(ctx, x, nullptr, Mc, 1, -1, 1.0f, src_mode, src_n, 0, nullptr, nullptr, &F, 0, &w);
   if (rc) return rc;
-  {
+  if (me->RA == 0) {  // three-step kernel
+    const size_t lds = mid3_lds(m.R, me->tm);
+    static std::mutex mu;
+    static std::unordered_map<const void *, bool> done;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (!done.count((const void *)me->fn)) {
+        TSDR_HIP(ctx, hipFuncSetAttribute((const void *)me->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done[(const void *)me->fn] = true;
+      }
+    }
+    const unsigned grid = (unsigned)ceil_div((size_t)m.ndir, (size_t)Th);
+    TSDR_LAUNCH(ctx, "fftm_mid", me->fn, dim3(grid), dim3(me->nt), lds, (const float2 *)w, Zbuf, m);
+  } else {
     const size_t T = (size_t)1 << m.logT, RB = m.R / me->RA;
     const size_t SA = (RB << m.logT) + (T < 32 ? T : 0);
     const size_t lds = (std::max((size_t)m.R * (T + 1), (size_t)me->RA * SA) + (size_t)(1 + 2 * m.tw_sets) * m.R) * sizeof(float2) + 2 * T * 4;
@@ -1163,7 +1526,7 @@ extern "C" int tsdr_fft_plan(size_t n, unsigned *factors, int cap) {
     return p;
   }
   MixPlan pl;
-  if (!fft_mixed_plan(n, &pl)) return 0;
+  if (!fft_mixed_plan(n, &pl, n <= (size_t(1) << 22))) return 0;  // (as fft_big_ok with the default options, batch 1)
   for (int i = 0; i < pl.p && i < cap && factors; ++i) factors[i] = pl.R[i];
   return pl.p;
 }

@@ -63,7 +63,7 @@ def test_zoom_bounds_is_pure_host_logic(tsdr):
 
 
 def test_fft_plan_is_pure_host_logic(tsdr):
-    """The pass planner of the FFT engines (host arithmetic): factors multiply back to n, none exceeds 256, at most six
+    """The pass planner of the FFT engines (host arithmetic): factors multiply back to n, none exceeds 256 except the three-step kernels' 500 / 1000 / 2000 (multi-pass splits of at most 2^22 points), at most six
     passes; lengths with a prime factor above 5 take the Bluestein route (0 passes reported)."""
     import random
     lib = tsdr._lib.load()

@@ -72,6 +72,23 @@ def test_fft_mixed_radix(ctx, n):
     assert e < FFT_TOL, f"inverse n={n}: {e:.3e}"
 
 
+@pytest.mark.parametrize("n", [250_000, 500_000, 1_000_000, 2_000_000, 4_000_000, 80_000, 100_000, 3_000_000, 1500 * 2000, 20_000_000])
+def test_fft_three_step_passes(ctx, n):
+    """Factors of 500 / 1000 / 2000 (k_fft_mix3: three register steps, 8000-point tiles) as first, middle and last pass,
+    ragged column tiles, and the same lengths with the option off (two-step kernels only) as the cross-check."""
+    x = crandn(n)
+    ref = np.fft.fft(x.astype(np.complex128))
+    for big in (1, 0):
+        ctx.set_option("fft_big", big)
+        try:
+            e = relmax(ctx.fft(x), ref)
+            assert e < FFT_TOL, f"n={n} big={big}: {e:.3e}"
+            e = relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128)))
+            assert e < FFT_TOL, f"inverse n={n} big={big}: {e:.3e}"
+        finally:
+            ctx.set_option("fft_big", 1)
+
+
 @pytest.mark.parametrize("n", [1000, 30000, 390_625, 2_000_000, 2_400_000])
 def test_fft_mixed_radix_lds_stage_kernel(ctx, n):
     """Factor sizes without a two-register-step kernel (e.g. 60, 120, 150) go through the generic LDS-stage kernel;
