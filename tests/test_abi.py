@@ -79,7 +79,7 @@ def test_fft_plan_is_pure_host_logic(tsdr):
         assert 1 <= p <= 6, (n, p)
         prod = 1
         for i in range(p):
-            assert 2 <= f[i] <= 256, (n, list(f)[:p])
+            assert 2 <= f[i] <= 256 or (f[i] in (500, 1000, 2000) and p > 1 and n <= 1 << 22), (n, list(f)[:p])
             prod *= f[i]
         assert prod == n, (n, list(f)[:p])
     # the search transforms of the three workloads: three, three and four passes
