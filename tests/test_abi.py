@@ -82,8 +82,10 @@ def test_fft_plan_is_pure_host_logic(tsdr):
             assert 2 <= f[i] <= 256 or (f[i] in (500, 1000, 2000) and p > 1 and n <= 1 << 22), (n, list(f)[:p])
             prod *= f[i]
         assert prod == n, (n, list(f)[:p])
-    # the search transforms of the three workloads: three, three and four passes
-    assert lib.tsdr_fft_plan(2_000_000, f, 8) == 3 and sorted(f[:3]) == [100, 100, 200]
-    assert lib.tsdr_fft_plan(20_000_000, f, 8) == 4
+    # the search transforms of the workloads: C2 two passes of the three-step kernels (2e6 points stay cache-resident), C5
+    # and C3 (5e6 / 2e7 points, streamed from HBM) three and four passes of the two-step kernels
+    assert lib.tsdr_fft_plan(2_000_000, f, 8) == 2 and sorted(f[:2]) == [1000, 2000]
+    assert lib.tsdr_fft_plan(5_000_000, f, 8) == 3 and max(f[:3]) <= 256
+    assert lib.tsdr_fft_plan(20_000_000, f, 8) == 4 and max(f[:4]) <= 256
     for n in (7, 999 * 3, 1_000_003, 2 * 7 * 11):
         assert lib.tsdr_fft_plan(n, f, 8) == 0
