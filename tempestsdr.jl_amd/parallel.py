@@ -274,7 +274,9 @@ def bench_search(ctx, iq, n, n_lags, Fs, steps, world, rank, dev):
                       f"replicated on {world} GPUs: a rank's segment+halo transform ({sharded_route_points(n, n_lags, world)} points) "
                       f"would not be smaller than the single-GPU one ({single_route_points(n, n_lags)} points), so no collective is used")),
             "includes": "abs2, FFT autocorrelation, 10log10(abs2), zoom argmax with host readback (tsdr_autocorr_search_d: "
-                        "one call; on the mixed-radix route 5 launches for 3+3 passes)"}
+                        "one call; the last forward pass, the power spectrum and the first inverse pass are one launch, the "
+                        "findmax an epilogue of the last pass + a one-wavefront publish launch; 2e6-point transforms run as "
+                        "1000 | 2000 in three-step kernels: 3 launches + publish)"}
 
 
 # ---------------------------------------------------------------------------------------------
