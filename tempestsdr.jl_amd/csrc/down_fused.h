@@ -56,7 +56,7 @@ __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
 
 // NT: threads of the workgroup (a multiple of 64); lds_dn: its dynamic LDS region (plan_down's `lds` bytes)
 template <bool CPLX, int MODE, int NT>
-__device__ inline void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
+__device__ __forceinline__ void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
                                        float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn) {
   constexpr bool EXACT = MODE == DM_EXACT;
   constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample

@@ -72,10 +72,13 @@ __device__ inline float wave_tree64(float v) {  // oracle tree64: v[i] += v[i+of
 // (launch bound: 128 registers, so that two workgroups share a CU and the 300 of a C2 buffer are resident at once --
 // at 136 registers they ran in two rounds)
 constexpr size_t kProjLds = (size_t)(8 * 64 * 26 + 64) * sizeof(float);  // 8 tiles of 64 x 26 floats + the row chain: 52 KiB
-// body of one k_proj workgroup (512 threads): frame f, 64-row block rb; lds: kProjLds bytes
-__device__ inline void proj_wg(const float *__restrict__ img, size_t img_stride, int y_t, int x_t, float *__restrict__ proj,
-                               size_t proj_stride, unsigned long long *__restrict__ keys, int f, int rb, float *lds) {
+// body of one k_proj workgroup (512 threads): frame f, 64-row block rb; uses the first kProjLds bytes of the launch's
+// dynamic LDS (declared here, not passed in: through a pointer parameter the compiler lost the address space, issued flat
+// accesses and moved the 100-value register array to scratch -- k_proj 27 -> 52 us)
+__device__ __forceinline__ void proj_wg(const float *__restrict__ img, size_t img_stride, int y_t, int x_t, float *__restrict__ proj,
+                               size_t proj_stride, unsigned long long *__restrict__ keys, int f, int rb) {
   constexpr int CH = 100, SB = 25, PITCH = SB + 1, RND = 8 * CH;
+  extern __shared__ float lds[];
   float *chain = lds + 8 * 64 * PITCH;
   const int nrb = (y_t + 63) >> 6;
   const float *im = img + (size_t)f * img_stride;
@@ -143,8 +146,7 @@ __device__ inline void proj_wg(const float *__restrict__ img, size_t img_stride,
 __global__ __launch_bounds__(512, 4) void k_proj(const float *__restrict__ img, size_t img_stride, int y_t, int x_t,
                                                  float *__restrict__ proj, size_t proj_stride,
                                                  unsigned long long *__restrict__ keys) {
-  extern __shared__ float proj_lds[];
-  proj_wg(img, img_stride, y_t, x_t, proj, proj_stride, keys, (int)blockIdx.y, (int)blockIdx.x, proj_lds);
+  proj_wg(img, img_stride, y_t, x_t, proj, proj_stride, keys, (int)blockIdx.y, (int)blockIdx.x);
 }
 constexpr int kProjRowParts = 1;
 static inline dim3 proj_grid(int y_t, int frames) { return dim3((unsigned)((y_t + 63) >> 6), (unsigned)frames); }
@@ -303,7 +305,7 @@ __device__ inline int gridDim_x_of_frame(const SyncGeom &g) { return ((g.x_t + 6
 
 // body of one k_beta workgroup: blk = block index within the frame (x-axis blocks first), f = frame
 template <int NWV>
-__device__ inline void beta_wg(const BetaArgs &A, int blk, int f, float *sh) {
+__device__ __forceinline__ void beta_wg(const BetaArgs &A, int blk, int f, float *sh) {
   const float *__restrict__ proj = A.proj;
   const size_t proj_stride = A.proj_stride;
   const int ncp = A.ncp, nrp = A.nrp;
@@ -498,7 +500,7 @@ struct IirArgs {
 };
 
 // body of one shift + IIR workgroup: wg = workgroup index, nthr = its thread count
-__device__ inline void shift_iir_wg(const IirArgs &A, unsigned wg, unsigned nthr) {
+__device__ __forceinline__ void shift_iir_wg(const IirArgs &A, unsigned wg, unsigned nthr) {
   const float *__restrict__ img = A.img;
   const size_t img_stride = A.img_stride;
   const int h = A.h, w = A.w, frames = A.frames, do_align = A.do_align;
@@ -719,7 +721,8 @@ __device__ inline void guard_signal(unsigned *ctr) {
 }
 
 #ifndef TSDR_ROWSUM_CHUNK8
-__global__ __launch_bounds__(512, 4) void k_guard(GuardAllArgs a) {
+// (launch bound: one workgroup per CU is all the launch asks for, so the bodies may use up to 256 registers: no spills)
+__global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
   extern __shared__ double glds[];
   __shared__ int list[kGuardChunk];
   __shared__ int cnt_s;
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(512, 4) void k_guard(GuardAllArgs a) {
       const unsigned u = t - nA;
       const int j = (int)(u / (unsigned)a.nB), rb = (int)(u - (unsigned)j * (unsigned)a.nB);
       guard_wait(doneA + j, (unsigned)a.tilesA);
-      proj_wg(a.img, a.img_stride, a.y_t, a.x_t, a.proj, a.proj_stride, a.B.keys, list[j], rb, reinterpret_cast<float *>(glds));
+      proj_wg(a.img, a.img_stride, a.y_t, a.x_t, a.proj, a.proj_stride, a.B.keys, list[j], rb);
       guard_signal(doneB + j);
     } else {
       const unsigned u = t - nA - nBt;

@@ -24,5 +24,7 @@ for leg in welch waterfall welch_1000 spectrum resampler_1024x4 resampler_100000
   python3 $R/tools/make_traffic.py --spectra $leg $CALLS $O/${TAG}_pmcs_${leg}_FETCH_SIZE $O/${TAG}_pmcs_${leg}_WRITE_SIZE $TAG >> $O/${TAG}_traffic_spectra.txt
   rm -rf $O/${TAG}_pmcs_${leg}_FETCH_SIZE $O/${TAG}_pmcs_${leg}_WRITE_SIZE
 done
-cp $R/profiles/traffic.json $O/${TAG}_traffic_full.json
+cp $R/profiles/traffic.json $O/${TAG}_traffic_full.json   # (the box's copy: C2 frame kernels + search + spectra legs of this tag)
+# the bench line once more, now that this tag's traffic file is in place (its `traffic` fields are read from it)
+python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 ls $O | grep $TAG
