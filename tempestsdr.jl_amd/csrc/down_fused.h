@@ -54,10 +54,14 @@ __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
   return fast_blend(r[j], r[j + 1], x - xf);
 }
 
-// NT: threads of the workgroup (a multiple of 64); lds_dn: its dynamic LDS region (plan_down's `lds` bytes)
-template <bool CPLX, int MODE, int NT>
+// NT: threads of the workgroup (a multiple of 64); lds_dn: its dynamic LDS region (plan_down's `lds` bytes).
+// COLSUM (sync guard): the tile's rows are one of k_proj's 64-row blocks, so the body also leaves that block's column
+// sums of its TC columns -- rows added in row order from 0.0f, exactly k_proj's colpart -- in colpart[c] (c = image
+// column); colT: TC * 65 floats of LDS beyond lds_dn's region.
+template <bool CPLX, int MODE, int NT, bool COLSUM = false>
 __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
-                                       float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn) {
+                                       float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn,
+                                       float *__restrict__ colpart = nullptr, float *colT = nullptr) {
   constexpr bool EXACT = MODE == DM_EXACT;
   constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample
   const int Wp = q.W | 1;
@@ -131,7 +135,8 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   }
   const int wave = tid >> 6, lane = tid & 63;
   const int r = r0 + lane;
-  if (r >= q.h_out) return;  // (no barrier follows in the body)
+  if (!COLSUM && r >= q.h_out) return;  // (no barrier follows in the body)
+  if (r < q.h_out) {
   double dy;
   const int ky = (int)rs_pos(ay, (double)(r + 1), dy);
   const int i0 = ky - ly0;
@@ -174,6 +179,18 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
       v = (float)fma(dy, bot - top, top);
     }
     o[(size_t)c * q.h_out] = v;
+    if (COLSUM) colT[ct * 65 + lane] = v;
+  }
+  }
+  if (COLSUM) {
+    __syncthreads();
+    const int nval = min(64, q.h_out - r0), c = c0 + tid;
+    if (tid < q.TC && c < q.w_out) {
+      float t = 0.0f;
+      const float *col = colT + tid * 65;
+      for (int rr = 0; rr < nval; ++rr) t = __fadd_rn(t, col[rr]);
+      colpart[c] = t;
+    }
   }
 }
 

@@ -51,7 +51,7 @@ __device__ inline bool guard_axis(const uint2 *e, int nb, float thr) {
 }
 
 // true when frame f needs the exact re-evaluation (one lane does a whole frame: two short scans of the records)
-__device__ inline bool guard_eval(const GuardArgs &g, int f) {
+__device__ inline bool guard_eval(const GuardArgs &g, int f, bool *y_too = nullptr) {
   const uint2 *base = g.top2 + (size_t)f * (size_t)(g.nbx + g.nby);
   bool bx, by;  // (both axes are always evaluated: no divergent second scan)
   if (g.nbx == 13 && g.nby == 10) {  // the 600 x 800 rendering image (the only SyncXY the frame loop accepts)
@@ -61,6 +61,7 @@ __device__ inline bool guard_eval(const GuardArgs &g, int f) {
     bx = guard_axis<0>(base, g.nbx, g.thr);
     by = guard_axis<0>(base + g.nbx, g.nby, g.thr);
   }
+  if (y_too) *y_too = by;
   return bx || by;
 }
 #endif

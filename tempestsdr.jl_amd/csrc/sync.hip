@@ -745,9 +745,10 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
       int n = 0;
       for (int base = 0; base < a.frames; base += 64) {
         const int f = base + tid;
-        const bool bad = f < a.frames && guard_eval(gl, f);
+        bool bad_y = false;
+        const bool bad = f < a.frames && guard_eval(gl, f, &bad_y);
         const unsigned long long m = __ballot(bad);
-        if (bad) list[n + (int)__builtin_popcountll(m & ((1ull << tid) - 1ull))] = f;
+        if (bad) list[n + (int)__builtin_popcountll(m & ((1ull << tid) - 1ull))] = f | (bad_y ? 0x40000000 : 0);
         n += (int)__builtin_popcountll(m);
         if (blockIdx.x == 0 && f < a.frames) a.g.flags[f] = bad ? 1 : 0;
       }
@@ -771,21 +772,38 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
     const unsigned t = ticket_s;
     __syncthreads();
     if (t >= nA + nBt + nCt) break;
+    // list[j]: frame, bit 30 = the y axis is too close to call as well.  Only then do the row sums -- one strict left-to-right
+    // chain per row, the slow part -- have to be redone: when x alone is flagged (the usual case: frames drift along x), the
+    // image tiles leave the exact column sums themselves (they are k_proj's 64-row blocks) and the x scan follows them directly
     if (t < nA) {
       const int j = (int)(t / (unsigned)a.tilesA), tile = (int)(t - (unsigned)j * (unsigned)a.tilesA);
-      down_fused_body<true, DM_EXACT, 512>(a.iq, a.in_stride, a.dq, a.img, a.img_stride, tile, list[j], glds);
+      const int f = list[j] & 0x3FFFFFFF;
+      if (tile == 0 && tid == 0) a.B.keys[(size_t)f * 2] = 0ull;  // the x key (proj_wg clears both when it runs)
+      const int tr = tile / a.dq.tiles_c;
+      down_fused_body<true, DM_EXACT, 512, true>(a.iq, a.in_stride, a.dq, a.img, a.img_stride, tile, f, glds,
+                                                  a.proj + (size_t)f * a.proj_stride + (size_t)tr * a.x_t,
+                                                  reinterpret_cast<float *>(reinterpret_cast<char *>(glds) + a.lds_bytes));
       guard_signal(doneA + j);
     } else if (t < nA + nBt) {
       const unsigned u = t - nA;
       const int j = (int)(u / (unsigned)a.nB), rb = (int)(u - (unsigned)j * (unsigned)a.nB);
-      guard_wait(doneA + j, (unsigned)a.tilesA);
-      proj_wg(a.img, a.img_stride, a.y_t, a.x_t, a.proj, a.proj_stride, a.B.keys, list[j], rb);
-      guard_signal(doneB + j);
+      if (list[j] & 0x40000000) {
+        guard_wait(doneA + j, (unsigned)a.tilesA);
+        proj_wg(a.img, a.img_stride, a.y_t, a.x_t, a.proj, a.proj_stride, a.B.keys, list[j] & 0x3FFFFFFF, rb);
+        guard_signal(doneB + j);
+      }
     } else {
       const unsigned u = t - nA - nBt;
       const int j = (int)(u / (unsigned)a.nC), blk = (int)(u - (unsigned)j * (unsigned)a.nC);
-      guard_wait(doneB + j, (unsigned)a.nB);
-      beta_wg<8>(a.B, blk, list[j], reinterpret_cast<float *>(glds));
+      const bool need_y = (list[j] & 0x40000000) != 0;
+      const int nbx = (a.x_t + 63) >> 6;
+      if (need_y) {
+        guard_wait(doneB + j, (unsigned)a.nB);
+        beta_wg<8>(a.B, blk, list[j] & 0x3FFFFFFF, reinterpret_cast<float *>(glds));
+      } else if (blk < nbx) {
+        guard_wait(doneA + j, (unsigned)a.tilesA);
+        beta_wg<8>(a.B, blk, list[j] & 0x3FFFFFFF, reinterpret_cast<float *>(glds));
+      }
     }
     __syncthreads();  // the item's LDS is free again
   }
@@ -840,7 +858,8 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     a.B.write_frame = (f0 + nf == frames) ? nf - 1 : -1;
     a.nB = (y + 63) >> 6; a.nC = (int)nbb;
     a.sync = ctx->guard_sync;
-    const size_t lds = std::max(std::max(a.lds_bytes, kProjLds), lds_beta);
+    a.lds_bytes = (a.lds_bytes + 15) & ~(size_t)15;
+    const size_t lds = std::max(std::max(a.lds_bytes + (size_t)a.dq.TC * 65 * 4, kProjLds), lds_beta);
     a.lds_total = lds;
     static const int grid_env = getenv("TSDR_GUARD_GRID") ? atoi(getenv("TSDR_GUARD_GRID")) : 0;  // (development: A/B of the grid size)
     const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)ncu;
