@@ -254,6 +254,17 @@ def test_sync_guard_queue_under_full_load(ctx, tsdr, synth, wl, nfr, ppb):
         ctx.set_option("sync_guard_ppb", 20000)
 
 
+def test_sync_guard_many_frames_in_chunks(ctx, tsdr, synth):
+    """More frames per buffer than one guard launch lists (256): 300 frames of a small raster with the plateau leak, whose
+    flagged frames fall into both launches; indices identical to the oracle on all of them."""
+    Fs, x_t, y_t, fv, nfr = 1.0e6, 300, 130, 50.0, 300
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 5, card="plateau")
+    r = fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, 0.1, False, RTOL)
+    assert r["n_frames"] == nfr and not r["ties"] and r["guard"][0] == nfr
+    print("sync guard (checked, re-evaluated):", r["guard"])
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_frames_fast_random_geometries(ctx, tsdr, seed):
     """Random raster sizes and sampling ratios (0.08 .. 1.6 samples per pixel), white-noise IQ -- the hardest input
