@@ -704,7 +704,13 @@ struct GuardAllArgs {
 
 __device__ inline void guard_wait(unsigned *ctr, unsigned target) {
   if (threadIdx.x == 0) {
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+    // (the queue cannot deadlock by construction; the bound turns a protocol bug into a failed launch instead of a hung GPU:
+    // 2^24 polls are several seconds, four orders of magnitude beyond any real wait)
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 24)) __builtin_trap();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
