@@ -74,7 +74,11 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
  *               sync guard re-evaluates, in the TSDR_EXACT operation sequence (image, projections, beta scan),
  *               every frame whose best blank-band column leads the best other column by less than the guard
  *               threshold (relative; default 2e-5, option "sync_guard_ppb") on either axis; such a frame
- *               carries TSDR_EXACT pixels.  tsdr_sync_guard_stats reports how often that happened.
+ *               carries TSDR_EXACT pixels.  tsdr_sync_guard_stats reports how often that happened.  When more
+ *               than 15 % of the recent frames were flagged (an input whose blanking interval is flat, so that
+ *               neighbouring columns tie), re-evaluating them one by one costs more than computing everything
+ *               exactly: the loop then runs WHOLE buffers in the TSDR_EXACT sequence (frames keep being counted)
+ *               until the share falls below 5 % (option "sync_guard_auto", default 1; tsdr_sync_guard_auto).
  * The mode applies ONLY to tsdr_frames / _d / _submit_d / _scan_d.  The per-function entry points
  * (tsdr_sig_to_image, tsdr_resize1d/2d, tsdr_downgrade, tsdr_vsync, ... and their _d forms) always run
  * the TSDR_EXACT operation sequence.  Shift + IIR are evaluated identically in both modes. */
@@ -89,14 +93,21 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 first inverse pass run as one launch; 0: two separate transforms.
  *   "sync_guard_ppb"  sync-guard threshold of the TSDR_FAST frame loop in parts per billion (default 20000 = 2e-5;
  *                 0 switches the guard off: indices may then differ from the reference's where beta is tied at 1e-7).
- * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB preset them, read once in tsdr_create. */
+ *   "sync_guard_auto" 1 (default): the adaptive whole-buffer TSDR_EXACT route described above; 0: flagged frames are always
+ *                 re-evaluated one by one.
+ * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO preset them, read
+ * once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
-/* running totals of the sync guard on this context: frames whose margins were checked / frames re-evaluated in the
- * TSDR_EXACT sequence.  Synchronises; reset != 0 zeroes the totals. */
+/* running totals of the sync guard on this context: frames whose margins were checked / frames flagged (re-evaluated in
+ * the TSDR_EXACT sequence, one by one or as part of a whole exact buffer).  Synchronises; reset != 0 zeroes the totals. */
 int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, unsigned long long *frames_reevaluated, int reset);
 /* relative top-2 margins (best column vs best OTHER column) the guard saw in the most recent TSDR_FAST frame-loop call
  * on this context, BEFORE any re-evaluation: margins[2f] = beta_x of frame f (decides s_x of frame f), margins[2f+1] =
  * beta_y of frame f (decides s_y of frame f+1).  Fills min(*n_frames, max_frames) frames.  Synchronises. */
+/* state of the adaptive route (host-side, no synchronisation): *exact_now = 1 while whole buffers run in the TSDR_EXACT
+ * sequence; *buffers_exact = frame-loop calls that did so far; *switches = changes of route so far.  The decision uses
+ * counters of completed buffers only, so it lags by the buffers in flight. */
+int tsdr_sync_guard_auto(tsdr_ctx *ctx, int *exact_now, unsigned long long *buffers_exact, unsigned long long *switches);
 int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *n_frames);
 
 /* resident buffers for callers without their own device allocator */

@@ -80,14 +80,20 @@ class Context:
         return "exact" if self.lib.tsdr_get_precision(self.h) == _lib.EXACT else "fast"
 
     def set_option(self, name, value):
-        """switches ("ac_mixed", "fft_no_mix2", "sync_guard_ppb") -- tsdr_set_option"""
+        """switches ("ac_mixed", "fft_no_mix2", "sync_guard_ppb", "sync_guard_auto", ...) -- tsdr_set_option"""
         self.call("tsdr_set_option", name.encode(), int(value))
 
     def sync_guard_stats(self, reset=False):
-        """running totals of the FAST frame loop's sync guard: (frames checked, frames re-evaluated exactly)"""
+        """running totals of the FAST frame loop's sync guard: (frames checked, frames flagged = computed exactly)"""
         a, b = C.c_ulonglong(0), C.c_ulonglong(0)
         self.call("tsdr_sync_guard_stats", C.byref(a), C.byref(b), int(bool(reset)))
         return int(a.value), int(b.value)
+
+    def sync_guard_auto(self):
+        """adaptive route of the sync guard: (whole buffers run exactly right now?, calls that did, route changes)"""
+        e, a, b = C.c_int(0), C.c_ulonglong(0), C.c_ulonglong(0)
+        self.call("tsdr_sync_guard_auto", C.byref(e), C.byref(a), C.byref(b))
+        return bool(e.value), int(a.value), int(b.value)
 
     def sync_guard_margins(self, max_frames=1 << 16):
         """(frames, 2) relative top-2 margins (x, y) the guard saw in the last FAST frame-loop call"""

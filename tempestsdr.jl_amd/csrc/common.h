@@ -69,6 +69,16 @@ struct tsdr_ctx {
   float guard_thr = 2e-5f;
   unsigned long long *guard_stats = nullptr;
   unsigned *guard_sync = nullptr;           // work-queue words of the guard kernel (zero between launches)
+  // adaptive route (option "sync_guard_auto"): when more than guard_auto_hi of the recent frames were flagged, re-evaluating
+  // them one by one costs more than running whole buffers in the exact sequence, so the FAST frame loop does that until the
+  // share (still counted, on the exact statistics) falls below guard_auto_lo.  Decided on the host from a pinned mirror of
+  // the device counters: no synchronisation, the decision lags by the buffers in flight.
+  int opt_guard_auto = 1;
+  float guard_auto_hi = 0.15f, guard_auto_lo = 0.05f;
+  unsigned long long *guard_host = nullptr;  // pinned: checked << 32 | flagged
+  unsigned guard_seen_c = 0, guard_seen_f = 0;
+  bool guard_exact_now = false;
+  unsigned long long guard_auto_buffers = 0, guard_auto_switches = 0;
   const uint2 *guard_last_top2 = nullptr;  // the top-2 records of the most recent guarded call (tsdr_sync_guard_margins)
   int guard_last_frames = 0, guard_last_nbx = 0, guard_last_nby = 0;
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];

@@ -127,6 +127,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_AC_FUSE_MID")) ctx->opt_ac_fuse_mid = atoi(e) != 0;
   if (const char *e = getenv("TSDR_FFT_BIG")) ctx->opt_fft_big = atoi(e) != 0;
   if (const char *e = getenv("TSDR_SYNC_GUARD_PPB")) ctx->guard_thr = (float)atoi(e) * 1e-9f;
+  if (const char *e = getenv("TSDR_SYNC_GUARD_AUTO")) ctx->opt_guard_auto = atoi(e) != 0;
   return ctx;
 }
 
@@ -143,6 +144,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->amax_keys) (void)hipFree(ctx->amax_keys);
   if (ctx->guard_stats) (void)hipFree(ctx->guard_stats);
   if (ctx->guard_sync) (void)hipFree(ctx->guard_sync);
+  if (ctx->guard_host) (void)hipHostFree(ctx->guard_host);
   if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
@@ -188,8 +190,26 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");
     ctx->guard_thr = (float)value * 1e-9f;
+    // the adaptive route's history belongs to the old threshold: start over on the fast route
+    ctx->guard_exact_now = false;
+    if (ctx->guard_host) {
+      const unsigned long long w = __atomic_load_n(ctx->guard_host, __ATOMIC_RELAXED);
+      ctx->guard_seen_c = (unsigned)(w >> 32); ctx->guard_seen_f = (unsigned)w;
+    }
+  }
+  else if (!strcmp(name, "sync_guard_auto")) {
+    ctx->opt_guard_auto = value != 0;
+    if (!value) ctx->guard_exact_now = false;
   }
   else return tsdr::set_err(ctx, TSDR_EINVAL, "unknown option '%s'", name);
+  return TSDR_OK;
+}
+
+int tsdr_sync_guard_auto(tsdr_ctx *ctx, int *exact_now, unsigned long long *buffers_exact, unsigned long long *switches) {
+  if (!ctx) return TSDR_EINVAL;
+  if (exact_now) *exact_now = ctx->guard_exact_now ? 1 : 0;
+  if (buffers_exact) *buffers_exact = ctx->guard_auto_buffers;
+  if (switches) *switches = ctx->guard_auto_switches;
   return TSDR_OK;
 }
 

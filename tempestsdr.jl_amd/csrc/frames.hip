@@ -69,10 +69,26 @@ struct PrecisionScope {  // a call that has to run in TSDR_EXACT restores the ca
   ~PrecisionScope() { ctx->precision = saved; }
 };
 
+// the adaptive route's decision (common.h): evaluated over windows of at least kGuardAutoWindow frames
+constexpr unsigned kGuardAutoWindow = 60;
+static void guard_auto_update(tsdr_ctx *ctx) {
+  if (!ctx->opt_guard_auto) { ctx->guard_exact_now = false; return; }
+  if (!ctx->guard_host) return;
+  const unsigned long long w = __atomic_load_n(ctx->guard_host, __ATOMIC_RELAXED);
+  const unsigned c = (unsigned)(w >> 32), fl = (unsigned)w;
+  const unsigned dc = c - ctx->guard_seen_c, df = fl - ctx->guard_seen_f;
+  if (dc < kGuardAutoWindow) return;
+  const float share = (float)df / (float)dc;
+  if (!ctx->guard_exact_now && share > ctx->guard_auto_hi) { ctx->guard_exact_now = true; ++ctx->guard_auto_switches; }
+  else if (ctx->guard_exact_now && share < ctx->guard_auto_lo) { ctx->guard_exact_now = false; ++ctx->guard_auto_switches; }
+  ctx->guard_seen_c = c; ctx->guard_seen_f = fl;
+}
+
 static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int x_t, int do_align, int F, int slot, int nslots,
                          GuardPlan *gp) {
   *gp = GuardPlan{};
   if (!do_align || ctx->precision != TSDR_FAST || !(ctx->guard_thr > 0.f)) return TSDR_OK;
+  guard_auto_update(ctx);
   int nbx = 0, nby = 0;
   sync_beta_blocks(sync, &nbx, &nby);
   GuardArgs g;
@@ -82,8 +98,15 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
   if (rc) return rc;
   if (!can) { ctx->precision = TSDR_EXACT; return TSDR_OK; }  // (the caller holds a PrecisionScope)
   if (!ctx->guard_stats) {
-    TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_stats, 16));
-    TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_stats, 0, 16, ctx->stream));
+    TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_stats, 32));
+    TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_stats, 0, 32, ctx->stream));
+    TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->guard_host, 8, hipHostMallocDefault));
+    *ctx->guard_host = 0ull;
+  }
+  if (ctx->opt_guard_auto && ctx->guard_exact_now) {  // this buffer: the exact sequence as a whole; flagged frames are only counted
+    ctx->precision = TSDR_EXACT;                      // (the caller holds a PrecisionScope)
+    g.count_only = 1;
+    ++ctx->guard_auto_buffers;
   }
   const size_t per = ((size_t)F * 4 + 15) / 16 * 16 + (size_t)F * (size_t)(nbx + nby) * 8;
   char *w = (char *)ctx->scratch(WS_GUARD, (size_t)nslots * per);
@@ -93,6 +116,7 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
   gp->top2 = (uint2 *)(w + ((size_t)F * 4 + 15) / 16 * 16);
   g.top2 = gp->top2;
   g.stats = ctx->guard_stats;
+  g.host = ctx->guard_host;
   gp->g = g;
   gp->on = true;
   ctx->guard_last_top2 = gp->top2; ctx->guard_last_frames = F; ctx->guard_last_nbx = nbx; ctx->guard_last_nby = nby;

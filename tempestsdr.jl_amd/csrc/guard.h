@@ -21,7 +21,10 @@ struct GuardArgs {
   int nbx = 0, nby = 0;         // k_beta workgroups per frame along x / y
   float thr = 0.f;              // relative margin below which a frame is re-evaluated
   int *flags = nullptr;         // [frames] out: 1 = re-evaluated
-  unsigned long long *stats = nullptr;  // [0] frames checked, [1] frames re-evaluated (running totals)
+  unsigned long long *stats = nullptr;  // [0] frames checked, [1] frames flagged (running totals; resettable), [2] the same
+                                        // two as one never-reset word: checked << 32 | flagged (both mod 2^32)
+  unsigned long long *host = nullptr;   // pinned host mirror of stats[2]: what the adaptive mode switch reads without a sync
+  int count_only = 0;                   // 1: the buffer was computed in the exact sequence as a whole; only count
 };
 
 constexpr int kGuardChunk = 256;   // frames per guard_image launch

@@ -763,13 +763,19 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
         if (blockIdx.x == 0) {
           atomicAdd(&a.g.stats[0], (unsigned long long)a.frames);
           if (n) atomicAdd(&a.g.stats[1], (unsigned long long)n);
+          // guard launches of one context are stream-ordered and this lane is the only writer: plain read-modify-write
+          const unsigned long long w = a.g.stats[2];
+          const unsigned long long nw = ((unsigned long long)((unsigned)(w >> 32) + (unsigned)a.frames) << 32) |
+                                        (unsigned long long)((unsigned)w + (unsigned)n);
+          a.g.stats[2] = nw;
+          if (a.g.host) __hip_atomic_store(a.g.host, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
     __syncthreads();
   }
   const int cnt = cnt_s;
-  if (cnt == 0) return;
+  if (cnt == 0 || a.g.count_only) return;
   unsigned *ticket = a.sync, *exited = a.sync + 1, *doneA = a.sync + 2, *doneB = a.sync + 2 + a.frames;
   const unsigned nA = (unsigned)cnt * (unsigned)a.tilesA, nBt = (unsigned)cnt * (unsigned)a.nB, nCt = (unsigned)cnt * (unsigned)a.nC;
   for (;;) {
@@ -868,7 +874,7 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     const size_t lds = std::max(std::max(a.lds_bytes + (size_t)a.dq.TC * 65 * 4, kProjLds), lds_beta);
     a.lds_total = lds;
     static const int grid_env = getenv("TSDR_GUARD_GRID") ? atoi(getenv("TSDR_GUARD_GRID")) : 0;  // (development: A/B of the grid size)
-    const unsigned grid = grid_env > 0 ? (unsigned)grid_env : (unsigned)ncu;
+    const unsigned grid = g.count_only ? 1u : grid_env > 0 ? (unsigned)grid_env : (unsigned)ncu;
     TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
   }
   return TSDR_OK;

@@ -20,7 +20,7 @@ export calculate_autocorrelation, zoom_autocorr
 export getSpectrum, getWelch, getWaterfall
 export SyncXY, vsync
 export hip_frames!           # fused GUI.jl:163-178 loop body (optional fast path)
-export hip_extract_configuration, sync_guard_stats   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
+export hip_extract_configuration, sync_guard_stats, sync_guard_auto   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
 
 const LIB = get(ENV, "TEMPEST_HIP_LIB", joinpath(@__DIR__, "..", "libtempest_hip.so"))
 const RENDERING_SIZE = (600, 800)   # GUI.jl:10
@@ -251,6 +251,13 @@ function sync_guard_stats(; reset = false)
     a = Ref{Culonglong}(0); b = Ref{Culonglong}(0); c = ctx()
     check(c, ccall((:tsdr_sync_guard_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Culonglong}, Ptr{Culonglong}, Cint), c.h, a, b, reset ? 1 : 0), "sync_guard_stats")
     return (Int(a[]), Int(b[]))
+end
+
+"(whole buffers currently run in the exact sequence?, calls that did, route changes): the sync guard's adaptive route"
+function sync_guard_auto()
+    e = Ref{Cint}(0); a = Ref{Culonglong}(0); b = Ref{Culonglong}(0); c = ctx()
+    check(c, ccall((:tsdr_sync_guard_auto, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Culonglong}, Ptr{Culonglong}), c.h, e, a, b), "sync_guard_auto")
+    return (e[] != 0, Int(a[]), Int(b[]))
 end
 
 # ---- streaming ingest: the staging ring (AtomicAbstractSDRs.jl:64-190 on pinned memory) ----------

@@ -265,6 +265,63 @@ def test_sync_guard_many_frames_in_chunks(ctx, tsdr, synth):
     print("sync guard (checked, re-evaluated):", r["guard"])
 
 
+def test_sync_guard_adaptive_route(ctx, tsdr, synth):
+    """At 1080p60 / 20 MS/s the plateau leak flags ~70 % of its frames: re-evaluating them one by one costs more than the
+    exact sequence for everything, so after a window of 60 frames the FAST loop runs whole buffers exactly (bit-identical to
+    TSDR_EXACT), keeps counting, and returns to the fast route once a leak with a defined sync answer (the box profile: < 1 %
+    flagged) has filled a window.  Indices equal TSDR_EXACT's on every buffer on either route; "sync_guard_auto" = 0 pins
+    the one-by-one route."""
+    w = synth.WORKLOADS["C2"]
+    Fs, x_t, y_t, fv, nfr = w["Fs"], w["x_t"], w["y_t"], w["fv"], 30
+    S = synth.samples_per_frame(Fs, fv)
+    tie = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 3, card="plateau")
+    box = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 3, card="box")
+
+    def run(iq, precision):
+        ctx.set_precision(precision)
+        try:
+            st = np.zeros((600, 800), np.float32, order="F")
+            r = ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), st)
+        finally:
+            ctx.set_precision("fast")
+        return r, st
+
+    e_tie, se_tie = run(tie, "exact")
+    e_box, _ = run(box, "exact")
+    ctx.set_option("sync_guard_ppb", 20000)  # (also restarts the adaptive route's window)
+    base = ctx.sync_guard_auto()
+    assert base[0] is False
+    ctx.sync_guard_stats(reset=True)
+    routes = []
+    for i in range(4):
+        g, sg = run(tie, "fast")
+        routes.append(ctx.sync_guard_auto()[1] - base[1])
+        assert np.array_equal(g["sync_idx"], e_tie["sync_idx"]), i
+        if routes[-1] > (routes[-2] if i else 0):  # this call ran as a whole exact buffer
+            for a, b in zip(g["frames"], e_tie["frames"]):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert np.array_equal(sg.view(np.uint32), se_tie.view(np.uint32))
+    checked, flagged = ctx.sync_guard_stats()
+    assert checked == 4 * nfr and flagged > 0.5 * checked, (checked, flagged)
+    assert routes == [0, 0, 1, 2], routes          # two fast buffers fill the window; the third and fourth run exactly
+    assert ctx.sync_guard_auto()[0] is True
+    for i in range(4):
+        g, _ = run(box, "fast")
+        assert np.array_equal(g["sync_idx"], e_box["sync_idx"]), i
+    now, n_exact, switches = ctx.sync_guard_auto()
+    assert now is False and n_exact - base[1] == 4 and switches - base[2] == 2, (now, n_exact, switches)
+    # pinned to the one-by-one route
+    ctx.set_option("sync_guard_auto", 0)
+    try:
+        for i in range(3):
+            g, _ = run(tie, "fast")
+            assert np.array_equal(g["sync_idx"], e_tie["sync_idx"])
+        assert ctx.sync_guard_auto()[:2] == (False, n_exact)
+    finally:
+        ctx.set_option("sync_guard_auto", 1)
+        ctx.set_option("sync_guard_ppb", 20000)
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_frames_fast_random_geometries(ctx, tsdr, seed):
     """Random raster sizes and sampling ratios (0.08 .. 1.6 samples per pixel), white-noise IQ -- the hardest input
