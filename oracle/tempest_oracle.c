@@ -778,6 +778,37 @@ static double blackman_w(size_t n, size_t N) {
   return 0.42 - 0.5 * cos(2.0 * M_PI * t) + 0.08 * cos(4.0 * M_PI * t);
 }
 
+/* pulsation[k+1] of `2*pi*(0:sizeFFT-1)/sizeFFT` (:88).  [RECALLED: Base ranges] `2*pi` is Float64(2pi); Float64 * UnitRange
+ * and StepRangeLen / Int stay StepRangeLen{Float64,TwicePrecision,TwicePrecision}, whose getindex forms k*step in ~106 bits
+ * and rounds once: to the accuracy that matters (2^-100) that is the correctly rounded quotient of the exact product
+ * Float64(2pi)*k by sizeFFT.  Formed here by long division in 128-bit integers: p = mant(2pi_d)*k, then 53 quotient bits,
+ * a guard bit and a sticky flag.  (An earlier version used x87 long double: right on almost every k, double-rounded on
+ * the rest.  The last bit decides round.(...) at :90 wherever sin or cos of the phase is 0.5 -/+ 1e-13.) */
+static double range_elem_2pi_k_over_n(unsigned long long k, unsigned long long n) {
+  if (k == 0) return 0.0;
+  const double two_pi = 6.283185307179586;            /* == 2*M_PI exactly */
+  int ex;
+  double fr = frexp(two_pi, &ex);                     /* two_pi = fr * 2^ex, fr in [0.5,1) */
+  unsigned long long mant = (unsigned long long)(fr * 9007199254740992.0); /* fr * 2^53: exact integer */
+  unsigned __int128 p = (unsigned __int128)mant * k;  /* exact */
+  /* normalise: shift p left until p >= n * 2^54, so that p/n has at least 55 bits (and at most 56 + a few) */
+  int sh = 0;
+  while ((p >> 54) < n && sh < 70) { p <<= 1; sh++; }
+  unsigned __int128 quo = p / n, rem = p % n;
+  /* keep 53 bits of quo */
+  int nb = 0;
+  for (unsigned __int128 t = quo; t; t >>= 1) nb++;
+  int cut = nb - 53;
+  unsigned long long keep = (unsigned long long)(quo >> cut);
+  unsigned __int128 tail = quo & ((((unsigned __int128)1) << cut) - 1);
+  unsigned __int128 mid = ((unsigned __int128)1) << (cut - 1);
+  int up = 0;
+  if (tail > mid) up = 1;
+  else if (tail == mid) up = (rem != 0) || (keep & 1ull);
+  keep += (unsigned long long)up;
+  return ldexp((double)keep, ex - 53 - sh + cut);
+}
+
 /* initLPF(T,sizeFFT,upCoeff) -> H (ComplexF64, interleaved). :83-99.
  * f32_stage!=0 mirrors T=Float32: H is stored ComplexF32 before the ifft. */
 int orc_init_lpf(size_t sizeFFT, int upCoeff, double *H /*2*sizeFFT*/, double *h_out /*optional*/) {
@@ -788,7 +819,7 @@ int orc_init_lpf(size_t sizeFFT, int upCoeff, double *H /*2*sizeFFT*/, double *h
   if (bound > sizeFFT) { free(X); return ORC_EBOUNDS; }
   double g = -((double)sizeFFT - 1.0) / 2.0;
   for (size_t k = 0; k < bound; k++) {
-    double om = (double)((long double)2.0 * (long double)M_PI * (long double)k / (long double)sizeFFT);
+    double om = range_elem_2pi_k_over_n((unsigned long long)k, (unsigned long long)sizeFFT);
     double th = g * om;
     /* round.(H .* exp(im*th)) : re and im rounded to integers (ties-to-even) */
     X[k].re = jl_round(cos(th));

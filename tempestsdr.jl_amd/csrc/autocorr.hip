@@ -377,9 +377,11 @@ static int amax_begin(tsdr_ctx *ctx, AmaxReq *r) {
     TSDR_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->amax_host_dev, ctx->amax_host, 0));
     ctx->amax_slot = 0;
   }
+  // (the two key slots change roles only when k_argmax runs -- argmax_launch: it is the kernel that clears the other one.  A
+  // findmax fused into an FFT pass uses `slots` and leaves both alone; toggling here as well handed the next k_argmax a slot
+  // that still held an older search's key)
   r->key = ctx->amax_keys + ctx->amax_slot;
   r->clear = ctx->amax_keys + (ctx->amax_slot ^ 1);
-  ctx->amax_slot ^= 1;
   r->arrived = reinterpret_cast<unsigned *>(ctx->amax_keys + 2);
   r->slots = ctx->amax_keys + 4;
   r->host = ctx->amax_host_dev;
@@ -412,6 +414,7 @@ static int amax_wait(tsdr_ctx *ctx, unsigned long long seq, size_t *idx, float *
 static int argmax_launch(tsdr_ctx *ctx, const float *v, size_t n, const AmaxReq &r) {
   const int ablocks = (int)std::min<size_t>(ceil_div(n, 2048), 256);
   TSDR_LAUNCH(ctx, "argmax", k_argmax, dim3(ablocks), dim3(256), 0, v, n, r.key, r.clear, r.arrived, r.host, r.seq);
+  ctx->amax_slot ^= 1;
   return TSDR_OK;
 }
 

@@ -566,6 +566,30 @@ int tsdr_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, 
 }
 
 // ---- init_resampler / initLPF (Resampler.jl:26-99) ------------------------------------------------
+// Element k of `2*pi*(0:sizeFFT-1)/sizeFFT` (Resampler.jl:88).  `2*pi` is the Float64 6.283185307179586; times a range and
+// divided by a number it stays a TwicePrecision range in Julia, whose element k is k*(2pi_d/N) carried in ~106 bits and rounded
+// once -- the correctly rounded value of the exact rational 2pi_d*k/N, formed here in integers.  The last bit matters:
+// round.(exp(im*theta)) (:90) has entries whose sine or cosine is 0.5 -/+ 1e-13 when 6 (or 3) divides sizeFFT, and an `om` one
+// ulp off (e.g. from the long-double pi instead of the Float64 one) moves theta by more than that and flips the entry.
+static double lpf_pulsation(size_t k, size_t N) {
+  if (k == 0) return 0.0;
+  int e2;
+  const unsigned long long m = (unsigned long long)ldexp(frexp(6.283185307179586, &e2), 53);  // 2pi_d = m * 2^(e2-53)
+  auto bits = [](unsigned __int128 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };
+  const unsigned __int128 num = (unsigned __int128)m * (unsigned __int128)k;
+  const int s = std::max(0, 3 + bits(N) - bits(k));          // quotient of (num << s) / N: 55..57 bits
+  const unsigned __int128 sh = num << s;
+  unsigned __int128 q = sh / N;
+  const bool sticky = (sh % N) != 0;
+  const int drop = bits(q) - 53;
+  if (drop > 0) {
+    const unsigned __int128 low = q & (((unsigned __int128)1 << drop) - 1), half = (unsigned __int128)1 << (drop - 1);
+    q >>= drop;
+    if (low > half || (low == half && (sticky || (q & 1)))) ++q;
+  }
+  return ldexp((double)(unsigned long long)q, e2 - 53 - s + std::max(drop, 0));
+}
+
 int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resampler **out) {
   if (!ctx || !out) return TSDR_EINVAL;
   *out = nullptr;
@@ -590,7 +614,7 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
   const size_t bound = bound_d < (double)N ? (size_t)bound_d : N;
   const double g = -((double)N - 1.0) / 2.0;
   for (size_t k = 0; k < bound; ++k) {
-    const double om = (double)(2.0L * M_PIl * (long double)k / (long double)N);
+    const double om = lpf_pulsation(k, N);
     const double th = g * om;
     H0[k] = make_double2(nearbyint(cos(th)), nearbyint(sin(th)));
   }

@@ -181,6 +181,23 @@ def test_autocorr_fused_middle_and_fused_findmax(ctx, n, Fs):
     assert np.max(np.abs(res[0] - res[1])) < 2e-4
 
 
+def test_findmax_routes_interleaved_on_one_context(ctx):
+    """Searches whose findmax is an FFT-pass epilogue (n = 2 * 2^a3^b5^c) and searches that run the separate argmax kernel
+    (every other n), alternating on one context with the LARGER maxima first: the argmax kernel's two key slots change roles
+    only when it runs (a stale key from an earlier search used to win the later one's atomicMax)."""
+    Fs = 1e6
+    def case(n, amp):
+        z = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * amp).astype(np.complex64)
+        z *= (1.0 + 0.5 * np.cos(2 * np.pi * np.arange(n) / 977.0)).astype(np.float32)
+        return z
+    order = [(100_003, 3e-1), (200_000, 3e-2), (100_003, 3e-3), (131_072, 3e-1), (180_000, 3e-2), (99_999, 3e-4), (65_536, 3e-4)]
+    for n, amp in order:
+        z = case(n, amp)
+        G, pos, val = ctx.autocorr_search(z, Fs, 0, (n // 2) / Fs, rate_min=Fs / 3000, rate_max=Fs / 300)
+        win = G[300 - 1: min(3000, G.size)]
+        assert pos == int(np.argmax(win)) and val == win[pos], (n, amp, pos, int(np.argmax(win)), val, float(win.max()))
+
+
 def test_autocorr_bounds_error(ctx):
     x = np.ones(100, np.float32)
     with pytest.raises(IndexError):  # BoundsError at Autocorrelations.jl:33
@@ -309,7 +326,10 @@ def test_fft64(ctx, n):
 # it lies, one pointwise kernel, inverse transform of sizeFFT/2 points straight into `out`); (999, 3) / (625, 3): odd
 # bufferSize -> full-size transforms with fused loaders / Bluestein; (64, 2): one pass; sizeFFT = 4096: one workgroup
 @pytest.mark.parametrize("bufferSize,up", [(1000, 4), (1024, 2), (999, 3), (64, 2), (4096, 8), (100000, 5), (625, 3), (1024, 4), (512, 8),
-                                           (2048, 2), (10, 1), (4, 2), (250000, 4), (3000, 7)])  # (sizes whose round.() hits an exact tie, e.g. sizeFFT = 6, depend on libm's last bit)
+                                           (2048, 2), (10, 1), (4, 2), (250000, 4), (3000, 7),
+                                           # sizeFFT divisible by 6: round.(exp(im*theta)) has an entry 0.5 -/+ 1e-13 away from a tie, decided by the
+                                           # last bit of the range element 2pi*k/sizeFFT (the library once formed it with the long-double pi: 0.9 % off)
+                                           (6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2)])
 def test_init_resampler(ctx, bufferSize, up):
     r, o = ctx.init_resampler(np.float32, bufferSize, up), O.Resampler(bufferSize, up)
     # H is ComplexF64 on both sides (Resampler.jl:93-97): the device builds it with its own f64 transforms

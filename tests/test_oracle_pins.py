@@ -269,16 +269,26 @@ def test_frames_equals_composition():
 
 
 # ------------------------------------------------------------------ init_resampler / initLPF
-def test_init_lpf_properties():
+@pytest.mark.parametrize("n,up", [(500, 4), (6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2)])
+def test_init_lpf_properties(n, up):
+    """(6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2): sizeFFT divisible by 6 (or 3 with upCoeff 1) -- round.(exp(im*theta))
+    (Resampler.jl:90) then has an entry whose sine or cosine is 0.5 -/+ 1e-13, decided by the last bit of the TwicePrecision
+    range element 2pi*k/sizeFFT; the restatement below forms that element as the correctly rounded exact rational."""
+    from fractions import Fraction
+    import math
     scipy_signal = pytest.importorskip("scipy.signal")
-    n, up = 500, 4
     r = O.Resampler(n, up)
     H = r.lpf()
     N = n * up
     # restate Resampler.jl:83-99 in numpy (f64) and compare
     H0 = np.zeros(N, complex)
     bound = int(np.round(N / up / 2))
-    th = -(N - 1) / 2 * 2 * np.pi * np.arange(N) / N
+    two_pi = Fraction(2 * math.pi)
+    om = np.array([float(two_pi * k / N) for k in range(N)])   # Fraction -> float rounds correctly
+    th = -(N - 1) / 2 * om
+    near = np.minimum(np.abs(np.abs(np.cos(th[:bound])) - 0.5), np.abs(np.abs(np.sin(th[:bound])) - 0.5))
+    if N % 6 == 0 and up <= 2:
+        assert near.min() < 1e-11     # the case this size is here for
     H0[:bound] = np.round(np.cos(th[:bound])) + 1j * np.round(np.sin(th[:bound]))
     h = np.fft.ifft(H0) * scipy_signal.windows.blackman(N, sym=True)
     ref = np.fft.fft(h) * (-1.0) ** np.arange(N)

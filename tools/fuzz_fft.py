@@ -38,3 +38,49 @@ for mixed in (0, 1):
         e = relmax(g, o); worst = max(worst, e)
         assert g.shape == o.shape and e < 4e-5, (n, mixed, e)
 print("autocorr: 24 cases ok, worst", worst)
+
+# the fused search (lags + zoom window + findmax in one call) on random lengths / windows, real and IQ input
+ctx.set_option("ac_mixed", 1)
+worst = 0.0
+for it in range(16):
+    n = 2 * smooth(2_500_000) if it % 4 else int(rng.integers(20_000, 600_000))
+    if n < 20_000: n = 2 * 3 ** 9
+    Fs = float(rng.choice([1e6, 2e6, 20e6]))
+    cplx = bool(it % 2)
+    t = np.arange(n)
+    per = int(rng.integers(n // 12, n // 5))          # a periodic component so that the window holds a real peak
+    base = (0.2 + (t % per < per // 7)).astype(np.float32)
+    if cplx:
+        x = (base * np.exp(2j * np.pi * rng.random(n))).astype(np.complex64) * 1e-2
+        pw = (x.real.astype(np.float32) ** 2 + x.imag.astype(np.float32) ** 2)
+    else:
+        x = (base * (1 + 0.05 * rng.random(n))).astype(np.float32) * 1e-2
+        pw = x
+    maxd = (n // 2) / Fs
+    rmin, rmax = float(rng.uniform(20, 60)), float(rng.uniform(70, 140))
+    G, pos, val = ctx.autocorr_search(x, Fs, 0.0, maxd, rmin, rmax, "log")
+    o, _ = O.calculate_autocorrelation(pw if not cplx else ctx.abs2(x), Fs, 0.0, maxd, "log")
+    assert G.shape == o.shape
+    e = float(np.max(np.abs(G - o))); worst = max(worst, e)
+    assert e < 5e-4, ("search dB", n, cplx, e)
+    _, zw = ctx.zoom_autocorr(G, Fs, rmin, rmax)
+    if zw.size:
+        want = int(np.argmax(zw))                     # first maximum, like findmax
+        assert pos == want and val == zw[want], ("search findmax", n, cplx, pos, want, val, float(zw[want]))
+print("search: 16 cases ok, worst |dB| diff", worst)
+
+# resampler!: random (bufferSize, upCoeff) incl. odd sizes (full-size route), 4096-point fast path, large primes
+worst = 0.0
+for it in range(14):
+    up = int(rng.choice([1, 2, 3, 4, 5, 8]))
+    nb = [int(rng.integers(4, 3000)), 4096 // up if 4096 % up == 0 else 1024, 2 * smooth(300_000), smooth(200_000) | 1,
+          int(rng.integers(3000, 120_000))][it % 5]
+    nb = max(nb, 4)
+    r, ro = T.Resampler(ctx, nb, up), O.Resampler(nb, up)
+    x = rng.standard_normal(nb).astype(np.float32)
+    a, b = np.zeros(nb * up, np.float32), np.zeros(nb * up, np.float32)
+    r(a, x); ro(b, x)
+    e = float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)); worst = max(worst, e)
+    assert e < 8e-6, ("resampler", nb, up, e)
+    r.close()
+print("resampler: 14 cases ok, worst", worst)
