@@ -33,8 +33,11 @@ for mixed in (0, 1):
         n = 2 * smooth(1_000_000) if it % 2 else int(rng.integers(1500, 500_000))
         x = (rng.random(n) ** 2).astype(np.float32) * 1e-5
         Fs = 1e6; maxd = (n // 2) / Fs
-        g, _ = ctx.calculate_autocorrelation(x, Fs, 0.0, maxd, "lin")
-        o, _ = O.calculate_autocorrelation(x, Fs, 0.0, maxd, "lin")
+        mind = 0.0 if it % 3 == 0 else float(rng.integers(0, max(n // 6, 1))) / Fs      # indexMin > 1: the lag vector starts later
+        if it % 4 == 1:   # a signal longer than 2*indexMax: only its first 2*indexMax samples are used (:27)
+            x = np.concatenate([x, (rng.random(int(rng.integers(1, 5000))) ** 2).astype(np.float32)])
+        g, _ = ctx.calculate_autocorrelation(x, Fs, mind, maxd, "lin")
+        o, _ = O.calculate_autocorrelation(x, Fs, mind, maxd, "lin")
         e = relmax(g, o); worst = max(worst, e)
         assert g.shape == o.shape and e < 4e-5, (n, mixed, e)
 print("autocorr: 24 cases ok, worst", worst)
@@ -58,8 +61,9 @@ for it in range(16):
         pw = x
     maxd = (n // 2) / Fs
     rmin, rmax = float(rng.uniform(20, 60)), float(rng.uniform(70, 140))
-    G, pos, val = ctx.autocorr_search(x, Fs, 0.0, maxd, rmin, rmax, "log")
-    o, _ = O.calculate_autocorrelation(pw if not cplx else ctx.abs2(x), Fs, 0.0, maxd, "log")
+    mind = 0.0 if it % 3 else float(rng.integers(1, 50)) / Fs
+    G, pos, val = ctx.autocorr_search(x, Fs, mind, maxd, rmin, rmax, "log")
+    o, _ = O.calculate_autocorrelation(pw if not cplx else ctx.abs2(x), Fs, mind, maxd, "log")
     assert G.shape == o.shape
     e = float(np.max(np.abs(G - o))); worst = max(worst, e)
     assert e < 5e-4, ("search dB", n, cplx, e)
