@@ -778,36 +778,46 @@ static double blackman_w(size_t n, size_t N) {
   return 0.42 - 0.5 * cos(2.0 * M_PI * t) + 0.08 * cos(4.0 * M_PI * t);
 }
 
-/* pulsation[k+1] of `2*pi*(0:sizeFFT-1)/sizeFFT` (:88).  [RECALLED: Base ranges] `2*pi` is Float64(2pi); Float64 * UnitRange
- * and StepRangeLen / Int stay StepRangeLen{Float64,TwicePrecision,TwicePrecision}, whose getindex forms k*step in ~106 bits
- * and rounds once: to the accuracy that matters (2^-100) that is the correctly rounded quotient of the exact product
- * Float64(2pi)*k by sizeFFT.  Formed here by long division in 128-bit integers: p = mant(2pi_d)*k, then 53 quotient bits,
- * a guard bit and a sticky flag.  (An earlier version used x87 long double: right on almost every k, double-rounded on
- * the rest.  The last bit decides round.(...) at :90 wherever sin or cos of the phase is 0.5 -/+ 1e-13.) */
-static double range_elem_2pi_k_over_n(unsigned long long k, unsigned long long n) {
-  if (k == 0) return 0.0;
-  const double two_pi = 6.283185307179586;            /* == 2*M_PI exactly */
-  int ex;
-  double fr = frexp(two_pi, &ex);                     /* two_pi = fr * 2^ex, fr in [0.5,1) */
-  unsigned long long mant = (unsigned long long)(fr * 9007199254740992.0); /* fr * 2^53: exact integer */
-  unsigned __int128 p = (unsigned __int128)mant * k;  /* exact */
-  /* normalise: shift p left until p >= n * 2^54, so that p/n has at least 55 bits (and at most 56 + a few) */
-  int sh = 0;
-  while ((p >> 54) < n && sh < 70) { p <<= 1; sh++; }
-  unsigned __int128 quo = p / n, rem = p % n;
-  /* keep 53 bits of quo */
-  int nb = 0;
-  for (unsigned __int128 t = quo; t; t >>= 1) nb++;
-  int cut = nb - 53;
-  unsigned long long keep = (unsigned long long)(quo >> cut);
-  unsigned __int128 tail = quo & ((((unsigned __int128)1) << cut) - 1);
-  unsigned __int128 mid = ((unsigned __int128)1) << (cut - 1);
-  int up = 0;
-  if (tail > mid) up = 1;
-  else if (tail == mid) up = (rem != 0) || (keep & 1ull);
-  keep += (unsigned long long)up;
-  return ldexp((double)keep, ex - 53 - sh + cut);
+/* The phase of Resampler.jl:88-90, theta[k] = imag((1im*groupDelay * pulsation)[k+1]).               [RECALLED: Base ranges]
+ * `pulsation = 2*pi*(0:sizeFFT-1)/sizeFFT` is not a vector: Float64 * UnitRange gives a StepRangeLen{Float64,TwicePrecision,
+ * TwicePrecision} (range_start_step_length: ref = 0, step = (2pi_d, 0); rat() finds no small rational for 2pi), `/ sizeFFT`
+ * divides the step in twice precision and truncates its hi word by nb = ceil(log2(sizeFFT-1)) bits (twiceprecision.jl: `/`
+ * on a TwicePrecision range), and the COMPLEX scalar 1im*groupDelay = (-0.0, g) times that range takes broadcast.jl's
+ * StepRangeLen{T} method: StepRangeLen{ComplexF64}(x*r.ref, x*r.step, len, offset), whose step is the TwicePrecision product
+ * (mul12 has no low word for complex operands; canonicalize2 of g*hi + g*lo).  getindex then returns
+ *     theta[k] = fl( fl(k*hi') + fl(k*lo') ),   hi' = fl(g*hi_t + fl(g*lo_t)),  lo' = (g*hi_t - hi') + fl(g*lo_t)
+ * -- not fl(g * fl(2pi*k/N)).  The two agree to an ulp, which is all that matters except where 6 divides sizeFFT (3 when
+ * upCoeff = 1): there one or two entries of round.(exp(im*theta)) have a sine or cosine 0.5 -/+ 1e-13, the ulp decides, and
+ * the filter changes by ~1 %.  Those sizes are therefore pinned only as far as this recollection of Base is right;
+ * tests/golden/make_golden.jl dumps two such filters (up6_H, up3_H) to settle it on a machine with Julia.  The reference's
+ * own use (production/test_resampler.jl: 1024 x 4) and every power-of-two size has no such entry. */
+typedef struct { double hi, lo; } orc_tp;
+static orc_tp tp_canon(double big, double little) { orc_tp r; r.hi = big + little; r.lo = (big - r.hi) + little; return r; }
+static double tp_truncbits(double x, int nb) {
+  unsigned long long b;
+  memcpy(&b, &x, 8);
+  b &= ~((1ull << nb) - 1ull);
+  memcpy(&x, &b, 8);
+  return x;
 }
+/* step of (1im*g) * (2pi*(0:N-1)/N), imaginary part */
+static orc_tp lpf_phase_step(size_t N) {
+  const double two_pi = 6.283185307179586, y = (double)N, g = -((double)N - 1.0) / 2.0;
+  /* TwicePrecision(2pi_d, 0) / N */
+  double hi = two_pi / y;
+  double uh = hi * y, ul = fma(hi, y, -uh);           /* mul12 */
+  double lo = ((((two_pi - uh) - ul) + 0.0) - hi * 0.0) / y;
+  orc_tp q = tp_canon(hi, lo);
+  /* twiceprecision(q, nbitslen(len, offset = 1)) */
+  int nb = 0;
+  if (N >= 2) { nb = (int)ceil(log2((double)(N - 1))); if (nb > 27) nb = 27; }
+  double hi_t = tp_truncbits(q.hi, nb), lo_t = (q.hi - hi_t) + q.lo;
+  /* (hi_t, lo_t) * (g, 0) as complex TwicePrecision numbers: imaginary parts */
+  double zh = hi_t * g + (-0.0);                       /* real(z)*imag(w) + imag(z)*real(w) */
+  double cross = (hi_t * 0.0 + 0.0 * g) + (lo_t * g + (-0.0)); /* x.hi*y.lo + x.lo*y.hi */
+  return tp_canon(zh, cross + 0.0);
+}
+static double lpf_phase(size_t k, orc_tp st) { double a = (double)k * st.hi, b = (double)k * st.lo; return a + b; }
 
 /* initLPF(T,sizeFFT,upCoeff) -> H (ComplexF64, interleaved). :83-99.
  * f32_stage!=0 mirrors T=Float32: H is stored ComplexF32 before the ifft. */
@@ -817,10 +827,9 @@ int orc_init_lpf(size_t sizeFFT, int upCoeff, double *H /*2*sizeFFT*/, double *h
   if (!X) return ORC_ENOMEM;
   size_t bound = (size_t)jl_round((double)sizeFFT / (double)upCoeff / 2.0);
   if (bound > sizeFFT) { free(X); return ORC_EBOUNDS; }
-  double g = -((double)sizeFFT - 1.0) / 2.0;
+  orc_tp st = lpf_phase_step(sizeFFT);
   for (size_t k = 0; k < bound; k++) {
-    double om = range_elem_2pi_k_over_n((unsigned long long)k, (unsigned long long)sizeFFT);
-    double th = g * om;
+    double th = lpf_phase(k, st);
     /* round.(H .* exp(im*th)) : re and im rounded to integers (ties-to-even) */
     X[k].re = jl_round(cos(th));
     X[k].im = jl_round(sin(th));

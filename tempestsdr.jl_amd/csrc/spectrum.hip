@@ -3,6 +3,7 @@
 // All transforms go through the hand-written FFT engine (fft.hip).
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "fft_dev.h"
 
@@ -566,28 +567,34 @@ int tsdr_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, 
 }
 
 // ---- init_resampler / initLPF (Resampler.jl:26-99) ------------------------------------------------
-// Element k of `2*pi*(0:sizeFFT-1)/sizeFFT` (Resampler.jl:88).  `2*pi` is the Float64 6.283185307179586; times a range and
-// divided by a number it stays a TwicePrecision range in Julia, whose element k is k*(2pi_d/N) carried in ~106 bits and rounded
-// once -- the correctly rounded value of the exact rational 2pi_d*k/N, formed here in integers.  The last bit matters:
-// round.(exp(im*theta)) (:90) has entries whose sine or cosine is 0.5 -/+ 1e-13 when 6 (or 3) divides sizeFFT, and an `om` one
-// ulp off (e.g. from the long-double pi instead of the Float64 one) moves theta by more than that and flips the entry.
-static double lpf_pulsation(size_t k, size_t N) {
-  if (k == 0) return 0.0;
-  int e2;
-  const unsigned long long m = (unsigned long long)ldexp(frexp(6.283185307179586, &e2), 53);  // 2pi_d = m * 2^(e2-53)
-  auto bits = [](unsigned __int128 v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };
-  const unsigned __int128 num = (unsigned __int128)m * (unsigned __int128)k;
-  const int s = std::max(0, 3 + bits(N) - bits(k));          // quotient of (num << s) / N: 55..57 bits
-  const unsigned __int128 sh = num << s;
-  unsigned __int128 q = sh / N;
-  const bool sticky = (sh % N) != 0;
-  const int drop = bits(q) - 53;
-  if (drop > 0) {
-    const unsigned __int128 low = q & (((unsigned __int128)1 << drop) - 1), half = (unsigned __int128)1 << (drop - 1);
-    q >>= drop;
-    if (low > half || (low == half && (sticky || (q & 1)))) ++q;
-  }
-  return ldexp((double)(unsigned long long)q, e2 - 53 - s + std::max(drop, 0));
+// The phase theta[k] of Resampler.jl:88-90 as Julia evaluates it.  `2*pi*(0:sizeFFT-1)/sizeFFT` is a TwicePrecision range (ref 0,
+// step (2pi_d, 0) divided by sizeFFT in twice precision, hi word truncated by ceil(log2(sizeFFT-1)) bits), and the complex
+// scalar 1im*groupDelay times it is again a range -- StepRangeLen{ComplexF64} with the TwicePrecision product as its step
+// (broadcast.jl's StepRangeLen{T} method; no low word from the complex mul12) -- so element k is
+//   fl( fl(k*hi2) + fl(k*lo2) ),  hi2 = fl(g*hi_t + fl(g*lo_t)),  lo2 = (g*hi_t - hi2) + fl(g*lo_t),
+// an ulp away from fl(g*fl(2pi*k/N)) on a quarter of the k.  The ulp matters where 6 divides sizeFFT (3 when upCoeff = 1):
+// round.(exp(im*theta)) (:90) then has entries whose sine or cosine is 0.5 -/+ 1e-13.  (A first version used the long-double
+// pi here: 0.9 % off the oracle on such sizes.)  Needs -ffp-contract=off (build.py) like everything on this path.
+struct LpfPhase { double hi, lo; };
+static LpfPhase lpf_phase_step(size_t N) {
+  auto canon = [](double big, double little) { LpfPhase r; r.hi = big + little; r.lo = (big - r.hi) + little; return r; };
+  const double two_pi = 6.283185307179586, y = (double)N, g = -((double)N - 1.0) / 2.0;
+  const double q = two_pi / y;
+  const double uh = q * y, ul = std::fma(q, y, -uh);
+  const LpfPhase d = canon(q, (((two_pi - uh) - ul) + 0.0) / y);
+  int nb = 0;
+  if (N >= 2) nb = std::min(27, (int)std::ceil(std::log2((double)(N - 1))));
+  unsigned long long bits;
+  std::memcpy(&bits, &d.hi, 8);
+  bits &= ~((1ull << nb) - 1ull);
+  double hi_t;
+  std::memcpy(&hi_t, &bits, 8);
+  const double lo_t = (d.hi - hi_t) + d.lo;
+  return canon(hi_t * g, lo_t * g);
+}
+static inline double lpf_phase(size_t k, const LpfPhase &st) {
+  const double a = (double)k * st.hi, b = (double)k * st.lo;
+  return a + b;
 }
 
 int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resampler **out) {
@@ -612,10 +619,9 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
   std::vector<double2> H0(N, make_double2(0.0, 0.0));
   const double bound_d = nearbyint((double)N / (double)upCoeff / 2.0);
   const size_t bound = bound_d < (double)N ? (size_t)bound_d : N;
-  const double g = -((double)N - 1.0) / 2.0;
+  const LpfPhase st = lpf_phase_step(N);
   for (size_t k = 0; k < bound; ++k) {
-    const double om = lpf_pulsation(k, N);
-    const double th = g * om;
+    const double th = lpf_phase(k, st);
     H0[k] = make_double2(nearbyint(cos(th)), nearbyint(sin(th)));
   }
   hipError_t e = hipMemcpyAsync(r->H, H0.data(), N * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);

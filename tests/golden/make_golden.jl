@@ -146,6 +146,13 @@ function main()
     H, _ = Resampler.initLPF(Float32, 500, 4)
     save("up_H_re", Float64.(real.(H)))
     save("up_H_im", Float64.(imag.(H)))
+    # sizeFFT divisible by 6 (by 3 with upCoeff = 1): round.(H .* exp.(1im*groupDelay*pulsation)) has an entry whose sine or
+    # cosine sits 1e-13 from a tie, so these two filters pin how Base evaluates that phase (range arithmetic) to the last bit
+    for (tag, L, u) in (("up6", 2436, 2), ("up3", 2691, 1))
+        Hn, _ = Resampler.initLPF(Float32, L, u)
+        save("$(tag)_H_re", Float64.(real.(Hn)))
+        save("$(tag)_H_im", Float64.(imag.(Hn)))
+    end
     # ---- FrameSynchronisation.jl
     β = zeros(Float32, 23, 101)
     FrameSynchronisation.fill_β!(β, inp["beta_cv"], FrameSynchronisation.Sync(3, 25, 101))

@@ -66,6 +66,10 @@ def sub(a, step):
     return np.ascontiguousarray(np.asarray(a).ravel(order="F")[::step])
 
 
+# initLPF sizes (bufferSize, upCoeff) whose round.(exp(im*theta)) has an entry 1e-13 from a tie (sizeFFT = 2436, 2691)
+NEAR_TIE_LPF = (("up6", 1218, 2), ("up3", 2691, 1))
+
+
 def outputs(B, inp, sync_cls, frames_fn, vsync_debug=None):
     """Everything make_golden.jl writes, from backend B (oracle_lib, or the HIP api Context)."""
     o = {}
@@ -128,6 +132,9 @@ def oracle_outputs(inp):
     r(out, inp["up_in"])
     H = r.lpf()
     o["up_out"], o["up_H_re"], o["up_H_im"] = out, np.ascontiguousarray(H.real), np.ascontiguousarray(H.imag)
+    for tag, nb, up in NEAR_TIE_LPF:
+        Hn = O.Resampler(nb, up).lpf()
+        o[f"{tag}_H_re"], o[f"{tag}_H_im"] = np.ascontiguousarray(Hn.real), np.ascontiguousarray(Hn.imag)
     o["naive"] = O.naiveResampler(inp["up_in"], 3)
     return o
 

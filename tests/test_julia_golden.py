@@ -36,7 +36,7 @@ POLICY = [
     ("ac_db", ("abs", 2e-4)), ("zoom_G", ("abs", 2e-4)), ("ac_lin", ("relmax", 4e-5)),
     ("zoom_rates", ("relmax", 1e-15)),
     ("sp_db", ("abs", 2e-3)), ("spz_db", ("abs", 2e-3)), ("welch_db", ("abs", 1e-3)), ("wf", ("sqrtrel", 2e-5)),
-    ("up_out", ("relmax", 1e-5)), ("up_H", ("relmax", 2e-5)),
+    ("up_out", ("relmax", 1e-5)), ("up_H", ("relmax", 2e-5)), ("up6_H", ("relmax", 2e-5)), ("up3_H", ("relmax", 2e-5)),
     ("_idx", ("eq", 0)), ("_chk", ("eq", 0)),
 ]
 # against Julia only: downstream of an @simd reduction (column sums, Sigma = sum(c_v))
@@ -81,8 +81,9 @@ def compare(cand, ref, vs_julia, only=None):
                 a64, b64 = np.sqrt(a64), np.sqrt(b64)
             d = float(np.max(np.abs(a64 - b64))) if a64.size else 0.0
             scale = float(np.max(np.abs(b64)))
-            if k.startswith("up_H"):  # real and imaginary part of one complex vector: relative to its largest magnitude
-                scale = float(np.max(np.hypot(np.asarray(ref["up_H_re"], np.float64), np.asarray(ref["up_H_im"], np.float64))))
+            if k.endswith(("_H_re", "_H_im")):  # real and imaginary part of one complex vector: relative to its largest magnitude
+                stem = k[:-3]
+                scale = float(np.max(np.hypot(np.asarray(ref[stem + "_re"], np.float64), np.asarray(ref[stem + "_im"], np.float64))))
             lim = tol if kind == "abs" else tol * scale
             ok, err = d <= lim, d
             if vs_julia and ok and any(k.startswith(p) for p, _ in OPEN_VS_JULIA) and d == 0.0:
@@ -109,6 +110,9 @@ def hip_outputs(ctx, tsdr, inp):
     r(out, inp["up_in"])
     H = r.lpf()
     o["up_out"], o["up_H_re"], o["up_H_im"] = out, H.real.astype(np.float64), H.imag.astype(np.float64)
+    for tag, nb, up in V2.NEAR_TIE_LPF:
+        Hn = ctx.init_resampler(np.float32, nb, up).lpf64()
+        o[f"{tag}_H_re"], o[f"{tag}_H_im"] = np.ascontiguousarray(Hn.real), np.ascontiguousarray(Hn.imag)
     nv = np.empty(375, np.float32)
     ctx.naiveResampler(nv, inp["up_in"], 3)
     o["naive"] = nv

@@ -269,13 +269,38 @@ def test_frames_equals_composition():
 
 
 # ------------------------------------------------------------------ init_resampler / initLPF
-@pytest.mark.parametrize("n,up", [(500, 4), (6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2)])
-def test_init_lpf_properties(n, up):
-    """(6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2): sizeFFT divisible by 6 (or 3 with upCoeff 1) -- round.(exp(im*theta))
-    (Resampler.jl:90) then has an entry whose sine or cosine is 0.5 -/+ 1e-13, decided by the last bit of the TwicePrecision
-    range element 2pi*k/sizeFFT; the restatement below forms that element as the correctly rounded exact rational."""
-    from fractions import Fraction
+def _julia_lpf_phase(N):
+    """theta[k] of Resampler.jl:88-90 as Base's range arithmetic evaluates it (see lpf_phase_step in the oracle), restated
+    independently: error-free products through Fractions instead of fma."""
     import math
+    import struct
+    from fractions import Fraction
+
+    def truncbits(x, nb):
+        b = struct.unpack("<Q", struct.pack("<d", x))[0] & ~((1 << nb) - 1)
+        return struct.unpack("<d", struct.pack("<Q", b))[0]
+
+    def canon(big, little):
+        h = big + little
+        return h, (big - h) + little
+
+    two_pi, y, g = 2 * math.pi, float(N), -(N - 1) / 2.0
+    hi = two_pi / y
+    uh = hi * y
+    ul = float(Fraction(hi) * Fraction(y) - Fraction(uh))          # mul12's low word
+    hi, lo = canon(hi, (((two_pi - uh) - ul) + 0.0) / y)
+    nb = 0 if N < 2 else min(27, math.ceil(math.log2(N - 1)))
+    hi_t = truncbits(hi, nb)
+    lo_t = (hi - hi_t) + lo
+    hi2, lo2 = canon(hi_t * g, lo_t * g)
+    return np.array([k * hi2 + k * lo2 for k in range(N)])
+
+
+@pytest.mark.parametrize("n,up", [(500, 4), (6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2), (18, 1), (24, 2), (1023, 1)])
+def test_init_lpf_properties(n, up):
+    """(6, 1), (1218, 2), (2691, 1), (6561, 2), (3000, 2), ...: sizeFFT divisible by 6 (or 3 with upCoeff 1) --
+    round.(exp(im*theta)) (Resampler.jl:90) then has an entry whose sine or cosine is 0.5 -/+ 1e-13, decided by the last bit of
+    theta, i.e. by Base's TwicePrecision range arithmetic ([RECALLED], restated in _julia_lpf_phase and in the oracle)."""
     scipy_signal = pytest.importorskip("scipy.signal")
     r = O.Resampler(n, up)
     H = r.lpf()
@@ -283,11 +308,9 @@ def test_init_lpf_properties(n, up):
     # restate Resampler.jl:83-99 in numpy (f64) and compare
     H0 = np.zeros(N, complex)
     bound = int(np.round(N / up / 2))
-    two_pi = Fraction(2 * math.pi)
-    om = np.array([float(two_pi * k / N) for k in range(N)])   # Fraction -> float rounds correctly
-    th = -(N - 1) / 2 * om
+    th = _julia_lpf_phase(N)
     near = np.minimum(np.abs(np.abs(np.cos(th[:bound])) - 0.5), np.abs(np.abs(np.sin(th[:bound])) - 0.5))
-    if N % 6 == 0 and up <= 2:
+    if N % 6 == 0 and up <= 2 and N > 6:
         assert near.min() < 1e-11     # the case this size is here for
     H0[:bound] = np.round(np.cos(th[:bound])) + 1j * np.round(np.sin(th[:bound]))
     h = np.fft.ifft(H0) * scipy_signal.windows.blackman(N, sym=True)
