@@ -873,8 +873,7 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     a.lds_bytes = (a.lds_bytes + 15) & ~(size_t)15;
     const size_t lds = std::max(std::max(a.lds_bytes + (size_t)a.dq.TC * 65 * 4, kProjLds), lds_beta);
     a.lds_total = lds;
-    static const int grid_env = getenv("TSDR_GUARD_GRID") ? atoi(getenv("TSDR_GUARD_GRID")) : 0;  // (development: A/B of the grid size)
-    const unsigned grid = g.count_only ? 1u : grid_env > 0 ? (unsigned)grid_env : (unsigned)ncu;
+    const unsigned grid = g.count_only ? 1u : (unsigned)ncu;   // (one workgroup per CU: 64 / 128 / 512 measured no better)
     TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
   }
   return TSDR_OK;

@@ -275,8 +275,20 @@ def bench_search(ctx, iq, n, n_lags, Fs, steps, world, rank, dev):
                       f"would not be smaller than the single-GPU one ({single_route_points(n, n_lags)} points), so no collective is used")),
             "includes": "abs2, FFT autocorrelation, 10log10(abs2), zoom argmax with host readback (tsdr_autocorr_search_d: "
                         "one call; the last forward pass, the power spectrum and the first inverse pass are one launch, the "
-                        "findmax an epilogue of the last pass + a one-wavefront publish launch; 2e6-point transforms run as "
-                        "1000 | 2000 in three-step kernels: 3 launches + publish)"}
+                        "findmax an epilogue of the last pass + a one-wavefront publish launch; "
+                        + _passes_note(ctx, single_route_points(n, n_lags)) + ")"}
+
+
+def _passes_note(ctx, points):
+    """how the FFT engine splits a transform of `points` complex points (tsdr_fft_plan: host arithmetic)"""
+    import ctypes as C
+    f = (C.c_uint * 8)()
+    p = ctx.lib.tsdr_fft_plan(int(points), f, 8)
+    if p <= 0:
+        return f"{points}-point transforms: power-of-two / Bluestein route"
+    fac = " | ".join(str(f[i]) for i in range(p))
+    kind = "three-step kernels (factors up to 2000, 8000-point tiles)" if max(f[:p]) > 256 else "two-step kernels"
+    return f"{points}-point transforms run as {fac} in the {kind}: {2 * p - 1} FFT launches + publish"
 
 
 # ---------------------------------------------------------------------------------------------
