@@ -93,6 +93,10 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 first inverse pass run as one launch; 0: two separate transforms.
  *   "sync_guard_ppb"  sync-guard threshold of the TSDR_FAST frame loop in parts per billion (default 20000 = 2e-5;
  *                 0 switches the guard off: indices may then differ from the reference's where beta is tied at 1e-7).
+ *   "vsync_current_sy" 0 (default): tsdr_vsync and the frame loop reproduce the reference's ordering -- s_y is read from beta_y
+ *                 BEFORE this call refills it (FrameSynchronisation.jl:66), so it is the previous image's; 1: s_y of the
+ *                 current image (what the code presumably meant; NOT what TempestSDR.jl does).  Takes effect from the
+ *                 next call; the pending value is kept up to date in either mode.
  *   "sync_guard_auto" 1 (default): the adaptive whole-buffer TSDR_EXACT route described above; 0: flagged frames are always
  *                 re-evaluated one by one.
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO preset them, read

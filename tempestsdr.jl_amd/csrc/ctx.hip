@@ -186,6 +186,11 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "ac_mixed")) ctx->opt_ac_mixed = value != 0;
   else if (!strcmp(name, "fft_no_mix2")) ctx->opt_fft_no_mix2 = value != 0;
   else if (!strcmp(name, "ac_fuse_mid")) ctx->opt_ac_fuse_mid = value != 0;
+  else if (!strcmp(name, "vsync_current_sy")) {
+    int rc = tsdr::pipe_drain(ctx);   // a deferred shift + IIR stage was submitted under the old setting
+    if (rc) return rc;
+    ctx->opt_vsync_current_sy = value != 0;
+  }
   else if (!strcmp(name, "fft_big")) ctx->opt_fft_big = value != 0;
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");

@@ -495,6 +495,7 @@ struct IirArgs {
   const int *pend_in;
   int *pend_out, *sync_idx;
   int do_align;
+  int sy_current;   // option "vsync_current_sy": s_y from THIS frame's beta_y instead of the previous call's (the reference's :66)
   float alpha;
   float *state, *frames_out;
 };
@@ -514,10 +515,11 @@ __device__ __forceinline__ void shift_iir_wg(const IirArgs &A, unsigned wg, unsi
   if (do_align && wg == 0 && threadIdx.x == 0) {
     int sy = pend_in[0];
     for (int f = 0; f < frames; ++f) {
-      if (sync_idx) { sync_idx[2 * f] = sy; sync_idx[2 * f + 1] = key_col1(keys[(size_t)f * 2 + 0]); }
-      sy = key_col1(keys[(size_t)f * 2 + 1]);
+      const int sy_now = key_col1(keys[(size_t)f * 2 + 1]);
+      if (sync_idx) { sync_idx[2 * f] = A.sy_current ? sy_now : sy; sync_idx[2 * f + 1] = key_col1(keys[(size_t)f * 2 + 0]); }
+      sy = sy_now;
     }
-    pend_out[0] = sy;
+    pend_out[0] = sy;   // (rolled in either mode: the option may change between calls)
   }
   if (idx >= npx) return;
   const int i = (int)(idx % (size_t)h), j = (int)(idx / (size_t)h);
@@ -525,7 +527,7 @@ __device__ __forceinline__ void shift_iir_wg(const IirArgs &A, unsigned wg, unsi
   const float oma = __fsub_rn(1.0f, alpha);
   auto src_of = [&](int f) -> size_t {
     if (!do_align) return idx;
-    const int sy = f == 0 ? pend_in[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
+    const int sy = A.sy_current ? key_col1(keys[(size_t)f * 2 + 1]) : f == 0 ? pend_in[0] : key_col1(keys[(size_t)(f - 1) * 2 + 1]);
     const int sx = key_col1(keys[(size_t)f * 2 + 0]);
     int si = i + sy; if (si >= h) si %= h;   // 1 <= s <= n: one conditional subtraction almost always
     int sj = j + sx; if (sj >= w) sj %= w;
@@ -573,9 +575,9 @@ __global__ __launch_bounds__(64 * NWV) void k_tail(BetaArgs B, unsigned nbb, uns
 
 // standalone vsync: publish (s_y,s_x) of one scanned image and roll the pending s_y
 __global__ void k_publish(const unsigned long long *__restrict__ keys, const int *__restrict__ pend_in,
-                          int *__restrict__ pend_out, int *__restrict__ s_yx) {
+                          int *__restrict__ pend_out, int *__restrict__ s_yx, int sy_current) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (s_yx) { s_yx[0] = pend_in[0]; s_yx[1] = key_col1(keys[0]); }
+  if (s_yx) { s_yx[0] = sy_current ? key_col1(keys[1]) : pend_in[0]; s_yx[1] = key_col1(keys[0]); }
   pend_out[0] = key_col1(keys[1]);
 }
 
@@ -648,6 +650,7 @@ static void iir_args(tsdr_sync *s, const float *img, size_t img_stride, int h, i
   I->pend_in = do_align ? s->pending + s->cur : nullptr;
   I->pend_out = do_align ? s->pending + (s->cur ^ 1) : nullptr;
   I->sync_idx = sync_idx; I->do_align = do_align; I->alpha = alpha; I->state = state; I->frames_out = frames_out;
+  I->sy_current = (do_align && s) ? s->ctx->opt_vsync_current_sy : 0;   // (s is null when do_align == 0)
 }
 
 //   top2 (sync guard, guard.h): k_beta also leaves every workgroup's {best, best other column} pair there.
@@ -1026,7 +1029,7 @@ int tsdr_vsync_d(tsdr_sync *s, const float *img, int *s_yx_dev) {
   rc = sync_scan_d(s, img, (size_t)s->y_t * s->x_t, 1, keys, proj, nullptr, nullptr);
   if (rc) return rc;
   TSDR_LAUNCH(ctx, "sync_publish", k_publish, dim3(1), dim3(64), 0, (const unsigned long long *)keys,
-              (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev);
+              (const int *)(s->pending + s->cur), s->pending + (s->cur ^ 1), s_yx_dev, ctx->opt_vsync_current_sy);
   s->cur ^= 1;
   return TSDR_OK;
 }

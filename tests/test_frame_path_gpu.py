@@ -171,6 +171,51 @@ def test_vsync_degenerate_images(ctx, tsdr):
             assert g.vsync(im) == o.vsync(im)
 
 
+def test_vsync_current_sy_option(ctx, tsdr, synth):
+    """the reference reads beta_y before this call refills it (FrameSynchronisation.jl:66), so s_y lags one image --
+    the default, reproduced.  The opt-in "vsync_current_sy" returns the current image's s_y: in vsync, and in the frame
+    loop, where frame f then takes the s_y the default mode gives frame f+1; s_x and the images are untouched.  With
+    alpha = 0 the frames are the shifted 600x800 images themselves, so the shift can be checked against numpy."""
+    Fs, x_t, y_t, fv, nfr = 2.0e6, 1056, 628, 60.0, 5
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 3)
+
+    def run(opt, align=True):
+        ctx.set_option("vsync_current_sy", opt)
+        try:
+            st = np.zeros((600, 800), np.float32, order="F")
+            return ctx.frames(tsdr.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.0), st, do_align=align)
+        finally:
+            ctx.set_option("vsync_current_sy", 0)
+
+    ctx.set_precision("exact")
+    try:
+        ref, fix, raw = run(0), run(1), run(0, align=False)
+    finally:
+        ctx.set_precision("fast")
+    a, b = np.asarray(ref["sync_idx"]), np.asarray(fix["sync_idx"])
+    assert np.array_equal(a[:, 1], b[:, 1])               # s_x: current frame in both
+    assert np.array_equal(b[:-1, 0], a[1:, 0])            # s_y(f) under the option = the default's s_y(f+1)
+    assert a[0, 0] == 1                                   # the default's first s_y: beta_y still all zero
+    for f in range(nfr):
+        img = raw["frames"][f]
+        for got, idx in ((ref["frames"][f], a[f]), (fix["frames"][f], b[f])):
+            want = np.roll(img, (-int(idx[0]), -int(idx[1])), axis=(0, 1))   # circshift(image, (-s_y, -s_x)), GUI.jl:172
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f
+    # standalone vsync
+    sg = tsdr.SyncXY(ctx, 600, 800)
+    imgs = [np.asfortranarray(raw["frames"][f]) for f in range(3)]
+    dflt = [sg.vsync(im) for im in imgs]
+    sg.reset()
+    ctx.set_option("vsync_current_sy", 1)
+    try:
+        cur = [sg.vsync(im) for im in imgs]
+    finally:
+        ctx.set_option("vsync_current_sy", 0)
+    assert [c[1] for c in cur] == [d[1] for d in dflt]
+    assert [c[0] for c in cur[:-1]] == [d[0] for d in dflt[1:]]
+
+
 def test_circshift(ctx):
     img = np.asfortranarray(rng.random((600, 800), dtype=np.float32))
     assert_bitexact(ctx.circshift_neg(img, 17, 333), O.circshift_neg(img, 17, 333), "circshift")
