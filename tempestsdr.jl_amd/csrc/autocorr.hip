@@ -281,7 +281,8 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
 static int autocorr_args(tsdr_ctx *ctx, size_t len, double Fs, double minDelay, double maxDelay, size_t *n, size_t *k0,
                          size_t *cnt) {
   const double dmin = jl_round(minDelay * Fs), dmax = jl_round(maxDelay * Fs);
-  if (!(dmin >= 0) || !(dmax >= 1) || dmax > 1e15) return set_err(ctx, TSDR_EBOUNDS, "autocorr: delay window out of range");
+  // (round(x) |> Int of a non-finite or huge value is an InexactError in the reference; a negative index a BoundsError)
+  if (!(dmin >= 0) || !(dmax >= 1) || dmax > 1e15 || dmin > 1e15) return set_err(ctx, TSDR_EBOUNDS, "autocorr: delay window out of range");
   const size_t indexMin = 1 + (size_t)dmin, indexMax = (size_t)dmax;
   *n = 2 * indexMax < len ? 2 * indexMax : len;                     // :27
   if (indexMax > *n) return set_err(ctx, TSDR_EBOUNDS, "autocorr: signal shorter than maxDelay*Fs (BoundsError at :33)");

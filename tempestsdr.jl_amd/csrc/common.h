@@ -80,7 +80,7 @@ struct tsdr_ctx {
   unsigned guard_seen_c = 0, guard_seen_f = 0;
   bool guard_exact_now = false;
   unsigned long long guard_auto_buffers = 0, guard_auto_switches = 0;
-  const uint2 *guard_last_top2 = nullptr;  // the top-2 records of the most recent guarded call (tsdr_sync_guard_margins)
+  size_t guard_last_off = (size_t)-1;       // byte offset inside WS_GUARD of the most recent guarded call's top-2 records (tsdr_sync_guard_margins)
   int guard_last_frames = 0, guard_last_nbx = 0, guard_last_nby = 0;
   struct Buf { void *p = nullptr; size_t cap = 0; } ws[tsdr::WS_COUNT];
   // profiling

@@ -16,6 +16,9 @@ int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...) {
     va_end(ap);
     ctx->err = buf;
   }
+  // HIP keeps a failed call's status as the thread's "last error" until someone reads it; TSDR_LAUNCH reads it after every
+  // launch, so an allocation that failed here (reported as TSDR_ENOMEM) would otherwise fail the NEXT, valid call too
+  (void)hipGetLastError();
   return status;
 }
 
@@ -74,6 +77,7 @@ void *tsdr_ctx::scratch(int slot, size_t bytes) {
     (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+    if (slot == tsdr::WS_GUARD) guard_last_off = (size_t)-1;   // (its contents are gone)
   }
   size_t want = bytes + bytes / 8 + 4096;  // slack so slowly growing inputs do not realloc
   hipError_t e = hipMalloc(&b.p, want);
@@ -237,13 +241,18 @@ int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *
   if (!ctx || max_frames < 0 || (max_frames && !margins)) return TSDR_EINVAL;
   int rc = tsdr::pipe_drain(ctx);
   if (rc) return rc;
-  const int F = ctx->guard_last_top2 ? ctx->guard_last_frames : 0;
+  const int nbx = ctx->guard_last_nbx, nby = ctx->guard_last_nby, nbb = nbx + nby;
+  const tsdr_ctx::Buf &gb_ws = ctx->ws[tsdr::WS_GUARD];
+  // the records are still there only if the workspace has not been reallocated smaller than where they lay
+  const bool have = ctx->guard_last_off != (size_t)-1 && gb_ws.p &&
+                    ctx->guard_last_off + (size_t)ctx->guard_last_frames * nbb * sizeof(uint2) <= gb_ws.cap;
+  const int F = have ? ctx->guard_last_frames : 0;
   if (n_frames) *n_frames = F;
   const int nf = F < max_frames ? F : max_frames;
   if (nf == 0) return TSDR_OK;
-  const int nbx = ctx->guard_last_nbx, nby = ctx->guard_last_nby, nbb = nbx + nby;
   std::vector<uint2> h((size_t)nf * nbb);
-  TSDR_HIP(ctx, hipMemcpyAsync(h.data(), ctx->guard_last_top2, h.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+  TSDR_HIP(ctx, hipMemcpyAsync(h.data(), (const char *)gb_ws.p + ctx->guard_last_off, h.size() * sizeof(uint2), hipMemcpyDeviceToHost,
+                               ctx->stream));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int f = 0; f < nf; ++f)
     for (int axis = 0; axis < 2; ++axis) {  // the same top-2 merge as guard_eval (guard.h)

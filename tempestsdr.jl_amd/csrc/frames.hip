@@ -119,7 +119,9 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
   g.host = ctx->guard_host;
   gp->g = g;
   gp->on = true;
-  ctx->guard_last_top2 = gp->top2; ctx->guard_last_frames = F; ctx->guard_last_nbx = nbx; ctx->guard_last_nby = nby;
+  // (an offset, not the pointer: the workspace may be reallocated by a later, larger call)
+  ctx->guard_last_off = (size_t)((const char *)gp->top2 - (const char *)ctx->ws[WS_GUARD].p);
+  ctx->guard_last_frames = F; ctx->guard_last_nbx = nbx; ctx->guard_last_nby = nby;
   return TSDR_OK;
 }
 
@@ -342,7 +344,7 @@ int tsdr_frames_flush(tsdr_ctx *ctx) {
 
 int tsdr_frames(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha,
                 int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx, int *n_frames) {
-  if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0) return TSDR_EINVAL;
+  if (!ctx || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0 || (nEch && !iq)) return TSDR_EINVAL;
   const size_t nb = nEch / S, npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W, P = (size_t)y_t * x_t;
   float *d_iq = (float *)ctx->scratch(WS_IN, nEch * 8);
   float *d_state = (float *)ctx->scratch(WS_AUX, npx * 4);

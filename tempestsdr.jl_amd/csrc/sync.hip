@@ -1073,6 +1073,7 @@ int tsdr_fill_beta(tsdr_ctx *ctx, const float *cv, int n, int w_min, int w_max, 
 int tsdr_circshift_neg(tsdr_ctx *ctx, const float *img, int h, int w, int s_y, int s_x, float *out) {
   if (!ctx || !img || !out || h <= 0 || w <= 0) return TSDR_EINVAL;
   const size_t npx = (size_t)h * w;
+  s_y %= h; s_x %= w;   // any shift is legal (circshift reduces it); the kernel adds it to an index in 32 bits
   return host_map(ctx, img, npx * 4, out, npx * 4, [&](void *i, void *o) {
     TSDR_LAUNCH(ctx, "circshift", k_circshift, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, (const float *)i, h, w,
                 s_y, s_x, (float *)o);

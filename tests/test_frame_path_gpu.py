@@ -5,6 +5,8 @@ Bar: BIT-EXACT for everything on the frame path (demodulation, resize/raster, pr
 beta, sync indices, IIR) -- the kernels follow the oracle's IEEE operation sequence -- except
 fmDemod (atan2 implementations differ; tolerance stated in the test).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -452,3 +454,17 @@ def test_sync_margins_on_the_synthetic_leak(ctx, tsdr, synth):
         col, margin = beta_margin(sync.beta(w))
         print(f"C2 beta_{w}: argmax column {col}, relative margin to the best other column {margin:.3e}")
         assert margin >= 0.0, (w, col, margin)
+
+
+def test_c_abi_misuse_returns_instead_of_crashing():
+    """tools/fuzz_api_errors.py in a child process: ~540 calls over 54 entry points with one argument at a time replaced by
+    a null pointer / zero, one or absurd size / zero, negative or INT_MAX dimension / NaN, negative or huge rate.  Every call
+    must return a status (the reference throws; it never crashes), leave the stream usable, and the unmodified call must
+    still succeed afterwards (a failed allocation used to leave HIP's sticky last-error behind and fail the next launch)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.join(root, "tools", "fuzz_api_errors.py")], capture_output=True,
+                       text=True, timeout=600)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
+    assert r.returncode == 0 and "every baseline still succeeds" in r.stdout and "context closed" in r.stdout, tail
