@@ -130,6 +130,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_FFT_NO_MIX2")) ctx->opt_fft_no_mix2 = atoi(e) != 0;
   if (const char *e = getenv("TSDR_AC_FUSE_MID")) ctx->opt_ac_fuse_mid = atoi(e) != 0;
   if (const char *e = getenv("TSDR_FFT_BIG")) ctx->opt_fft_big = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_FAST_WALK_ONLY")) ctx->opt_fast_walk_only = atoi(e) != 0;
   if (const char *e = getenv("TSDR_SYNC_GUARD_PPB")) ctx->guard_thr = (float)atoi(e) * 1e-9f;
   if (const char *e = getenv("TSDR_SYNC_GUARD_AUTO")) ctx->opt_guard_auto = atoi(e) != 0;
   return ctx;
@@ -190,6 +191,7 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   if (!strcmp(name, "ac_mixed")) ctx->opt_ac_mixed = value != 0;
   else if (!strcmp(name, "fft_no_mix2")) ctx->opt_fft_no_mix2 = value != 0;
   else if (!strcmp(name, "ac_fuse_mid")) ctx->opt_ac_fuse_mid = value != 0;
+  else if (!strcmp(name, "fast_walk_only")) ctx->opt_fast_walk_only = value != 0;
   else if (!strcmp(name, "vsync_current_sy")) {
     int rc = tsdr::pipe_drain(ctx);   // a deferred shift + IIR stage was submitted under the old setting
     if (rc) return rc;

@@ -16,10 +16,35 @@ __device__ inline float abs_iq(float re, float im) {
   return abs_c(re, im);                                            // tiny / huge / non-finite: the f64 form
 }
 
+// FAST |IQ| of the raster-free kernel: the same m, but a correctly rounded square root (HIP's sqrtf: v_sqrt_f32 plus a fix-up,
+// ~6 instructions on the ~460 k samples a frame's tiles stage) -- 0.75 ulp overall instead of 1.5.  Frames end up within 4.2e-7
+// of EXACT's (fuzzers; asserted: 5e-7).  EXACT's own f64 square root here would make that 2.4e-7 for +7.7 us per C2 buffer
+// (54 -> 62 us): measured, not taken -- the bar is 1e-5.
+__device__ inline float abs_iq_rn(float re, float im) {
+  const float m = fmaf(re, re, im * im);
+  if (m > 1e-30f && m < 1e30f) return sqrtf(m);
+  return abs_c(re, im);
+}
+
 // a + d*(b - a) with one f64 FMA and one rounding to f32: within 1 ulp of the value whatever |b-a| is
 __device__ inline float fast_blend(float a, float b, double d) {
   return (float)fma(d, (double)b - (double)a, (double)a);
 }
+
+// sum over the 64 lanes by the fixed DPP tree (row_shr 1, 2, 4, 8, then row_bcast 15 and 31); the total lands in lane 63.
+// Lanes a step does not reach (out of their row, or masked by row/bank mask) add the `old` operand, 0.
+#define TSDR_DPP_ADD(x, ctrl, rmask, bmask) \
+  __fadd_rn((x), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), (rmask), (bmask), false)))
+__device__ inline float wave_sum63(float v) {
+  v = TSDR_DPP_ADD(v, 0x111, 0xF, 0xF);
+  v = TSDR_DPP_ADD(v, 0x112, 0xF, 0xF);
+  v = TSDR_DPP_ADD(v, 0x114, 0xF, 0xE);
+  v = TSDR_DPP_ADD(v, 0x118, 0xF, 0xC);
+  v = TSDR_DPP_ADD(v, 0x142, 0xA, 0xF);
+  v = TSDR_DPP_ADD(v, 0x143, 0xC, 0xF);
+  return v;
+}
+#undef TSDR_DPP_ADD
 
 // ------------------------------------------------------------------------------------------------------------
 // k_down_fused: sig_to_image |> downgradeImage without the raster.  Tile = 64 output rows x TC output columns;
@@ -31,6 +56,10 @@ struct DownParams {
   int y_t, x_t, h_out, w_out;
   int TC, NL, W, tiles_c;
   int lpl_log;
+  // PSUM (FAST frame loop without a raster): projection partial sums of the (h_out, w_out) image and the frame's argmax keys
+  float *proj = nullptr;        // per frame: colpart[row blocks][w_out] | rowpart[tiles_c][h_out]  (sync_layout.h)
+  size_t proj_stride = 0;
+  unsigned long long *keys = nullptr;
 };
 
 enum { DM_EXACT = 0, DM_FAST_PAIR = 1, DM_FAST_F32 = 2 };
@@ -58,11 +87,18 @@ __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
 // COLSUM (sync guard): the tile's rows are one of k_proj's 64-row blocks, so the body also leaves that block's column
 // sums of its TC columns -- rows added in row order from 0.0f, exactly k_proj's colpart -- in colpart[c] (c = image
 // column); colT: TC * 65 floats of LDS beyond lds_dn's region.
-template <bool CPLX, int MODE, int NT, bool COLSUM = false>
+// SUMS = 2 (PSUM, FAST only): the tile also leaves the partial projection sums of its 64 rows x TC columns -- per column the
+// sum over the rows (one fixed DPP tree per column, -> colpart[row block][column]) and per row the sum over the columns (a
+// wavefront adds its columns in ascending order, the wavefronts are added in order through LDS, -> rowpart[column tile][row]):
+// every slot is written by exactly one lane, nothing is cleared; tile 0 clears the frame's two argmax keys.  psum_lds:
+// (NT + TC) floats of LDS beyond lds_dn's region.
+enum { DS_NONE = 0, DS_COLSUM = 1, DS_PSUM = 2 };
+template <bool CPLX, int MODE, int NT, int SUMS = DS_NONE>
 __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
                                        float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn,
                                        float *__restrict__ colpart = nullptr, float *colT = nullptr) {
   constexpr bool EXACT = MODE == DM_EXACT;
+  constexpr bool COLSUM = SUMS == DS_COLSUM, PSUM = SUMS == DS_PSUM;
   constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample
   const int Wp = q.W | 1;
   char *base = reinterpret_cast<char *>(lds_dn);
@@ -116,7 +152,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
         for (int u = 0; u < 4; ++u) {
           const int j = jb + u * lpl;
           if (j < q.W) {
-            const float a = CPLX ? abs_iq<EXACT>(re[u], im[u]) : re[u];
+            const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
             if (MODE == DM_FAST_PAIR) reinterpret_cast<double2 *>(base)[i * Wp + j].x = (double)a;
             else reinterpret_cast<float *>(base)[i * Wp + j] = a;
           }
@@ -135,17 +171,22 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   }
   const int wave = tid >> 6, lane = tid & 63;
   const int r = r0 + lane;
-  if (!COLSUM && r >= q.h_out) return;  // (no barrier follows in the body)
-  if (r < q.h_out) {
+  if (SUMS == DS_NONE && r >= q.h_out) return;  // (no barrier follows in the body)
+  float racc = 0.0f;   // PSUM: this wavefront's sum of row r over its columns
+  float *prow = PSUM ? colT : nullptr;          // [NT/64][64] row sums per wavefront, then [TC] column sums
+  float *pcol = PSUM ? colT + NT : nullptr;
+  if (r < q.h_out || PSUM) {
+  const bool live = r < q.h_out;
+  const int rr_ = live ? r : q.h_out - 1;       // (PSUM: lanes past the image follow the last row and contribute 0)
   double dy;
-  const int ky = (int)rs_pos(ay, (double)(r + 1), dy);
+  const int ky = (int)rs_pos(ay, (double)(rr_ + 1), dy);
   const int i0 = ky - ly0;
   const char *row0 = base + (size_t)i0 * Wp * SB;
   const char *row1 = row0 + (size_t)Wp * SB;
   const int kf0 = kfirst[i0], kf1 = kfirst[i0 + 1];
   const unsigned b0 = (unsigned)ky * (unsigned)q.x_t, b1 = b0 + (unsigned)q.x_t;
   const int cend = min(c0 + q.TC, q.w_out);
-  float *o = out + (size_t)f * out_stride + (size_t)r;
+  float *o = out + (size_t)f * out_stride + (size_t)rr_;
   // FAST: 0-based source coordinate of raster pixel (ky, 0) and the per-line / per-pixel increments
   const double xrow = fma(ax1.sf, (double)b0 + 0.5, -0.5), xline = ax1.sf * (double)q.x_t;
   for (int c = c0 + wave; c < cend; c += NT / 64) {
@@ -178,9 +219,29 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
       const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
       v = (float)fma(dy, bot - top, top);
     }
-    o[(size_t)c * q.h_out] = v;
+    if (live) o[(size_t)c * q.h_out] = v;
     if (COLSUM) colT[ct * 65 + lane] = v;
+    if (PSUM) {
+      const float m = live ? v : 0.0f;
+      racc = __fadd_rn(racc, m);
+      const float tot = wave_sum63(m);
+      if (lane == 63) pcol[ct] = tot;
+    }
   }
+  }
+  if (PSUM) {
+    prow[wave * 64 + lane] = racc;
+    __syncthreads();
+    float *pr = q.proj + (size_t)f * q.proj_stride;
+    const int nrb = (q.h_out + 63) >> 6;
+    if (tile_idx == 0 && tid < 2) q.keys[(size_t)f * 2 + tid] = 0ull;
+    if (tid < 64 && r0 + tid < q.h_out) {
+      float a = prow[tid];
+#pragma unroll
+      for (int w2 = 1; w2 < NT / 64; ++w2) a = __fadd_rn(a, prow[w2 * 64 + tid]);
+      pr[(size_t)nrb * q.w_out + (size_t)tc * q.h_out + r0 + tid] = a;
+    }
+    if (tid < q.TC && c0 + tid < q.w_out) pr[(size_t)tr * q.w_out + c0 + tid] = pcol[tid];
   }
   if (COLSUM) {
     __syncthreads();

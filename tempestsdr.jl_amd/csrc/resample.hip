@@ -344,20 +344,6 @@ struct DownInfo {   // per-lane / per-wave state of the in-walk downgrade
   int lane;
 };
 
-// sum over the 64 lanes by the fixed DPP tree (row_shr 1, 2, 4, 8, then row_bcast 15 and 31); the total lands in lane 63.
-// Lanes a step does not reach (out of their row, or masked by row/bank mask) add the `old` operand, 0.
-#define TSDR_DPP_ADD(x, ctrl, rmask, bmask) \
-  __fadd_rn((x), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), (rmask), (bmask), false)))
-__device__ inline float wave_sum63(float v) {
-  v = TSDR_DPP_ADD(v, 0x111, 0xF, 0xF);
-  v = TSDR_DPP_ADD(v, 0x112, 0xF, 0xF);
-  v = TSDR_DPP_ADD(v, 0x114, 0xF, 0xE);
-  v = TSDR_DPP_ADD(v, 0x118, 0xF, 0xC);
-  v = TSDR_DPP_ADD(v, 0x142, 0xA, 0xF);
-  v = TSDR_DPP_ADD(v, 0x143, 0xC, 0xF);
-  return v;
-}
-#undef TSDR_DPP_ADD
 
 // dword store with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (the compiler keeps
 // emitting a 64-bit VGPR address, i.e. a 64-bit VALU add per store, for this pattern)
@@ -711,11 +697,12 @@ __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__
 }
 
 // grid = (tiles, frames)
-template <bool CPLX, int MODE>
+template <bool CPLX, int MODE, int SUMS = DS_NONE>
 __global__ __launch_bounds__(256) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
-                                                    float *__restrict__ out, size_t out_stride) {
+                                                    float *__restrict__ out, size_t out_stride, size_t lds_main) {
   extern __shared__ double lds_dn[];
-  down_fused_body<CPLX, MODE, 256>(in, in_stride, q, out, out_stride, (int)blockIdx.x, (int)blockIdx.y, lds_dn);
+  down_fused_body<CPLX, MODE, 256, SUMS>(in, in_stride, q, out, out_stride, (int)blockIdx.x, (int)blockIdx.y, lds_dn, nullptr,
+                                         reinterpret_cast<float *>(reinterpret_cast<char *>(lds_dn) + lds_main));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -982,20 +969,23 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
   const double sf = (double)S / ((double)y_t * (double)x_t);
   const double sfy = (double)y_t / (double)h_out, sfx = (double)x_t / (double)w_out;
   const long NL = (long)(63.0 * sfy) + 3;
-  static const int cand[] = {32, 16, 8, 4};
-  // preference: FAST with {a, slope} f64 pairs (16 B/sample) when it fits 32 KiB, else f32 staging
-  for (int pass = 0; pass < 3 && !pl.fused; ++pass) {
-    const int sb = (!exact && pass == 0) ? 16 : 4;
-    if (exact && pass == 0) continue;
+  // 64-column tiles (4096 pixels per 256-thread workgroup) with f32 staging: measured at C2 against the former preference
+  // (32 columns at most, {a, slope} f64 pairs when they fit 32 KiB -- which held the tile to 16 columns): 50 vs 65 us for the
+  // FAST kernel; 128 columns: 58 us.  The EXACT tiling is the sync guard's as well and stays as it was.
+  static const int cand_fast[] = {64, 32, 16, 8, 4}, cand_exact[] = {32, 16, 8, 4, 0};
+  const int *cand = exact ? cand_exact : cand_fast;
+  for (int pass = 1; pass < 3 && !pl.fused; ++pass) {
+    const int sb = 4;
     const size_t cap = pass == 2 ? 60 * 1024 : 32 * 1024;
-    for (int TC : cand) {
+    for (int ci = 0; ci < 5 && cand[ci] > 0; ++ci) {
+      const int TC = cand[ci];
       const long DPX = (long)((double)(TC - 1) * sfx) + 2;
       const long W = (long)((double)DPX * sf) + 4 + (exact ? 0 : 1);
       const size_t lds = (((size_t)NL * (size_t)(W | 1) * sb + 15) & ~(size_t)15) + (size_t)TC * 20 + (size_t)NL * 4;
       if (lds <= cap && W < (1 << 20)) {
         pl.fused = true;
         pl.lds = lds;
-        pl.mode = exact ? DM_EXACT : (sb == 16 ? DM_FAST_PAIR : DM_FAST_F32);
+        pl.mode = exact ? DM_EXACT : DM_FAST_F32;
         pl.q.S = (unsigned)S; pl.q.y_t = y_t; pl.q.x_t = x_t; pl.q.h_out = h_out; pl.q.w_out = w_out;
         pl.q.TC = TC; pl.q.NL = (int)NL; pl.q.W = (int)W; pl.q.tiles_c = (int)ceil_div((size_t)w_out, (size_t)TC);
         int best = 2; long best_slots = 1L << 60;
@@ -1012,8 +1002,11 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
 }
 
 // sig_to_image |> downgradeImage for `frames` frames, straight from the signal (no raster in HBM)
+// proj / got / keys (FAST, IQ input): the kernel also leaves the images' projection partial sums (layout in *got) and clears the
+// frames' argmax keys; plan_only: nothing is launched, *got says what a real call would produce (ncp == 0: nothing).
 int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, size_t S, int y_t, int x_t, int h_out,
-                  int w_out, int frames, float *out, size_t out_stride) {
+                  int w_out, int frames, float *out, size_t out_stride, float *proj = nullptr, ProjLayout *got = nullptr,
+                  bool plan_only = false, unsigned long long *keys = nullptr) {
   int rc = check_geom(ctx, S, y_t, x_t);
   if (rc) return rc;
   if (h_out <= 0 || w_out <= 0) return set_err(ctx, TSDR_EINVAL, "output size must be positive");
@@ -1021,23 +1014,35 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   if (!same2 && (y_t < 2 || x_t < 2)) return set_err(ctx, TSDR_EINVAL, "imresize needs at least a 2x2 raster");
   if (frames <= 0) return TSDR_OK;
   // imresize returns a copy when the sizes already match: the raster IS the result
-  if (same2) return raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, out, out_stride);
+  if (same2) return plan_only ? TSDR_OK : raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, out, out_stride);
   const size_t P = (size_t)y_t * x_t;
   const bool exact = ctx->precision == TSDR_EXACT || !cplx;
   DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact);
   if (pl.fused) {
+    const bool psum = !exact && got != nullptr && (plan_only || (proj != nullptr && keys != nullptr));
+    if (psum) {
+      got->ncp = (int)ceil_div((size_t)h_out, 64);
+      got->nrp = pl.q.tiles_c;
+    }
+    if (plan_only) return TSDR_OK;
     dim3 grid((unsigned)(ceil_div((size_t)h_out, 64) * (size_t)pl.q.tiles_c), (unsigned)frames);
-#define DOWNK(C, M, NAME) TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M>), grid, dim3(256), pl.lds, in, in_stride, pl.q, out, out_stride)
+    const size_t lds_main = (pl.lds + 15) & ~(size_t)15;
+#define DOWNK(C, M, SUMS, NAME, LDS) \
+  TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS>), grid, dim3(256), LDS, in, in_stride, pl.q, out, out_stride, lds_main)
     if (cplx) {
-      if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, "down_fused_iq_exact"); }
-      else if (pl.mode == DM_FAST_PAIR) { DOWNK(true, DM_FAST_PAIR, "down_fused_iq"); }
-      else { DOWNK(true, DM_FAST_F32, "down_fused_iq"); }
+      if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, DS_NONE, "down_fused_iq_exact", pl.lds); }
+      else if (psum) {
+        pl.q.proj = proj; pl.q.proj_stride = proj_floats(h_out, w_out, *got); pl.q.keys = keys;
+        DOWNK(true, DM_FAST_F32, DS_PSUM, "down_fused_iq_sums", lds_main + (256 + (size_t)pl.q.TC) * 4);
+      }
+      else { DOWNK(true, DM_FAST_F32, DS_NONE, "down_fused_iq", pl.lds); }
     } else {
-      DOWNK(false, DM_EXACT, "down_fused_f32_exact");
+      DOWNK(false, DM_EXACT, DS_NONE, "down_fused_f32_exact", pl.lds);
     }
 #undef DOWNK
     return TSDR_OK;
   }
+  if (plan_only) return TSDR_OK;
   // fallback: materialise each raster in workspace, then the generic 2-D resize
   float *ras = (float *)ctx->scratch(WS_RASTER, P * 4);
   if (!ras) return TSDR_ENOMEM;
@@ -1070,8 +1075,24 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
                       int w_out, int frames, float *raster, size_t raster_stride, float *down, size_t down_stride,
                       float *proj, ProjLayout *got, bool plan_only, unsigned long long *keys) {
   if (got) *got = ProjLayout{};
-  // FAST without a raster to write: the tile kernel still wins (its walk produces the raster values in registers and
-  // downgrades them on the spot; k_down_fused re-derives four taps per output pixel), so it runs with out == null
+  // FAST without a raster to write: k_down_fused re-derives the four taps of every output pixel from 64 x 64-pixel tiles of
+  // staged samples and leaves the projection partial sums itself (round 3: 54 us at C2 against the walk's 77 us with
+  // out == null -- the walk evaluates all 2.9 M raster pixels of a frame for the 1.8 M that are taps).  Other geometries
+  // fall through to the walk, then to the raster + resize fallback.
+  if (!raster && ctx->precision == TSDR_FAST && cplx && !ctx->opt_fast_walk_only) {
+    ProjLayout pl{};
+    const DownPlan dp = plan_down(S, y_t, x_t, h_out, w_out, false);
+    // ... when its full 64-column tile fits (few samples per raster pixel: C2 0.115, C5 0.084 -- 0.102 vs 0.123 and 0.138 vs
+    // 0.279 ms per buffer).  At C3's 1.15 samples per pixel only 32-column tiles fit and staging dominates either kernel: the
+    // walk wins there (0.420 vs 0.461 ms) and keeps the route.
+    if (dp.fused && dp.q.TC == 64 && !(y_t == h_out && x_t == w_out) && check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 2 && x_t >= 2) {
+      int rc = down_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, h_out, w_out, frames, down, down_stride, proj, got ? &pl : nullptr,
+                             plan_only, keys);
+      if (rc) return rc;
+      if (got) *got = pl;
+      return TSDR_OK;
+    }
+  }
   if (raster || (ctx->precision == TSDR_FAST && cplx)) {
     bool did = false;
     ProjLayout pl{};

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
       const int f = list[j] & 0x3FFFFFFF;
       if (tile == 0 && tid == 0) a.B.keys[(size_t)f * 2] = 0ull;  // the x key (proj_wg clears both when it runs)
       const int tr = tile / a.dq.tiles_c;
-      down_fused_body<true, DM_EXACT, 512, true>(a.iq, a.in_stride, a.dq, a.img, a.img_stride, tile, f, glds,
+      down_fused_body<true, DM_EXACT, 512, DS_COLSUM>(a.iq, a.in_stride, a.dq, a.img, a.img_stride, tile, f, glds,
                                                   a.proj + (size_t)f * a.proj_stride + (size_t)tr * a.x_t,
                                                   reinterpret_cast<float *>(reinterpret_cast<char *>(glds) + a.lds_bytes));
       guard_signal(doneA + j);
