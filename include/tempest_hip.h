@@ -97,9 +97,11 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 BEFORE this call refills it (FrameSynchronisation.jl:66), so it is the previous image's; 1: s_y of the
  *                 current image (what the code presumably meant; NOT what TempestSDR.jl does).  Takes effect from the
  *                 next call; the pending value is kept up to date in either mode.
+ *   "fast_walk_only" 1: the TSDR_FAST frame loop without a raster runs the raster walk with out == NULL (rounds 1-2) instead
+ *                 of the tap-based kernel with its own partial sums.  Default 0.  Results within the FAST tolerance either way.
  *   "sync_guard_auto" 1 (default): the adaptive whole-buffer TSDR_EXACT route described above; 0: flagged frames are always
  *                 re-evaluated one by one.
- * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO preset them, read
+ * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY preset them, read
  * once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
 /* running totals of the sync guard on this context: frames whose margins were checked / frames flagged (re-evaluated in

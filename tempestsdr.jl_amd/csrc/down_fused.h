@@ -62,7 +62,7 @@ struct DownParams {
   unsigned long long *keys = nullptr;
 };
 
-enum { DM_EXACT = 0, DM_FAST_PAIR = 1, DM_FAST_F32 = 2 };
+enum { DM_EXACT = 0, DM_FAST_F32 = 2 };   // (a {a, slope} f64-pair staging, mode 1, lost to f32 staging with 64-column tiles: 65 vs 50 us)
 
 // EXACT raster value at flat index `flat` (0-based) of a staged f32 line
 __device__ inline float raster_tap_exact(const RsAxis &ax1, bool same1, unsigned flat, const float *row, int kf) {
@@ -70,15 +70,11 @@ __device__ inline float raster_tap_exact(const RsAxis &ax1, bool same1, unsigned
   const int j = (int)rs_pos(ax1, (double)(flat + 1u), d) - kf;
   return same1 ? (d == 1.0 ? row[j + 1] : row[j]) : rs_blend(row[j], row[j + 1], d);
 }
-// FAST raster value at 0-based source coordinate x >= 0 (f64): staged {a, b-a} pairs or plain f32 samples
+// FAST raster value at 0-based source coordinate x >= 0 (f64) from the staged f32 samples
 template <int MODE>
 __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
   const double xf = floor(x);
   const int j = (int)xf - kf;
-  if (MODE == DM_FAST_PAIR) {
-    const double2 s = reinterpret_cast<const double2 *>(row)[j];
-    return (float)fma(x - xf, s.y, s.x);
-  }
   const float *r = reinterpret_cast<const float *>(row);
   return fast_blend(r[j], r[j + 1], x - xf);
 }
@@ -99,7 +95,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
                                        float *__restrict__ colpart = nullptr, float *colT = nullptr) {
   constexpr bool EXACT = MODE == DM_EXACT;
   constexpr bool COLSUM = SUMS == DS_COLSUM, PSUM = SUMS == DS_PSUM;
-  constexpr int SB = MODE == DM_FAST_PAIR ? 16 : 4;  // bytes per staged sample
+  constexpr int SB = 4;  // bytes per staged sample
   const int Wp = q.W | 1;
   char *base = reinterpret_cast<char *>(lds_dn);
   double *cdx = reinterpret_cast<double *>(base + (((size_t)q.NL * Wp * SB + 15) & ~(size_t)15));  // [TC] column weight
@@ -153,22 +149,13 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
           const int j = jb + u * lpl;
           if (j < q.W) {
             const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
-            if (MODE == DM_FAST_PAIR) reinterpret_cast<double2 *>(base)[i * Wp + j].x = (double)a;
-            else reinterpret_cast<float *>(base)[i * Wp + j] = a;
+            reinterpret_cast<float *>(base)[i * Wp + j] = a;
           }
         }
       }
     }
   }
   __syncthreads();
-  if (MODE == DM_FAST_PAIR) {  // slope towards the next sample
-    const int lpl = 1 << q.lpl_log;
-    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
-    double2 *s2 = reinterpret_cast<double2 *>(base);
-    for (int i = sub; i < nl; i += nsub)
-      for (int j = j0; j + 1 < q.W; j += lpl) s2[i * Wp + j].y = s2[i * Wp + j + 1].x - s2[i * Wp + j].x;
-    __syncthreads();
-  }
   const int wave = tid >> 6, lane = tid & 63;
   const int r = r0 + lane;
   if (SUMS == DS_NONE && r >= q.h_out) return;  // (no barrier follows in the body)
