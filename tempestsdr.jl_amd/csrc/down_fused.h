@@ -32,19 +32,29 @@ __device__ inline float fast_blend(float a, float b, double d) {
 }
 
 // sum over the 64 lanes by the fixed DPP tree (row_shr 1, 2, 4, 8, then row_bcast 15 and 31); the total lands in lane 63.
-// Lanes a step does not reach (out of their row, or masked by row/bank mask) add the `old` operand, 0.
-#define TSDR_DPP_ADD(x, ctrl, rmask, bmask) \
-  __fadd_rn((x), __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), (ctrl), (rmask), (bmask), false)))
-__device__ inline float wave_sum63(float v) {
-  v = TSDR_DPP_ADD(v, 0x111, 0xF, 0xF);
-  v = TSDR_DPP_ADD(v, 0x112, 0xF, 0xF);
-  v = TSDR_DPP_ADD(v, 0x114, 0xF, 0xE);
-  v = TSDR_DPP_ADD(v, 0x118, 0xF, 0xC);
-  v = TSDR_DPP_ADD(v, 0x142, 0xA, 0xF);
-  v = TSDR_DPP_ADD(v, 0x143, 0xC, 0xF);
+// Each step is ONE in-place v_add_f32_dpp -- v[i] += v[i - k] on the lanes the step reaches; lanes it does not reach (out of
+// their row: bound_ctrl reads 0; masked by row / bank mask: not written) keep their value, i.e. add 0.  Written as assembly
+// because the builtin form (update_dpp with old = 0, then an add) compiles to mov 0 + mov_dpp + add per step: 20 instructions
+// instead of 6 in kernels that issue VALU instructions all the time.  s_nop 1: a DPP source written by the previous VALU
+// instruction needs two wait states.  Must be called with all 64 lanes active.
+__device__ __forceinline__ float wave_sum63(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return v;
 }
-#undef TSDR_DPP_ADD
 
 // ------------------------------------------------------------------------------------------------------------
 // k_down_fused: sig_to_image |> downgradeImage without the raster.  Tile = 64 output rows x TC output columns;
@@ -95,7 +105,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
                                        float *__restrict__ colpart = nullptr, float *colT = nullptr) {
   constexpr bool EXACT = MODE == DM_EXACT;
   constexpr bool COLSUM = SUMS == DS_COLSUM, PSUM = SUMS == DS_PSUM;
-  constexpr int SB = 4;  // bytes per staged sample
+  constexpr int SB = 4;  // bytes per staged sample (f64 staging, which would save the taps' conversions: 58 vs 54 us)
   const int Wp = q.W | 1;
   char *base = reinterpret_cast<char *>(lds_dn);
   double *cdx = reinterpret_cast<double *>(base + (((size_t)q.NL * Wp * SB + 15) & ~(size_t)15));  // [TC] column weight
