@@ -963,7 +963,7 @@ int resize2d_d(tsdr_ctx *ctx, const float *img, int h_in, int w_in, int h_out, i
 
 struct DownPlan { bool fused; int mode; DownParams q; size_t lds; };
 
-static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool exact) {
+static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool exact, bool wide_exact = false) {
   DownPlan pl;
   pl.fused = false;
   pl.lds = 0;
@@ -975,7 +975,7 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
   // (32 columns at most, {a, slope} f64 pairs when they fit 32 KiB -- which held the tile to 16 columns): 50 vs 65 us for the
   // FAST kernel; 128 columns: 58 us.  The EXACT tiling is the sync guard's as well and stays as it was.
   static const int cand_fast[] = {64, 32, 16, 8, 4}, cand_exact[] = {32, 16, 8, 4, 0};
-  const int *cand = exact ? cand_exact : cand_fast;
+  const int *cand = (exact && !wide_exact) ? cand_exact : cand_fast;   // wide_exact: the EXACT frame path (not the sync guard's tiles)
   for (int pass = 1; pass < 3 && !pl.fused; ++pass) {
     const int sb = 4;
     const size_t cap = pass == 2 ? 60 * 1024 : 32 * 1024;
@@ -1019,7 +1019,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   if (same2) return plan_only ? TSDR_OK : raster_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, frames, out, out_stride);
   const size_t P = (size_t)y_t * x_t;
   const bool exact = ctx->precision == TSDR_EXACT || !cplx;
-  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact);
+  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact, true);
   if (pl.fused) {
     const bool psum = !exact && got != nullptr && (plan_only || (proj != nullptr && keys != nullptr));
     if (psum) {

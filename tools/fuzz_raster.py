@@ -49,10 +49,13 @@ for it in range(10):
     S = max(2, int(y_t * x_t * ratio))
     iq = ((rng.standard_normal(S * nfr + 3) + 1j * rng.standard_normal(S * nfr + 3)) * 1e-3).astype(np.complex64)
     gs = np.zeros((600, 800), np.float32, order="F"); os_ = np.zeros((600, 800), np.float32, order="F")
-    g = ctx.frames(T.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), gs, want_raster=True)
-    o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), os_, want_raster=True)
-    assert np.array_equal(g["sync_idx"], o["sync_idx"]) and beq(gs, os_), (S, y_t, x_t)
-    for f in range(nfr):
-        assert beq(g["frames"][f], o["frames"][f]) and beq(g["raster"][f], o["raster"][f]), (S, y_t, x_t, f)
-print("exact frames: 10 geometries bit-identical")
+    for want_raster in (True, False):   # (False: the raster-free kernel, k_down_fused<EXACT>)
+        gs[:] = 0; os_[:] = 0
+        g = ctx.frames(T.SyncXY(ctx, 600, 800), iq, S, y_t, x_t, np.float32(0.1), gs, want_raster=want_raster)
+        o = O.frames(O.SyncXY(600, 800), iq, S, y_t, x_t, np.float32(0.1), os_, want_raster=want_raster)
+        assert np.array_equal(g["sync_idx"], o["sync_idx"]) and beq(gs, os_), (S, y_t, x_t, want_raster)
+        for f in range(nfr):
+            assert beq(g["frames"][f], o["frames"][f]), (S, y_t, x_t, f, want_raster)
+            assert not want_raster or beq(g["raster"][f], o["raster"][f]), (S, y_t, x_t, f)
+print("exact frames: 10 geometries x 2 bit-identical")
 ctx.set_precision("fast")
