@@ -544,13 +544,13 @@ __device__ __forceinline__ void shift_iir_wg(const IirArgs &A, unsigned wg, unsi
 #pragma unroll
     for (int u = 0; u < FB; ++u) {
       acc = __fadd_rn(__fmul_rn(alpha, acc), __fmul_rn(oma, v[u]));
-      if (frames_out) frames_out[(size_t)(f + u) * npx + idx] = acc;
+      if (frames_out) __builtin_nontemporal_store(acc, &frames_out[(size_t)(f + u) * npx + idx]);
     }
   }
   for (; f < frames; ++f) {
     const float v = img[(size_t)f * img_stride + src_of(f)];
     acc = __fadd_rn(__fmul_rn(alpha, acc), __fmul_rn(oma, v));
-    if (frames_out) frames_out[(size_t)f * npx + idx] = acc;
+    if (frames_out) __builtin_nontemporal_store(acc, &frames_out[(size_t)f * npx + idx]);
   }
   state[idx] = acc;
 }
