@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float
         const float p = X.x * X.x + X.y * X.y;  // abs2 in f32, as the reference's abs2.(::ComplexF32)
         if (WATERFALL) {
           const int k = lane + 64 * j + 256 * kb0;
-          wf[seg * kSegN + ((k + kSegN / 2) & (kSegN - 1))] = (double)p;   // fftshift: output index of frequency k
+          __builtin_nontemporal_store((double)p, &wf[seg * kSegN + ((k + kSegN / 2) & (kSegN - 1))]);   // fftshift: output index of frequency k; written once
         } else {
           acc[j * 4 + kb0] += p;
         }
