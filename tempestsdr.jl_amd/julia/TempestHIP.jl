@@ -21,6 +21,7 @@ export getSpectrum, getWelch, getWaterfall
 export SyncXY, vsync
 export hip_frames!           # fused GUI.jl:163-178 loop body (optional fast path)
 export hip_extract_configuration, sync_guard_stats, sync_guard_auto   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
+export hip_set_precision, hip_set_option                              # TSDR_EXACT / TSDR_FAST and the library's options, per task context
 
 const LIB = get(ENV, "TEMPEST_HIP_LIB", joinpath(@__DIR__, "..", "libtempest_hip.so"))
 const RENDERING_SIZE = (600, 800)   # GUI.jl:10
@@ -244,6 +245,25 @@ function hip_extract_configuration(sigId::Vector{ComplexF32}, Fs; delay = 0.1, r
     Γ_refresh = Γ[Int(pmin[]):Int(pmax[])]
     fv = 1 / (1 / rates_refresh[Int(idx[]) + 1])                            # GUI.jl:80-81
     return rates_refresh, Γ_refresh, fv
+end
+
+"""
+    hip_set_precision(mode::Symbol)      # :exact (bit-identical to the CPU restatement) or :fast (default; DESIGN.md section 2)
+
+Arithmetic of the frame loop (`hip_frames!`) on this task's context; the per-function entry points always run the exact sequence.
+"""
+function hip_set_precision(mode::Symbol)
+    mode in (:exact, :fast) || throw(ArgumentError("mode must be :exact or :fast"))
+    c = ctx()
+    check(c, ccall((:tsdr_set_precision, LIB), Cint, (Ptr{Cvoid}, Cint), c.h, mode === :exact ? 0 : 1), "set_precision")
+    return mode
+end
+
+"`tsdr_set_option` on this task's context: \"sync_guard_ppb\", \"sync_guard_auto\", \"vsync_current_sy\", \"ac_mixed\", ... (include/tempest_hip.h)"
+function hip_set_option(name::AbstractString, value::Integer)
+    c = ctx()
+    check(c, ccall((:tsdr_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Cint), c.h, name, value), "set_option($name)")
+    return nothing
 end
 
 "(frames checked, frames re-evaluated in the exact sequence) by the TSDR_FAST frame loop's sync guard on this task's context"
