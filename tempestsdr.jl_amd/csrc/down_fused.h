@@ -16,10 +16,10 @@ __device__ inline float abs_iq(float re, float im) {
   return abs_c(re, im);                                            // tiny / huge / non-finite: the f64 form
 }
 
-// FAST |IQ| of the raster-free kernel: the same m, but a correctly rounded square root (HIP's sqrtf: v_sqrt_f32 plus a fix-up,
-// ~6 instructions on the ~460 k samples a frame's tiles stage) -- 0.75 ulp overall instead of 1.5.  Frames end up within 4.2e-7
-// of EXACT's (fuzzers: 4.7e-7 at worst over 360 random cases; asserted: 6e-7).  EXACT's own f64 square root here would make that 2.4e-7 for +7.7 us per C2 buffer
-// (54 -> 62 us): measured, not taken -- the bar is 1e-5.
+// FAST |IQ| of the raster-free kernel: the same m as abs_iq<false>, but a correctly rounded square root (HIP's sqrtf: v_sqrt_f32
+// plus a fix-up, ~10 instructions on the ~460 k samples a frame's tiles stage) -- 0.75 ulp overall instead of 1.5.  Frames of
+// this kernel are within 3.6e-7 of EXACT's over the fuzzers' cases.  Making the samples EXACT's own -- by the f64 square root
+// (+7.7 us per C2 buffer) or by sqrtf plus an exact midpoint test (+4.4 us) -- was measured and brings 2.4e-7; not taken.
 __device__ inline float abs_iq_rn(float re, float im) {
   const float m = fmaf(re, re, im * im);
   if (m > 1e-30f && m < 1e30f) return sqrtf(m);

@@ -3,7 +3,7 @@ f64 FMA per blend, projection sums formed inside the raster kernel.
 
 Bar (north_star): image pixels within 1e-5 relative, identical frame-sync indices.  FAST is designed
 so that each blend stays within 1 ulp of the f64-faithful evaluation and |IQ| within 1.5 ulp (hardware
-v_sqrt_f32); the tests assert 6e-7 relative (about 5 ulp; measured over 360 random cases: 3.95e-7 with the raster, 4.7e-7 without) against the CPU oracle and IDENTICAL sync indices on
+v_sqrt_f32); the tests assert 6e-7 relative (about 5 ulp; measured over 360 random cases: 4.7e-7 at ~1.2 samples per raster pixel, below 3.6e-7 at the ratios of C2 / C5) against the CPU oracle and IDENTICAL sync indices on
 every frame: the library's sync guard (csrc/guard.h) re-evaluates, in the exact operation sequence, every frame whose
 top-2 beta margin is below 2e-5, so no tie escape is needed (sync_margin.fast_vs_oracle keeps one only for the
 guard-off comparison in test_sync_guard_is_what_makes_indices_identical)."""

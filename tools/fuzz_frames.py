@@ -70,14 +70,16 @@ for it in range(ncase):
         gframes = [f.cpu().numpy().reshape(800, 600).T for fo in outs for f in fo.view(nfr, NPX)]
         gidx = [tuple(int(v) for v in r) for ix in idxs for r in ix.cpu().numpy().reshape(nfr, 2)]
         gstate = d_state.cpu().numpy().reshape(800, 600).T
+    case_worst = 0.0
     assert gidx == oidx, ("sync indices", it, S, y_t, x_t, card, pipelined, [(i, a, b) for i, (a, b) in enumerate(zip(gidx, oidx)) if a != b][:4])
     for f, (a, b) in enumerate(zip(gframes, oframes)):
-        e = relerr(a, b); worst = max(worst, e)
+        e = relerr(a, b); worst = max(worst, e); case_worst = max(case_worst, e)
         assert e < 6e-7, ("frame", it, f, S, y_t, x_t, card, pipelined, e)
     e = relerr(gstate, ostate); worst = max(worst, e)
     assert e < 6e-7, ("state", it, e)
     c, fl = ctx.sync_guard_stats()
     assert c in (0, nbuf * nfr), (c, nbuf * nfr)   # 0: a geometry the guard does not cover runs in TSDR_EXACT
     tot_checked += c; tot_flagged += fl
-    print(f"case {it}: {y_t}x{x_t} S={S} {card} nbuf={nbuf} nfr={nfr} pipelined={pipelined} flagged {fl}/{c} ok", flush=True)
+    print(f"case {it}: {y_t}x{x_t} S={S} (S/P {S / (y_t * x_t):.3f}) {card} nbuf={nbuf} nfr={nfr} pipelined={pipelined} flagged {fl}/{c} "
+          f"worst {case_worst:.3e} ok", flush=True)
 print(f"frames fuzz seed {seed}: {ncase} cases ok, worst rel {worst:.3e}, flagged {tot_flagged}/{tot_checked}")
