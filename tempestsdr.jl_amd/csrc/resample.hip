@@ -1084,10 +1084,12 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
   if (!raster && ctx->precision == TSDR_FAST && cplx && !ctx->opt_fast_walk_only) {
     ProjLayout pl{};
     const DownPlan dp = plan_down(S, y_t, x_t, h_out, w_out, false);
-    // ... when its full 64-column tile fits (few samples per raster pixel: C2 0.115, C5 0.084 -- 0.102 vs 0.123 and 0.138 vs
-    // 0.279 ms per buffer).  At C3's 1.15 samples per pixel only 32-column tiles fit and staging dominates either kernel: the
-    // walk wins there (0.420 vs 0.461 ms) and keeps the route.
-    if (dp.fused && dp.q.TC == 64 && !(y_t == h_out && x_t == w_out) && check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 2 && x_t >= 2) {
+    // ... where there are few samples per raster pixel and a tile of at least 32 columns fits (C2: 0.115 samples per pixel, 64
+    // columns, 0.102 vs 0.123 ms per buffer; C5: 0.084, 32 columns because of its 239 source lines per tile, 0.138 vs 0.279 ms).
+    // At C3's 1.15 samples per pixel staging dominates either kernel and the walk wins (0.420 vs 0.461 ms): it keeps the route
+    // above 0.5 samples per pixel.
+    const double spp = (double)S / ((double)y_t * (double)x_t);   // samples per raster pixel
+    if (dp.fused && dp.q.TC >= 32 && spp <= 0.5 && !(y_t == h_out && x_t == w_out) && check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 2 && x_t >= 2) {
       int rc = down_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, h_out, w_out, frames, down, down_stride, proj, got ? &pl : nullptr,
                              plan_only, keys);
       if (rc) return rc;

@@ -265,6 +265,26 @@ def test_sync_guard_many_frames_in_chunks(ctx, tsdr, synth):
     print("sync guard (checked, re-evaluated):", r["guard"])
 
 
+@pytest.mark.parametrize("wl,nfr", [("C2", 4), ("C5", 2)])
+def test_raster_free_routes_agree(ctx, tsdr, synth, wl, nfr):
+    """Without a raster the FAST loop has two routes: the tap-based kernel with its own projection partial sums (default where
+    its 64-column tile fits: C2, C5) and the raster walk with out == NULL (rounds 1-2; option "fast_walk_only").  Both against
+    the oracle: identical sync indices, frames and IIR state within RTOL; and the two routes' own sync indices identical."""
+    w = synth.WORKLOADS[wl]
+    Fs, x_t, y_t, fv = w["Fs"], w["x_t"], w["y_t"], w["fv"]
+    S = synth.samples_per_frame(Fs, fv)
+    iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 9)
+    res = {}
+    for walk in (0, 1):
+        ctx.set_option("fast_walk_only", walk)
+        try:
+            res[walk] = fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, 0.1, False, RTOL)
+        finally:
+            ctx.set_option("fast_walk_only", 0)
+        assert res[walk]["n_frames"] == nfr and not res[walk]["ties"], (walk, res[walk]["ties"])
+    print("worst relative frame error: tap-based", res[0]["worst"], "walk", res[1]["worst"])
+
+
 def test_sync_guard_adaptive_route(ctx, tsdr, synth):
     """At 1080p60 / 20 MS/s the plateau leak flags ~70 % of its frames: re-evaluating them one by one costs more than the
     exact sequence for everything, so after a window of 60 frames the FAST loop runs whole buffers exactly (bit-identical to
