@@ -101,8 +101,11 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 of the tap-based kernel with its own partial sums.  Default 0.  Results within the FAST tolerance either way.
  *   "sync_guard_auto" 1 (default): the adaptive whole-buffer TSDR_EXACT route described above; 0: flagged frames are always
  *                 re-evaluated one by one.
- * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY preset them, read
- * once in tsdr_create. */
+ *   "beta_waves"  wavefronts per workgroup of the vsync statistics kernel: 4 (default) or 8; identical results.
+ *   "pipe_lanes" / "pipe_priority"  tsdr_frames_submit_d's internal streams (before the first submission only): 2 (default;
+ *                 3 = shift + IIR on a stream of its own) / 1 (default; 0 = no stream priority for the tails).
+ * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
+ * TSDR_BETA_WAVES / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY preset them, read once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
 /* running totals of the sync guard on this context: frames whose margins were checked / frames flagged (re-evaluated in
  * the TSDR_EXACT sequence, one by one or as part of a whole exact buffer).  Synchronises; reset != 0 zeroes the totals. */
@@ -110,11 +113,14 @@ int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, uns
 /* relative top-2 margins (best column vs best OTHER column) the guard saw in the most recent TSDR_FAST frame-loop call
  * on this context, BEFORE any re-evaluation: margins[2f] = beta_x of frame f (decides s_x of frame f), margins[2f+1] =
  * beta_y of frame f (decides s_y of frame f+1).  Fills min(*n_frames, max_frames) frames.  Synchronises. */
+int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *n_frames);
 /* state of the adaptive route (host-side, no synchronisation): *exact_now = 1 while whole buffers run in the TSDR_EXACT
  * sequence; *buffers_exact = frame-loop calls that did so far; *switches = changes of route so far.  The decision uses
- * counters of completed buffers only, so it lags by the buffers in flight. */
+ * counters of completed buffers only, read from a pinned mirror without synchronising, so it lags by the buffers in
+ * flight: WHICH buffers carry TSDR_EXACT pixels and which TSDR_FAST pixels (both inside the tolerance; sync indices are
+ * the reference's either way) depends on host / GPU timing, i.e. the FAST loop is reproducible run to run at the
+ * 1e-7 pixel level only with "sync_guard_auto" = 0 (or in TSDR_EXACT). */
 int tsdr_sync_guard_auto(tsdr_ctx *ctx, int *exact_now, unsigned long long *buffers_exact, unsigned long long *switches);
-int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *n_frames);
 
 /* resident buffers for callers without their own device allocator */
 void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes);
@@ -267,19 +273,22 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
                   float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                   int *sync_idx, int *n_frames);
 
-/* The same per-buffer body software-pipelined for callers that stream successive buffers (the GUI loop of
- * GUI.jl:150-178 does: one buffer after the other from the SDR).  ONE stream, no internal streams or events:
- * submit(k) enqueues the raster stage of buffer k and then ONE launch that carries the vsync statistics of buffer k
- * together with shift + IIR of buffer k-1; the shift + IIR stage of the LAST submitted buffer stays deferred until
- * the next submission, tsdr_frames_flush or tsdr_synchronize enqueues it.  So the outputs of every submitted buffer
- * are complete, in stream order, after tsdr_frames_flush -- which only enqueues -- and on the host after
- * tsdr_synchronize, which drains the deferred stage itself.  Any other entry point that uses the same SyncXY state or
- * image slots (tsdr_frames_d, tsdr_frames_scan_d / _combine_d, tsdr_vsync_d, tsdr_sync_reset / _free, tsdr_set_stream,
- * tsdr_dev_free, tsdr_destroy) enqueues the deferred stage first, so results never depend on the mix of calls.
- * Results are identical to calling tsdr_frames_d once per buffer.
- * Lifetime: until the deferred stage has been enqueued AND has completed, the caller must not touch or free iq, the
- * SyncXY state, imageOut_state, frames_out / raster_out / sync_idx of submitted work (the library keeps the pointers
- * of the last submission), and each in-flight buffer needs its own frames_out / raster_out / sync_idx. */
+/* The same per-buffer body pipelined across buffers, for callers that stream successive buffers (the GUI loop of
+ * GUI.jl:150-178 does: one buffer after the other from the SDR).  submit(k) only enqueues: the image launch (raster +
+ * 600x800 images) of buffer k goes to an internal HIP stream that carries the image launches of all submissions back to
+ * back, its tail (vsync statistics, sync guard, shift + IIR) to a second internal stream of the highest priority, which
+ * waits for the image launch through an event -- so the latency-bound tail of buffer k runs beside the image launch of
+ * buffer k+1 (C2, raster-free: 357 k vs 313 k frames/s).  Three image / key / projection slots rotate.
+ * Ordering: a submission waits for whatever the context's stream holds at the time of the call (uploads, a producer's
+ * kernels); tsdr_frames_flush -- which only enqueues -- orders the context's stream behind every submitted buffer, so
+ * outputs are complete in stream order after the flush and on the host after tsdr_synchronize (which flushes).  Any
+ * other entry point that uses the same SyncXY state or image slots (tsdr_frames_d, tsdr_frames_scan_d / _combine_d,
+ * tsdr_vsync_d, tsdr_sync_reset / _free, tsdr_set_stream, tsdr_dev_free, tsdr_destroy) flushes first, so results never
+ * depend on the mix of calls.  Results are identical to calling tsdr_frames_d once per buffer (sync indices; pixels
+ * bit for bit -- except which buffers the adaptive guard route runs in TSDR_EXACT, see "sync_guard_auto").
+ * Lifetime: until a flush point has been reached AND the context's stream has completed, the caller must not touch or
+ * free iq, the SyncXY state, imageOut_state, frames_out / raster_out / sync_idx of submitted work, and each in-flight
+ * buffer (up to three) needs its own frames_out / raster_out / sync_idx. */
 int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, size_t S, int y_t, int x_t,
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                          int *sync_idx, int *n_frames);

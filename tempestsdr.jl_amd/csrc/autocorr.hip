@@ -381,6 +381,12 @@ static int amax_begin(tsdr_ctx *ctx, AmaxReq *r) {
   // (the two key slots change roles only when k_argmax runs -- argmax_launch: it is the kernel that clears the other one.  A
   // findmax fused into an FFT pass uses `slots` and leaves both alone; toggling here as well handed the next k_argmax a slot
   // that still held an older search's key)
+  // a fused search that failed between its last FFT pass and the publish launch (the only kernel that clears the slot words)
+  // left keys behind that the next fused search would take its maximum against
+  if (ctx->amax_dirty) {
+    TSDR_HIP(ctx, hipMemsetAsync(ctx->amax_keys + 4, 0, 8 * kAmaxSlots, ctx->launch_stream));
+    ctx->amax_dirty = false;
+  }
   r->key = ctx->amax_keys + ctx->amax_slot;
   r->clear = ctx->amax_keys + (ctx->amax_slot ^ 1);
   r->arrived = reinterpret_cast<unsigned *>(ctx->amax_keys + 2);
@@ -444,13 +450,16 @@ int tsdr_autocorr_search_d(tsdr_ctx *ctx, const float *x, int is_iq, size_t len,
   if (rc) return rc;
   r.lo = win_lo;
   r.cnt = win_cnt;
+  ctx->amax_dirty = true;   // until the publish launch (or the route without an epilogue) is known to have been enqueued
   rc = autocorr_core(ctx, x, is_iq, n, k0, cnt, log_scale, out, &r);
   if (rc) return rc;
   if (!r.fused) {  // routes whose last pass has no epilogue: the separate kernel
+    ctx->amax_dirty = false;
     rc = argmax_launch(ctx, out + win_lo, win_cnt, r);
     if (rc) return rc;
   } else {
     TSDR_LAUNCH(ctx, "amax_publish", k_amax_publish, dim3(1), dim3(64), 0, r.slots, r.host, r.seq);
+    ctx->amax_dirty = false;
   }
   return amax_wait(ctx, r.seq, idx, val);
 }

@@ -69,8 +69,8 @@ struct tsdr_ctx {
   // sync guard of the FAST frame loop (guard.h): relative top-2 margin below which a frame is re-evaluated exactly
   // (0: off); running totals {frames checked, frames re-evaluated} on the device
   float guard_thr = 2e-5f;
-  unsigned long long *guard_stats = nullptr;
   unsigned *guard_sync = nullptr;           // work-queue words of the guard kernel (zero between launches)
+  unsigned long long *guard_stats = nullptr;
   // adaptive route (option "sync_guard_auto"): when more than guard_auto_hi of the recent frames were flagged, re-evaluating
   // them one by one costs more than running whole buffers in the exact sequence, so the FAST frame loop does that until the
   // share (still counted, on the exact statistics) falls below guard_auto_lo.  Decided on the host from a pinned mirror of
@@ -79,6 +79,7 @@ struct tsdr_ctx {
   float guard_auto_hi = 0.15f, guard_auto_lo = 0.05f;
   unsigned long long *guard_host = nullptr;  // pinned: checked << 32 | flagged
   unsigned guard_seen_c = 0, guard_seen_f = 0;
+  unsigned guard_grid_seen_f = 0; int guard_quiet = 0;   // sync_guard_d: launches since the mirror last showed a flagged frame
   bool guard_exact_now = false;
   unsigned long long guard_auto_buffers = 0, guard_auto_switches = 0;
   size_t guard_last_off = (size_t)-1;       // byte offset inside WS_GUARD of the most recent guarded call's top-2 records (tsdr_sync_guard_margins)
@@ -99,20 +100,24 @@ struct tsdr_ctx {
   // tsdr_argmax_d: two device key slots (each launch clears the other one) and a pinned host word for the readback
   unsigned long long *amax_keys = nullptr, *amax_host = nullptr, *amax_host_dev = nullptr;
   int amax_slot = 0;
+  bool amax_dirty = false;   // a fused findmax may have left keys in the slot words (autocorr.hip:amax_begin clears them)
   unsigned long long amax_seq = 0;
-  // software-pipelined frame loop (tsdr_frames_submit_d)
-  unsigned long long pipe_n = 0;  // submissions since the last flush point
-  size_t pipe_nb = 0;             // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
-  struct PipePending {            // shift + IIR of the last submitted buffer: enqueued by the NEXT submission (or the flush)
-    bool valid = false;
-    void *sync = nullptr;
-    const float *img = nullptr;
-    int frames = 0, do_align = 0, slot = 0;
-    const unsigned long long *keys = nullptr;
-    float alpha = 0.f;
-    float *state = nullptr, *frames_out = nullptr;
-    int *sync_idx = nullptr;
-  } pipe_pending;
+  // frame loop pipelined across buffers (tsdr_frames_submit_d, frames.hip): the image launches of successive buffers run
+  // back to back on one internal stream, every buffer's tail (vsync statistics, sync guard, shift + IIR) on a second one
+  static constexpr int kPipeSlots = 3;   // image / key / projection / guard-record slots in rotation
+  unsigned long long pipe_n = 0;    // submissions since the last flush point
+  unsigned long long pipe_seq = 0;  // submissions since the lanes were last run empty (slot = pipe_seq % kPipeSlots)
+  size_t pipe_nb = 0;               // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
+  hipStream_t lane[3] = {nullptr, nullptr, nullptr};   // [0] image launches, [1] statistics + guard, [2] shift + IIR
+  hipEvent_t ev_stat[kPipeSlots] = {};
+  hipEvent_t ev_img[kPipeSlots] = {}, ev_tail[kPipeSlots] = {};  // recorded behind a slot's image launch / its shift + IIR
+  bool ev_tail_used[kPipeSlots] = {};
+  hipEvent_t lane_in = nullptr;     // "inputs ready" point of the context's stream
+  int pipe_last_slot = -1;          // slot of the latest submission: its tail is behind everything submitted
+  int opt_pipe_priority = 1;        // 1: the tail streams are created with the highest stream priority
+  int opt_pipe_lanes = 2;           // 3: shift + IIR on a stream of its own (measured: 348 k vs 357 k frames/s raster-free, 175 k vs 181 k with rasters)
+  int opt_beta_waves = 4;           // wavefronts per k_beta workgroup (4 or 8): alone the two tie; beside the pipeline's image kernel a 256-thread
+                                    // workgroup fits the holes its retiring workgroups leave (raster-free 357 k vs 309 k frames/s)
 
   void *scratch(int slot, size_t bytes);  // nullptr on failure (err set)
 };
@@ -121,8 +126,9 @@ namespace tsdr {
 
 int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...);
 int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what);
-// frames.hip: enqueue the deferred shift + IIR of the software pipeline (tsdr_frames_submit_d), if any
+// frames.hip: order the context's stream behind every buffer submitted to the pipeline (tsdr_frames_submit_d)
 int pipe_drain(tsdr_ctx *ctx);
+void pipe_sync_lanes(tsdr_ctx *ctx);   // host-side wait for the pipeline's internal streams
 void prof_begin(tsdr_ctx *ctx, const char *name);
 void prof_end(tsdr_ctx *ctx);
 

@@ -51,6 +51,10 @@ void prof_end(tsdr_ctx *ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->la
 // fold finished event pairs into the per-kernel aggregate
 static int prof_collect(tsdr_ctx *ctx) {
   if (ctx->prof.empty()) return TSDR_OK;
+  {  // (records may sit on the pipeline's lanes)
+    int rc = pipe_drain(ctx);
+    if (rc) return rc;
+  }
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (auto &r : ctx->prof) {
     float ms = 0.f;
@@ -74,6 +78,7 @@ void *tsdr_ctx::scratch(int slot, size_t bytes) {
   if (b.cap >= bytes) return b.p;
   if (b.p) {
     (void)hipStreamSynchronize(stream);
+    tsdr::pipe_sync_lanes(this);   // (the pipeline's lanes may be using the other half of this workspace)
     (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
@@ -133,6 +138,9 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_FAST_WALK_ONLY")) ctx->opt_fast_walk_only = atoi(e) != 0;
   if (const char *e = getenv("TSDR_SYNC_GUARD_PPB")) ctx->guard_thr = (float)atoi(e) * 1e-9f;
   if (const char *e = getenv("TSDR_SYNC_GUARD_AUTO")) ctx->opt_guard_auto = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_PIPE_PRIORITY")) ctx->opt_pipe_priority = atoi(e);
+  if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;
+  if (const char *e = getenv("TSDR_BETA_WAVES")) ctx->opt_beta_waves = atoi(e) == 8 ? 8 : 4;
   return ctx;
 }
 
@@ -141,6 +149,12 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)tsdr::pipe_drain(ctx);
   (void)hipStreamSynchronize(ctx->stream);
+  tsdr::pipe_sync_lanes(ctx);
+  for (auto &l : ctx->lane) if (l) (void)hipStreamDestroy(l);
+  for (auto &e : ctx->ev_img) if (e) (void)hipEventDestroy(e);
+  for (auto &e : ctx->ev_tail) if (e) (void)hipEventDestroy(e);
+  for (auto &e : ctx->ev_stat) if (e) (void)hipEventDestroy(e);
+  if (ctx->lane_in) (void)hipEventDestroy(ctx->lane_in);
   for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
   for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
@@ -198,6 +212,15 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
     ctx->opt_vsync_current_sy = value != 0;
   }
   else if (!strcmp(name, "fft_big")) ctx->opt_fft_big = value != 0;
+  else if (!strcmp(name, "beta_waves")) ctx->opt_beta_waves = value == 8 ? 8 : 4;
+  else if (!strcmp(name, "pipe_lanes")) {
+    if (ctx->lane[0]) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_lanes must be set before the first tsdr_frames_submit_d");
+    ctx->opt_pipe_lanes = value == 3 ? 3 : 2;
+  }
+  else if (!strcmp(name, "pipe_priority")) {   // takes effect when the pipeline's streams are created (first submission)
+    if (ctx->lane[0]) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_priority must be set before the first tsdr_frames_submit_d");
+    ctx->opt_pipe_priority = value != 0;
+  }
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");
     ctx->guard_thr = (float)value * 1e-9f;

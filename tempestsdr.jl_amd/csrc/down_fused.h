@@ -31,6 +31,9 @@ __device__ inline float fast_blend(float a, float b, double d) {
   return (float)fma(d, (double)b - (double)a, (double)a);
 }
 
+// (1-t) a + t b, 0 <= t <= 1, in f32 with two FMAs (see DM_FAST_FX)
+__device__ __forceinline__ float lerp2(float a, float b, float t) { return __fmaf_rn(t, b, __fmaf_rn(-t, a, a)); }
+
 // sum over the 64 lanes by the fixed DPP tree (row_shr 1, 2, 4, 8, then row_bcast 15 and 31); the total lands in lane 63.
 // Each step is ONE in-place v_add_f32_dpp -- v[i] += v[i - k] on the lanes the step reaches; lanes it does not reach (out of
 // their row: bound_ctrl reads 0; masked by row / bank mask: not written) keep their value, i.e. add 0.  Written as assembly
@@ -72,7 +75,11 @@ struct DownParams {
   unsigned long long *keys = nullptr;
 };
 
-enum { DM_EXACT = 0, DM_FAST_F32 = 2 };   // (a {a, slope} f64-pair staging, mode 1, lost to f32 staging with 64-column tiles: 65 vs 50 us)
+// DM_FAST_F32: f64 tap coordinates, f64 blends (any sample rate).  DM_FAST_FX (round 4; at most 0.5 samples per raster pixel):
+// tap coordinates in 32.32 fixed point -- a tap's sample index and its fraction are the two halves of one 64-bit add --, the
+// second tap of a line from the first one's three-sample window, every blend one f32 FMA: ~50 full-rate VALU instructions per
+// output pixel instead of ~75, a third of them half-rate f64.
+enum { DM_EXACT = 0, DM_FAST_F32 = 2, DM_FAST_FX = 3 };   // (a {a, slope} f64-pair staging, mode 1, lost to f32 staging with 64-column tiles: 65 vs 50 us)
 
 // EXACT raster value at flat index `flat` (0-based) of a staged f32 line
 __device__ inline float raster_tap_exact(const RsAxis &ax1, bool same1, unsigned flat, const float *row, int kf) {
@@ -103,7 +110,7 @@ template <bool CPLX, int MODE, int NT, int SUMS = DS_NONE>
 __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
                                        float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn,
                                        float *__restrict__ colpart = nullptr, float *colT = nullptr) {
-  constexpr bool EXACT = MODE == DM_EXACT;
+  constexpr bool EXACT = MODE == DM_EXACT, FX = MODE == DM_FAST_FX;
   constexpr bool COLSUM = SUMS == DS_COLSUM, PSUM = SUMS == DS_PSUM;
   constexpr int SB = 4;  // bytes per staged sample (f64 staging, which would save the taps' conversions: 58 vs 54 us)
   const int Wp = q.W | 1;
@@ -131,6 +138,8 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     const unsigned flat = (unsigned)(ly0 + i) * (unsigned)q.x_t + (unsigned)pxa;
     int k;
     if (EXACT) k = (int)rs_pos(ax1, (double)(flat + 1u), dtmp);
+    else if (FX) k = (int)floor(fma(ax1.sf, (double)flat + 0.5, -0.5)) - 1;   // may be -1 / -2 on the frame's first line: the
+                                                                               // staging clamps, so x < 0 reads s[0] twice
     else k = max((int)floor(fmax(fma(ax1.sf, (double)flat + 0.5, -0.5), 0.0)) - 1, 0);  // one spare sample on the
     kfirst[i] = k;                                                                        // left: tap coordinates
   }                                                                                       // are built by additions
@@ -138,19 +147,23 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     const int c = min(c0 + tid, q.w_out - 1);
     double dx;
     const int kx = (int)rs_pos(axx, (double)(c + 1), dx);
-    ckx[tid] = kx; cdx[tid] = dx; cxs[tid] = ax1.sf * (double)kx;
+    ckx[tid] = kx;
+    if (FX) {  // the same table slots: weight as f32, sf*kx in 32.32 fixed point
+      reinterpret_cast<float *>(cdx)[tid] = (float)dx;
+      reinterpret_cast<long long *>(cxs)[tid] = __double2ll_rd(ax1.sf * (double)kx * 4294967296.0);
+    } else { cdx[tid] = dx; cxs[tid] = ax1.sf * (double)kx; }
   }
   __syncthreads();
   {  // stage the source lines: loads of up to four samples are issued before any |IQ| math
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
     for (int i = sub; i < nl; i += nsub) {
-      const unsigned kf = (unsigned)kfirst[i];
+      const int kf = kfirst[i];
       for (int jb = j0; jb < q.W; jb += 4 * lpl) {
         float re[4], im[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const unsigned k = min(kf + (unsigned)min(jb + u * lpl, q.W - 1), q.S - 1u);
+          const unsigned k = (unsigned)min(max(kf + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
           if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
           else { re[u] = src[k]; im[u] = 0.f; }
         }
@@ -186,8 +199,41 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   float *o = out + (size_t)f * out_stride + (size_t)rr_;
   // FAST: 0-based source coordinate of raster pixel (ky, 0) and the per-line / per-pixel increments
   const double xrow = fma(ax1.sf, (double)b0 + 0.5, -0.5), xline = ax1.sf * (double)q.x_t;
+  // FX: 32.32 fixed-point coordinates of the two lines' first raster pixel, relative to the staged rows' first samples
+  long long B0 = 0, B1 = 0;
+  unsigned sf_lo = 0u;
+  float dyf = 0.f;
+  if (FX) {
+    B0 = __double2ll_rd(xrow * 4294967296.0) - ((long long)kf0 << 32);
+    B1 = __double2ll_rd((xrow + xline) * 4294967296.0) - ((long long)kf1 << 32);
+    sf_lo = (unsigned)__double2ll_rd(ax1.sf * 4294967296.0);   // sf < 1 on this route
+    dyf = (float)dy;
+  }
   for (int c = c0 + wave; c < cend; c += NT / 64) {
     const int ct = c - c0;
+    float v;
+    if (FX) {
+      const float dxf = reinterpret_cast<const float *>(cdx)[ct];
+      const long long cx = reinterpret_cast<const long long *>(cxs)[ct];
+      float R[4];
+#pragma unroll
+      for (int ln = 0; ln < 2; ++ln) {
+        const unsigned long long X = (unsigned long long)((ln ? B1 : B0) + cx);
+        const unsigned j = (unsigned)(X >> 32), lo = (unsigned)X;
+        const float *p = reinterpret_cast<const float *>(ln ? row1 : row0) + j;
+        const float s0 = p[0], s1 = p[1], s2 = p[2];
+        const unsigned lo2 = lo + sf_lo;        // the next raster pixel: same window, or one sample on (sf <= 0.5)
+        const bool cy = lo2 < lo;
+        const float a2 = cy ? s1 : s0, b2 = cy ? s2 : s1;
+        const float t0 = __fmul_rn((float)lo, 0x1p-32f), t1 = __fmul_rn((float)lo2, 0x1p-32f);
+        // (1-t) a + t b as two FMAs, a - t a first: the samples are magnitudes (>= 0), so both terms are non-negative and each
+        // rounding is relative to the RESULT -- fma(t, b - a, a) rounds b - a, an error of 2^-24 |b - a| that is several ulp
+        // of a result much smaller than the step between its two samples
+        R[2 * ln] = lerp2(s0, s1, t0);
+        R[2 * ln + 1] = lerp2(a2, b2, t1);
+      }
+      v = lerp2(lerp2(R[0], R[1], dxf), lerp2(R[2], R[3], dxf), dyf);
+    } else {
     const double dx = cdx[ct];
     float R00, R01, R10, R11;
     if (EXACT) {
@@ -204,7 +250,6 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
       R10 = raster_tap_fast<MODE>(x00 + xline, row1, kf1);           // line ky+1 >= 1: coordinate > 0
       R11 = raster_tap_fast<MODE>(x00 + xline + ax1.sf, row1, kf1);
     }
-    float v;
     if (EXACT) {
       // first dimension (lines) outermost: wy0*(wx0*a00 + wx1*a01) + wy1*(wx0*a10 + wx1*a11)
       const double wx0 = 1.0 - dx, wy0 = 1.0 - dy;
@@ -215,6 +260,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
       const double top = fma(dx, (double)R01 - (double)R00, (double)R00);
       const double bot = fma(dx, (double)R11 - (double)R10, (double)R10);
       v = (float)fma(dy, bot - top, top);
+    }
     }
     if (live) o[(size_t)c * q.h_out] = v;
     if (COLSUM) colT[ct * 65 + lane] = v;

@@ -91,7 +91,7 @@ static int smooth_passes(tsdr_ctx *ctx, double2 *data, double2 *scratch, size_t 
   double2 *src = data, *dst = scratch;
   size_t n = N, s = 1;
   for (unsigned r : rad) {
-    hipLaunchKernelGGL(k_fft64_pass, dim3(stream_grid(ctx, N / r)), dim3(256), 0, ctx->stream, (const double2 *)src, dst, N, n, s, r, sign);
+    TSDR_LAUNCH(ctx, "fft64_pass", k_fft64_pass, dim3(stream_grid(ctx, N / r)), dim3(256), 0, (const double2 *)src, dst, N, n, s, r, sign);
     n /= r; s *= r;
     std::swap(src, dst);
   }
@@ -111,7 +111,7 @@ int fft64_d(tsdr_ctx *ctx, double2 *data, double2 *scratch, size_t N, int dir) {
   if (m == 1) {
     int rc = smooth_passes(ctx, data, scratch, N, rad, sign);
     if (rc) return rc;
-    if (dir > 0) hipLaunchKernelGGL(k_scale64, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, data, N, 1.0 / (double)N);
+    if (dir > 0) TSDR_LAUNCH(ctx, "fft64_scale", k_scale64, dim3(stream_grid(ctx, N)), dim3(256), 0, data, N, 1.0 / (double)N);
     return TSDR_OK;
   }
   size_t L = 1;
@@ -124,16 +124,23 @@ int fft64_d(tsdr_ctx *ctx, double2 *data, double2 *scratch, size_t N, int dir) {
   }
   std::vector<unsigned> two;
   for (size_t v = L; v > 1; v >>= 1) two.push_back(2u);
-  hipLaunchKernelGGL(k_blue64_prep, dim3(stream_grid(ctx, L)), dim3(256), 0, ctx->stream, (const double2 *)data, N, L, sign, a, b);
-  int rc = smooth_passes(ctx, a, t, L, two, -1.0);
+  auto checked = [&](const char *what) {   // a launch failure must surface here, not as the sticky error of a later, unrelated launch
+    const hipError_t le = hipGetLastError();
+    return le == hipSuccess ? (int)TSDR_OK : hip_fail(ctx, le, what);
+  };
+  hipLaunchKernelGGL(k_blue64_prep, dim3(stream_grid(ctx, L)), dim3(256), 0, ctx->launch_stream, (const double2 *)data, N, L, sign, a, b);
+  int rc = checked("fft64: k_blue64_prep");
+  if (!rc) rc = smooth_passes(ctx, a, t, L, two, -1.0);
   if (!rc) rc = smooth_passes(ctx, b, t, L, two, -1.0);
   if (!rc) {
-    hipLaunchKernelGGL(k_mul64, dim3(stream_grid(ctx, L)), dim3(256), 0, ctx->stream, a, (const double2 *)b, L);
-    rc = smooth_passes(ctx, a, t, L, two, +1.0);
+    hipLaunchKernelGGL(k_mul64, dim3(stream_grid(ctx, L)), dim3(256), 0, ctx->launch_stream, a, (const double2 *)b, L);
+    rc = checked("fft64: k_mul64");
+    if (!rc) rc = smooth_passes(ctx, a, t, L, two, +1.0);
   }
   if (!rc) {
     const double g = (1.0 / (double)L) * (dir > 0 ? 1.0 / (double)N : 1.0);
-    hipLaunchKernelGGL(k_blue64_post, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, (const double2 *)a, N, sign, g, data);
+    hipLaunchKernelGGL(k_blue64_post, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->launch_stream, (const double2 *)a, N, sign, g, data);
+    rc = checked("fft64: k_blue64_post");
   }
   hipError_t e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(a); (void)hipFree(b); (void)hipFree(t);

@@ -31,9 +31,6 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
                  unsigned long long *keys, float *proj, const GuardArgs &g, bool *can, bool plan_only);
 int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys);
-int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
-                          const ProjLayout *have, const float *img_c, int frames_c, const unsigned long long *keys_c, int do_align,
-                          float alpha, float *state, float *frames_out, int *sync_idx, uint2 *top2);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx);
@@ -228,42 +225,68 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
   return tsdr_frames_combine_d(ctx, sync, img, keys, nf, alpha, do_align, imageOut_state, frames_out, sync_idx);
 }
 
-// ---- the same body software-pipelined across successive buffers ------------------------------------------------
-// What bounds the three stages of a buffer is different: the raster launch R is held by the memory system (its store
-// stream), shift + IIR (C) likewise, while the vsync statistics (B: k_beta) are a chain of LDS latencies that leaves
-// the memory system idle.  B(k) needs R(k) and C(k) needs B(k), but C(k-1) and B(k) are independent: submit(k)
-// enqueues
-//        R(k)   ->   [ B(k) + C(k-1) ]  as ONE launch (k_tail)
-// on the context's stream, so shift + IIR of a buffer rides along with the statistics of the next one and a buffer
-// costs two launches instead of three.  C(k) is thus enqueued by submit(k+1) -- or by the flush: outputs of a
-// submission are complete (in stream order) after the next submission or tsdr_frames_flush.  Two image / key /
-// projection slots alternate between buffers.
-// Tried on MI355X and dropped: R on one stream with B + C (0.198 vs 0.183 ms per buffer: the two memory-bound
-// launches slow each other down) or B alone (0.196 vs 0.175 ms) on a second stream -- an event hand-over between two
-// HIP streams costs 6-13 us on this stack, more than B is long.
+// ---- the same body pipelined across successive buffers ----------------------------------------------------------
+// Half of a buffer's sequence is a latency-bound tail (vsync statistics, sync guard, shift + IIR: chains of LDS and L2
+// latencies that leave most of the machine idle) behind one throughput-bound launch (raster / images).  Two independent
+// capture streams on one GPU fill each other's gaps (round 3: +29 % raster-free, +7 % with rasters); the same overlap is
+// available to ONE capture stream, because the tail of buffer k and the image launch of buffer k+1 are independent:
+//     image lane:  R(k)      R(k+1)            R(k+2)  ...          back to back
+//     tail lane :       [R(k) done] B(k) G(k) C(k)  [R(k+1) done] B(k+1) ...
+// The image launches of successive submissions go to one internal HIP stream, the tails to a second one created with
+// the highest stream priority -- its few, short-lived workgroups take the slots the image kernel's workgroups free
+// instead of queueing behind thousands of them (without the priority, shift + IIR beside the image kernel is stretched
+// to the image kernel's length: rocprofv3 trace in profiles/r04_*).  Hand-overs: one event per buffer from the image lane
+// to the tail lane (its latency delays the tail, which has the slack, never the image lane), and one from the tail of
+// submission k to the image launch of submission k+3, which reuses its image / key / projection slot -- long satisfied
+// when it is reached.  The sequential couplings of the loop (lagged s_y, IIR recurrence) all sit in shift + IIR, i.e. in
+// stream order on the tail lane.
+// The caller's inputs are ordered through the context's stream: a submission waits for whatever that stream holds at
+// the time of the call, and tsdr_frames_flush orders the context's stream behind everything submitted.
+// History (rounds 1-3, measured and dropped): R on one stream and B + C on another without priorities (the two launches
+// slowed each other down); B(k) + C(k-1) as one launch ("k_tail": 43 us = 17 + 22, no overlap inside the launch); round 4's
+// first form, whole buffers alternating between two equal streams (+10 % raster-free, 0 % with rasters).
 }  // extern "C"
 
 namespace tsdr {
-static int pipe_combine_pending(tsdr_ctx *ctx) {
-  tsdr_ctx::PipePending &p = ctx->pipe_pending;
-  if (!p.valid) return TSDR_OK;
-  int rc = shift_iir_d(ctx, (tsdr_sync *)p.sync, p.img, (size_t)TSDR_RENDER_H * TSDR_RENDER_W, TSDR_RENDER_H, TSDR_RENDER_W, p.frames,
-                       p.keys, p.do_align, p.alpha, p.state, p.frames_out, p.do_align ? p.sync_idx : nullptr);
-  if (rc) return rc;
-  p.valid = false;
+static int lanes_create(tsdr_ctx *ctx) {
+  if (ctx->lane[0]) return TSDR_OK;
+  int lo = 0, hi = 0;
+  TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically: hi <= lo)
+  TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[0], hipStreamNonBlocking));
+  for (int l = 1; l < 3; ++l) {
+    if (ctx->opt_pipe_priority) TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->lane[l], hipStreamNonBlocking, hi));
+    else TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
+  }
+  for (int i = 0; i < tsdr_ctx::kPipeSlots; ++i) {
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stat[i], hipEventDisableTiming));
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[i], hipEventDisableTiming));
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
+  }
+  TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
   return TSDR_OK;
 }
 
-// everything submitted so far is enqueued; the stream then holds all of it.  Every entry point that synchronises,
-// retargets or destroys the context, or that touches a SyncXY state / the IIR state outside the pipeline, calls this
-// first, so the deferred shift + IIR never runs out of order or on freed memory.
+// everything submitted so far is ordered before whatever the context's stream receives next.  Every entry point that
+// synchronises, retargets or destroys the context, or that touches a SyncXY state / the IIR state outside the pipeline,
+// calls this first.
 int pipe_drain(tsdr_ctx *ctx) {
   if (!ctx || ctx->pipe_n == 0) return TSDR_OK;
-  int rc = pipe_combine_pending(ctx);
-  if (rc) return rc;
+  // the tails run in submission order on one stream: the latest one is behind everything else
+  if (ctx->pipe_last_slot >= 0) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->pipe_last_slot], 0));
   ctx->pipe_n = 0;
   return TSDR_OK;
 }
+
+// host-side wait for both lanes (workspace reallocation, destruction)
+void pipe_sync_lanes(tsdr_ctx *ctx) {
+  for (auto l : ctx->lane) if (l) (void)hipStreamSynchronize(l);
+}
+
+struct LaneScope {  // launches of this scope go to a lane
+  tsdr_ctx *ctx; hipStream_t saved;
+  LaneScope(tsdr_ctx *c, int lane) : ctx(c), saved(c->launch_stream) { c->launch_stream = c->lane[lane]; }
+  ~LaneScope() { ctx->launch_stream = saved; }
+};
 }  // namespace tsdr
 
 extern "C" {
@@ -281,58 +304,83 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   if (nb == 0) return TSDR_OK;
   const int F = (int)nb;
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
-  // The two image slots sit nb frames apart, so a submission whose frame count differs from the one in flight (S or
-  // nEch changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images the pending shift + IIR still has to
-  // read: that one is enqueued first.
-  if (ctx->pipe_n > 0 && ctx->pipe_nb != nb) {
+  constexpr int NS = tsdr_ctx::kPipeSlots;
+  rc = lanes_create(ctx);
+  if (rc) return rc;
+  // The image slots sit nb frames apart, so a submission whose frame count differs from the one in flight (S or nEch
+  // changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images a tail still has to read: the pipeline runs
+  // empty first (a configuration change, not a steady-state event).
+  if (ctx->pipe_nb != nb) {
     rc = pipe_drain(ctx);
     if (rc) return rc;
+    pipe_sync_lanes(ctx);
+    for (bool &u : ctx->ev_tail_used) u = false;
+    ctx->pipe_seq = 0;
   }
   ctx->pipe_nb = nb;
-  const unsigned slot = (unsigned)(ctx->pipe_n & 1ull);
-  float *img2 = (float *)ctx->scratch(WS_IMG, 2 * nb * npx * 4);
-  unsigned long long *keys2 = (unsigned long long *)ctx->scratch(WS_KEYS, 2 * nb * 2 * 8);
-  if (!img2 || !keys2) return TSDR_ENOMEM;
-  float *img = img2 + (size_t)slot * nb * npx;
-  unsigned long long *keys = keys2 + (size_t)slot * nb * 2;
+  const int slot = (int)(ctx->pipe_seq % (unsigned long long)NS);
+  // (workspaces first: growing one synchronises and frees what the lanes may be using)
+  float *img3 = (float *)ctx->scratch(WS_IMG, NS * nb * npx * 4);
+  unsigned long long *keys3 = (unsigned long long *)ctx->scratch(WS_KEYS, NS * nb * 2 * 8);
+  if (!img3 || !keys3) return TSDR_ENOMEM;
+  float *img = img3 + (size_t)slot * nb * npx;
+  unsigned long long *keys = keys3 + (size_t)slot * nb * 2;
   float *proj = nullptr;
   ProjLayout plan{}, got{};
   PrecisionScope scope(ctx);
   GuardPlan gp;
-  rc = guard_prepare(ctx, sync, S, y_t, x_t, do_align, F, (int)slot, 2, &gp);
+  rc = guard_prepare(ctx, sync, S, y_t, x_t, do_align, F, slot, NS, &gp);
   if (rc) return rc;
   if (do_align) {
     rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, nullptr,
                            &plan, true);
     if (rc) return rc;
-    rc = sync_workspace(sync, F, (int)slot, 2, plan.ncp ? &plan : nullptr, &proj, nullptr);
+    rc = sync_workspace(sync, F, slot, NS, plan.ncp ? &plan : nullptr, &proj, nullptr);
     if (rc) return rc;
   }
-  rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj, &got,
-                         false, keys);
-  if (rc) return rc;
-  tsdr_ctx::PipePending &p = ctx->pipe_pending;
-  uint2 *top2 = gp.on ? gp.top2 : nullptr;
-  if (do_align && p.valid && p.do_align && p.sync == sync) {
-    // the tail launch: statistics of this buffer + shift/IIR of the previous one
-    rc = sync_scan_and_shift_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, p.img, p.frames, p.keys, 1, p.alpha, p.state,
-                               p.frames_out, p.sync_idx, top2);
+  {
+    LaneScope image_lane(ctx, 0);
+    // inputs: whatever the context's stream holds now (uploads, a producer's kernels, an earlier call's launches) comes
+    // first.  An idle stream -- the steady state of a caller that only submits -- needs no fence.
+    if (hipStreamQuery(ctx->stream) != hipSuccess) {
+      (void)hipGetLastError();  // (hipErrorNotReady is a status here, not a failure for the next launch check to find)
+      TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
+      TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->lane_in, 0));
+    }
+    // this slot's previous user: submission k - NS, whose tail read its images / keys / sums
+    if (ctx->ev_tail_used[slot]) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->ev_tail[slot], 0));
+    rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj,
+                           &got, false, keys);
     if (rc) return rc;
-    p.valid = false;
-  } else {
-    rc = pipe_combine_pending(ctx);
-    if (rc) return rc;
+    TSDR_HIP(ctx, hipEventRecord(ctx->ev_img[slot], ctx->lane[0]));
+  }
+  {
+    LaneScope tail_lane(ctx, 1);
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[1], ctx->ev_img[slot], 0));
     if (do_align) {
-      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, top2);
+      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr);
       if (rc) return rc;
+      if (gp.on) {
+        rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
+        if (rc) return rc;
+      }
     }
   }
-  if (gp.on) {  // the guard's launch follows the statistics of THIS buffer; its shift + IIR comes later
-    rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
+  {
+    const int cl = ctx->opt_pipe_lanes == 3 ? 2 : 1;
+    LaneScope iir_lane(ctx, cl);
+    if (cl == 2) {
+      TSDR_HIP(ctx, hipEventRecord(ctx->ev_stat[slot], ctx->lane[1]));
+      TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[2], ctx->ev_stat[slot], 0));
+    }
+    rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
+                     do_align ? sync_idx : nullptr);
     if (rc) return rc;
+    TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[cl]));
   }
-  p.valid = true; p.sync = sync; p.img = img; p.frames = F; p.do_align = do_align; p.slot = (int)slot; p.keys = keys;
-  p.alpha = alpha; p.state = imageOut_state; p.frames_out = frames_out; p.sync_idx = sync_idx;
+  ctx->ev_tail_used[slot] = true;
+  ctx->pipe_last_slot = slot;
+  ++ctx->pipe_seq;
   ++ctx->pipe_n;
   return TSDR_OK;
 }

@@ -912,10 +912,11 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.tiles_l = dn ? (y_t - 2) / 63 + 1 : (int)ceil_div((size_t)y_t, 64);
     q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
     q.inv_tiles_p = 1.0f / (float)q.tiles_p;
-    // staging lanes per line: the power of two that wastes the fewest lane slots for this W
+    // staging lanes per line: a lane issues its loads four at a time, lpl samples apart -- the power of two that wastes the
+    // fewest of the ceil(W / 4 lpl) * 4 lpl load slots of a line (see plan_down)
     int best = 0; long best_slots = 1L << 60;
     for (int lg = 2; lg <= 6; ++lg) {
-      const long lpl = 1L << lg, slots = (long)ceil_div((size_t)q.W, (size_t)lpl) * lpl;
+      const long chunk = 4L << lg, slots = (long)ceil_div((size_t)q.W, (size_t)chunk) * chunk;
       if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
     }
     q.lpl_log = best;
@@ -982,17 +983,22 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
     for (int ci = 0; ci < 5 && cand[ci] > 0; ++ci) {
       const int TC = cand[ci];
       const long DPX = (long)((double)(TC - 1) * sfx) + 2;
-      const long W = (long)((double)DPX * sf) + 4 + (exact ? 0 : 1);
+      const long W = (long)((double)DPX * sf) + 4 + (exact ? 0 : (sf <= 0.5 ? 2 : 1));
       const size_t lds = (((size_t)NL * (size_t)(W | 1) * sb + 15) & ~(size_t)15) + (size_t)TC * 20 + (size_t)NL * 4;
       if (lds <= cap && W < (1 << 20)) {
         pl.fused = true;
         pl.lds = lds;
-        pl.mode = exact ? DM_EXACT : DM_FAST_F32;
+        // FAST: fixed-point taps where a raster pixel spans at most half a sample (the second tap of a line then lies in the
+        // first one's three-sample window); one more staged sample for that window
+        pl.mode = exact ? DM_EXACT : (sf <= 0.5 ? DM_FAST_FX : DM_FAST_F32);
         pl.q.S = (unsigned)S; pl.q.y_t = y_t; pl.q.x_t = x_t; pl.q.h_out = h_out; pl.q.w_out = w_out;
         pl.q.TC = TC; pl.q.NL = (int)NL; pl.q.W = (int)W; pl.q.tiles_c = (int)ceil_div((size_t)w_out, (size_t)TC);
+        // staging lanes per line: a lane issues its loads four at a time, lpl samples apart, so a line costs
+        // ceil(W / 4 lpl) * 4 lpl load slots -- the power of two that wastes the fewest (round 4: the former rule counted
+        // ceil(W / lpl) * lpl and, for W = 29, chose 32 lanes per line: three of every four loads were clamped duplicates)
         int best = 2; long best_slots = 1L << 60;
         for (int lg = 2; lg <= 6; ++lg) {
-          const long lpl = 1L << lg, slots = (long)ceil_div((size_t)W, (size_t)lpl) * lpl;
+          const long chunk = 4L << lg, slots = (long)ceil_div((size_t)W, (size_t)chunk) * chunk;
           if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
         }
         pl.q.lpl_log = best;
@@ -1035,8 +1041,10 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
       if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, DS_NONE, "down_fused_iq_exact", pl.lds); }
       else if (psum) {
         pl.q.proj = proj; pl.q.proj_stride = proj_floats(h_out, w_out, *got); pl.q.keys = keys;
-        DOWNK(true, DM_FAST_F32, DS_PSUM, "down_fused_iq_sums", lds_main + (kDownNT + (size_t)pl.q.TC) * 4);
+        if (pl.mode == DM_FAST_FX) { DOWNK(true, DM_FAST_FX, DS_PSUM, "down_fused_iq_sums", lds_main + (kDownNT + (size_t)pl.q.TC) * 4); }
+        else { DOWNK(true, DM_FAST_F32, DS_PSUM, "down_fused_iq_sums", lds_main + (kDownNT + (size_t)pl.q.TC) * 4); }
       }
+      else if (pl.mode == DM_FAST_FX) { DOWNK(true, DM_FAST_FX, DS_NONE, "down_fused_iq", pl.lds); }
       else { DOWNK(true, DM_FAST_F32, DS_NONE, "down_fused_iq", pl.lds); }
     } else {
       DOWNK(false, DM_EXACT, DS_NONE, "down_fused_f32_exact", pl.lds);

@@ -629,17 +629,20 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
   if (e != hipSuccess) { (void)hipFree(scratch); tsdr_resampler_free(r); return hip_fail(ctx, e, "init_resampler upload"); }
   // h = ifft(H0) .* blackman  (ifft on ComplexF32 data in the reference, the window and everything after it in f64);
   // H = fft(h) .* (-1)^k -- on the device in f64 (fft64.hip)
-  int rc = fft64_d(ctx, r->H, scratch, N, +1);
-  if (!rc) {
-    hipLaunchKernelGGL(k_window64, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->H, N);
-    rc = fft64_d(ctx, r->H, scratch, N, -1);
-  }
-  if (!rc) {
-    hipLaunchKernelGGL(k_altsign64, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->stream, r->H, N);
-    if (r->Hs) hipLaunchKernelGGL(k_herm_half, dim3(stream_grid(ctx, N / 2 + 1)), dim3(256), 0, ctx->stream, (const double2 *)r->H, N, r->Hs);
-    e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = hip_fail(ctx, e, "init_resampler finalize");
-  }
+  // (every launch is checked where it is made: a failure here must not surface as the sticky error of a later, unrelated
+  // launch and leave a silently wrong filter behind)
+  auto finish = [&]() -> int {
+    int rc2 = fft64_d(ctx, r->H, scratch, N, +1);
+    if (rc2) return rc2;
+    TSDR_LAUNCH(ctx, "lpf_window64", k_window64, dim3(stream_grid(ctx, N)), dim3(256), 0, r->H, N);
+    rc2 = fft64_d(ctx, r->H, scratch, N, -1);
+    if (rc2) return rc2;
+    TSDR_LAUNCH(ctx, "lpf_altsign64", k_altsign64, dim3(stream_grid(ctx, N)), dim3(256), 0, r->H, N);
+    if (r->Hs) TSDR_LAUNCH(ctx, "lpf_herm_half", k_herm_half, dim3(stream_grid(ctx, N / 2 + 1)), dim3(256), 0, (const double2 *)r->H, N, r->Hs);
+    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TSDR_OK;
+  };
+  int rc = finish();
   (void)hipFree(scratch);
   if (rc) { tsdr_resampler_free(r); return rc; }
   *out = r;

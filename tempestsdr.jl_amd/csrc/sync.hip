@@ -557,22 +557,6 @@ __device__ __forceinline__ void shift_iir_wg(const IirArgs &A, unsigned wg, unsi
 
 __global__ __launch_bounds__(256) void k_shift_iir(IirArgs A) { shift_iir_wg(A, blockIdx.x, 256u); }
 
-// The pipeline's tail launch: the vsync statistics of buffer k (k_beta workgroups, first in dispatch order) and shift +
-// IIR of buffer k-1 (the rest) in ONE grid.  The two are independent; the first is a chain of LDS latencies that
-// leaves the memory system idle, the second a stream that leaves the ALUs idle, so side by side they take little
-// more than the longer one -- with plain kernel boundaries around them instead of cross-stream events (measured:
-// an event hand-over between two HIP streams costs 6-13 us on this stack, more than it could hide).
-template <int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_tail(BetaArgs B, unsigned nbb, unsigned nB, IirArgs I) {
-  extern __shared__ float sh[];
-  // the two kinds of workgroup are interleaved in dispatch order in proportion to their numbers, so that every CU
-  // holds some of each from the start: block i is the b0-th statistics workgroup iff floor((i+1) nB / n) > floor(i nB / n)
-  const unsigned long long i = blockIdx.x, n = gridDim.x;
-  const unsigned b0 = (unsigned)(i * nB / n), b1 = (unsigned)((i + 1) * nB / n);
-  if (b1 > b0) beta_wg<NWV>(B, (int)(b0 % nbb), (int)(b0 / nbb), sh);
-  else shift_iir_wg(I, (unsigned)i - b0, 64u * NWV);
-}
-
 // standalone vsync: publish (s_y,s_x) of one scanned image and roll the pending s_y
 __global__ void k_publish(const unsigned long long *__restrict__ keys, const int *__restrict__ pend_in,
                           int *__restrict__ pend_out, int *__restrict__ s_yx, int sy_current) {
@@ -671,7 +655,11 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
   size_t lds = 0;
   unsigned nbb = 0;
   beta_args(s, proj, pl, keys, frames, &B, &nbb, &lds, top2);
-  TSDR_LAUNCH(ctx, "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
+  if (ctx->opt_beta_waves == 4) {
+    TSDR_LAUNCH(ctx, "sync_beta", k_beta<4>, dim3(nbb, (unsigned)frames), dim3(64 * 4), lds, B);
+  } else {
+    TSDR_LAUNCH(ctx, "sync_beta", k_beta<kBetaWaves>, dim3(nbb, (unsigned)frames), dim3(64 * kBetaWaves), lds, B);
+  }
   return TSDR_OK;
 }
 
@@ -688,6 +676,7 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
 // number of resident workgroups.  Hand-over between items of different CUs: every storing wavefront drains its stores,
 // workgroup barrier, one lane release-fences and bumps the frame's counter; the consumer polls the counter, acquire-
 // fences, barrier (MI355X_MICROARCH.md, inter-workgroup visibility).  The last workgroup to leave zeroes the queue words.
+constexpr int kGuardQuiet = 4;
 struct GuardSync {          // device words, all zero between launches
   unsigned ticket, exited;
   unsigned done[1];         // [2 * frames]: items A / B finished per LIST position
@@ -845,6 +834,12 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
 #else
   GuardAllArgs a{};
   if (!guard_image_plan(ctx, S, y_t, x_t, s->y_t, s->x_t, &a.dq, &a.lds_bytes)) return TSDR_OK;
+  {  // the launch's dynamic LDS plus k_guard's static arrays (list, colk, ticket words: < 4 KiB) must fit the 64 KiB a
+     // workgroup gets without opting in -- an exotic geometry's exact tiles may take up to 60 KiB on their own; the frame
+     // loop then falls back to whole buffers in TSDR_EXACT, as for geometries without a fused exact kernel
+    const size_t lds_a = ((a.lds_bytes + 15) & ~(size_t)15) + (size_t)a.dq.TC * 65 * 4;
+    if (std::max(lds_a, kProjLds) + 4096 > 65536) return TSDR_OK;
+  }
   if (can) *can = true;
   if (plan_only || frames <= 0) return TSDR_OK;
   const int y = s->y_t, x = s->x_t;
@@ -858,7 +853,7 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     const size_t words = 2 + 2 * (size_t)kGuardChunk;
     if (!ctx->guard_sync) {
       TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_sync, words * 4));
-      TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_sync, 0, words * 4, ctx->stream));
+      TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_sync, 0, words * 4, ctx->launch_stream));
     }
     a.g = g;
     a.g.top2 = g.top2 + (size_t)f0 * (size_t)(g.nbx + g.nby);
@@ -876,7 +871,19 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     a.lds_bytes = (a.lds_bytes + 15) & ~(size_t)15;
     const size_t lds = std::max(std::max(a.lds_bytes + (size_t)a.dq.TC * 65 * 4, kProjLds), lds_beta);
     a.lds_total = lds;
-    const unsigned grid = g.count_only ? 1u : (unsigned)ncu;   // (one workgroup per CU: 64 / 128 / 512 measured no better)
+    // one workgroup per CU (64 / 128 / 512 measured no better) -- while frames are being flagged.  The launch's cost when
+    // nothing is flagged is getting 512-thread workgroups onto every CU, which takes 5 us on an idle GPU and 30-90 us
+    // beside the pipeline's image kernel (rocprofv3 trace, round 4): after kGuardQuiet launches in a row whose
+    // predecessors flagged nothing (the pinned mirror of the counters, read without synchronising) the grid shrinks to an
+    // eighth.  The queue works with any number of workgroups, so this changes how fast a flagged frame is redone,
+    // never what is computed.
+    unsigned grid = g.count_only ? 1u : (unsigned)ncu;
+    if (!g.count_only && ctx->guard_host) {
+      const unsigned fl = (unsigned)__atomic_load_n(ctx->guard_host, __ATOMIC_RELAXED);
+      if (fl != ctx->guard_grid_seen_f) { ctx->guard_grid_seen_f = fl; ctx->guard_quiet = 0; }
+      else if (ctx->guard_quiet < 1000000) ++ctx->guard_quiet;
+      if (ctx->guard_quiet >= kGuardQuiet) grid = std::max(8u, (unsigned)ncu / 8u);
+    }
     TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
   }
   return TSDR_OK;
@@ -913,34 +920,6 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
   IirArgs I;
   iir_args(s, img, img_stride, h, w, frames, keys, do_align, alpha, state, frames_out, sync_idx, &I);
   TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, I);
-  if (do_align) s->cur ^= 1;
-  return TSDR_OK;
-}
-
-// the pipeline's tail: vsync statistics of one buffer (frames_b images -> keys_b; projections as in sync_scan_d) and
-// shift + IIR of the PREVIOUS buffer, one launch (k_tail)
-int sync_scan_and_shift_d(tsdr_sync *s, const float *img_b, size_t img_stride, int frames_b, unsigned long long *keys_b, float *proj,
-                          const ProjLayout *have, const float *img_c, int frames_c, const unsigned long long *keys_c, int do_align,
-                          float alpha, float *state, float *frames_out, int *sync_idx, uint2 *top2) {
-  tsdr_ctx *ctx = s->ctx;
-  const int y = s->y_t, x = s->x_t;
-  if (!proj || !keys_b) return TSDR_ENOMEM;
-  ProjLayout pl;
-  if (have) {
-    pl = *have;
-  } else {
-    pl = sync_proj_layout(s);
-    TSDR_LAUNCH(ctx, "sync_proj", k_proj, proj_grid(y, frames_b), proj_block(), proj_lds_bytes(), img_b, img_stride, y, x, proj,
-                proj_floats(y, x, pl), keys_b);
-  }
-  BetaArgs B;
-  IirArgs I;
-  size_t lds = 0;
-  unsigned nbb = 0;
-  beta_args(s, proj, pl, keys_b, frames_b, &B, &nbb, &lds, top2);
-  iir_args(s, img_c, img_stride, y, x, frames_c, keys_c, do_align, alpha, state, frames_out, sync_idx, &I);
-  const unsigned nB = nbb * (unsigned)frames_b, nC = (unsigned)ceil_div((size_t)y * x, (size_t)64 * kBetaWaves);
-  TSDR_LAUNCH(ctx, "sync_beta+shift_iir", k_tail<kBetaWaves>, dim3(nB + nC), dim3(64 * kBetaWaves), lds, B, nbb, nB, I);
   if (do_align) s->cur ^= 1;
   return TSDR_OK;
 }

@@ -181,9 +181,10 @@ class HipSearch:
         import torch
         self.torch, self.ctx, self.dev, self.world, self.rank, self.route = torch, ctx, dev, world, rank, route
 
-    def run(self, iq, n, n_lags, k0=0, log_scale=True):
+    def run(self, iq, n, n_lags, k0=0, log_scale=True, timing=None):
         """iq: device tensor of interleaved complex f32 (the first n samples are used).
-        Returns (device tensor of n_lags-k0 values, argmax index relative to k0, value)."""
+        Returns (device tensor of n_lags-k0 values, argmax index relative to k0, value).
+        timing: dict that accumulates wall seconds of the sharded route's stages (partial_s, all_reduce_s, finish_s)."""
         torch, ctx = self.torch, self.ctx
         route = self.route or search_route(n, n_lags, self.world)
         out = torch.empty(n_lags - k0, dtype=torch.float32, device=self.dev)
@@ -197,20 +198,31 @@ class HipSearch:
             return out, idx.value, val.value
         part = torch.empty(n_lags, dtype=torch.float32, device=self.dev)
 
+        def tick(key, t0):
+            if timing is not None:
+                timing[key] = timing.get(key, 0.0) + time.perf_counter() - t0
+
         def partial(m0, cnt):
+            t0 = time.perf_counter()
             ctx.call("tsdr_autocorr_partial_d", C.c_void_p(iq.data_ptr()), 1, int(n), int(m0), int(cnt), int(n_lags),
                      C.c_void_p(part.data_ptr()))
             ctx.synchronize()  # hand the buffer from the library's stream to torch's
+            tick("partial_s", t0)
             return part
 
         def all_reduce(buf):
-            import torch.distributed as dist
+            t0 = time.perf_counter()
             dist_all_reduce_sum(buf)
             torch.cuda.synchronize()
+            tick("all_reduce_s", t0)
 
         def finish(buf):
+            t0 = time.perf_counter()
             ctx.call("tsdr_autocorr_finish_d", C.c_void_p(buf.data_ptr()), int(k0), int(n_lags - k0), int(log_scale),
                      C.c_void_p(out.data_ptr()))
+            if timing is not None:
+                ctx.synchronize()
+            tick("finish_s", t0)
             return out
 
         if route == "sharded":
@@ -260,9 +272,37 @@ def bench_search(ctx, iq, n, n_lags, Fs, steps, world, rank, dev):
     ctx.synchronize()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    sharded = None
+    if world > 1:
+        # the exchange step north_star names (Autocorrelations.jl:27-29 is the sum being split), timed whether or not it pays at
+        # this window: route forced to "sharded" -- segment + halo partial sums, ONE all-reduce of n_lags f32, non-linear step after
+        hs2 = HipSearch(ctx, dev, world, rank, route="sharded")
+        tm = {}
+
+        def once_sharded(timing=None):
+            res, _, _ = hs2.run(iq, n, n_lags, timing=timing)
+            idx, val = C.c_size_t(0), C.c_float(0)
+            ctx.call("tsdr_argmax_d", C.c_void_p(res.data_ptr() + 4 * (pmin.value - 1)), int(pmax.value - pmin.value + 1), C.byref(idx), C.byref(val))
+            return idx.value
+        pos_s = once_sharded()
+        torch.cuda.synchronize()
+        import torch.distributed as dist
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            pos_s = once_sharded(tm)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        ms_s = (time.perf_counter() - t1) / steps * 1e3
+        sharded = {"ms_per_search": round(ms_s, 4), "all_reduce_bytes": 4 * int(n_lags), "ms_all_reduce": round(tm.get("all_reduce_s", 0.0) / steps * 1e3, 4),
+                   "ms_partial_sums": round(tm.get("partial_s", 0.0) / steps * 1e3, 4), "ms_finish": round(tm.get("finish_s", 0.0) / steps * 1e3, 4),
+                   "transform_points_per_rank": sharded_route_points(n, n_lags, world), "same_argmax_as_route_above": bool(pos_s == pos),
+                   "note": "route forced to 'sharded' so that the all-reduce of the accumulators is timed at this window too; "
+                           "times are this rank's (rank 0) wall clock per stage, host synchronisations between stages included"}
     fv = float(Fs) / float(pmin.value + pos)  # rates_refresh[posMax] (keeps the reference's off-by-one label)
     alg = 8 * n + 4 * n_lags                  # SURVEY 8d B_ac
     return {"ms_per_search": round(ms, 4), "n": int(n), "lags": int(n_lags), "fv_found_hz": round(fv, 4),
+            **({"search_sharded": sharded} if sharded else {}),
             "algorithmic_bytes": alg, "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1),
             "transform_points": single_route_points(n, n_lags),
             "mode": ((("single-GPU, native length-n/2 mixed-radix transform" if single_route_points(n, n_lags) == n // 2 else

@@ -74,3 +74,27 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert d["strong"] and "error" not in d["strong"] and d["strong"]["value"] > 0, d["strong"]
     assert d["search"] and "error" not in d["search"], d["search"]
     assert "replicated" in d["search"]["mode"]  # the reference's window: sharding cannot pay
+
+
+def test_bench_gpus_n_launched_bare_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with no torch.distributed.run around it and no WORLD_SIZE in the environment: the
+    parent must not touch the GPU, start the two ranks as a child process, relay rank 0's single JSON line and exit 0.
+    Both ranks share cuda:0 over gloo here (TSDR_BENCH_SHARE_ONE_GPU=1); the line must carry the forced-sharded search
+    leg with the size and the time of its all-reduce (SURVEY 8e / Autocorrelations.jl:27-29)."""
+    import json
+    if _ngpu() < 1:
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["TSDR_BENCH_SHARE_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--repeats", "2", "--search-steps", "2", "--no-cpu", "--no-ingest", "--no-extra"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, f"bare bench --gpus 2 failed:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    ss = d["search"]["search_sharded"]
+    assert ss["all_reduce_bytes"] == 4 * d["search"]["lags"] and ss["ms_all_reduce"] > 0 and ss["ms_per_search"] > 0
+    assert ss["same_argmax_as_route_above"] is True
+    assert d["pipeline"] and d["pipeline"]["raster"]["value"] > 0 and d["pipeline"]["fused"]["value"] > 0
