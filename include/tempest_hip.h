@@ -101,6 +101,9 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 of the tap-based kernel with its own partial sums.  Default 0.  Results within the FAST tolerance either way.
  *   "sync_guard_auto" 1 (default): the adaptive whole-buffer TSDR_EXACT route described above; 0: flagged frames are always
  *                 re-evaluated one by one.
+ *   "raster_split" 0 (default): the TSDR_FAST frame loop with rasters is ONE launch that walks every raster pixel and forms raster,
+ *                 600x800 image and projection sums; 1: rasters by the store-aligned ("sheared") raster-only kernel + images by the
+ *                 raster-free kernel (two launches, IQ read twice: measured slower, kept as the A/B); 2: the same unsheared.
  *   "beta_waves"  wavefronts per workgroup of the vsync statistics kernel: 4 (default) or 8; identical results.
  *   "pipe_lanes" / "pipe_priority"  tsdr_frames_submit_d's internal streams (before the first submission only): 2 (default;
  *                 3 = shift + IIR on a stream of its own) / 1 (default; 0 = no stream priority for the tails).

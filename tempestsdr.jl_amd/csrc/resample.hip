@@ -963,6 +963,8 @@ int resize2d_d(tsdr_ctx *ctx, const float *img, int h_in, int w_in, int h_out, i
 }
 
 struct DownPlan { bool fused; int mode; DownParams q; size_t lds; };
+int raster_shear_d(tsdr_ctx *ctx, const float *in, size_t in_stride, size_t S, int y_t, int x_t, int frames, float *out,
+                   size_t out_stride, bool shear, bool *did, bool plan_only);
 
 static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool exact, bool wide_exact = false) {
   DownPlan pl;
@@ -1103,6 +1105,25 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
       if (rc) return rc;
       if (got) *got = pl;
       return TSDR_OK;
+    }
+  }
+  // FAST with a raster (option "raster_split"; A/B of round 4): the rasters by the store-aligned ("sheared") raster-only
+  // kernel of raster_shear.hip, the images + projection sums by the raster-free kernel -- two launches, IQ read twice,
+  // instead of the one walk that produces raster, image and sums with misaligned column stores
+  if (raster && ctx->precision == TSDR_FAST && cplx && ctx->opt_raster_split) {
+    const DownPlan dp = plan_down(S, y_t, x_t, h_out, w_out, false);
+    const double spp = (double)S / ((double)y_t * (double)x_t);
+    if (dp.fused && dp.q.TC >= 32 && spp <= 0.5 && !(y_t == h_out && x_t == w_out) && check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 64 && x_t >= 128) {
+      bool did = false;
+      int rc = raster_shear_d(ctx, in, in_stride, S, y_t, x_t, frames, raster, raster_stride, ctx->opt_raster_split == 1, &did, plan_only);
+      if (rc) return rc;
+      if (did) {
+        ProjLayout pl{};
+        rc = down_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, h_out, w_out, frames, down, down_stride, proj, got ? &pl : nullptr, plan_only, keys);
+        if (rc) return rc;
+        if (got) *got = pl;
+        return TSDR_OK;
+      }
     }
   }
   if (raster || (ctx->precision == TSDR_FAST && cplx)) {

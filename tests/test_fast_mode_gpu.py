@@ -354,3 +354,25 @@ def test_frames_fast_random_geometries(ctx, tsdr, seed):
         iq = ((r.standard_normal(S * nfr + 3) + 1j * r.standard_normal(S * nfr + 3)) * 1e-3).astype(np.complex64)
         res = fast_vs_oracle(ctx, tsdr, O, iq, S, y_t, x_t, 0.1, True, RTOL)
         assert res["n_frames"] == nfr, (S, y_t, x_t)
+
+
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("case", [
+    dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, nfr=3),    # C2: y_t mod 32 = 5
+    dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, nfr=2),    # C5: y_t mod 32 = 10
+    dict(Fs=2.0e6, x_t=1056, y_t=628, fv=60.0, nfr=3),    # y_t mod 32 = 20, ragged tiles on both axes
+    dict(Fs=3.0e6, x_t=1200, y_t=640, fv=50.0, nfr=2),    # y_t mod 32 = 0: columns already on the 128-byte grid
+])
+def test_frames_fast_sheared_raster_route(ctx, tsdr, synth, case, split):
+    """Option "raster_split" (round 4's A/B of the raster-writing kernel; off by default because it loses to the one-launch
+    walk: DESIGN.md section 4): the rasters by the store-aligned raster-only kernel (raster_shear.hip: every wave-store two
+    full 128-byte lines; 2 = the same kernel unsheared), images and projection sums by the raster-free kernel.  Same bar as
+    every FAST route: identical sync indices, rasters and frames within 6e-7 of the oracle."""
+    S = synth.samples_per_frame(case["Fs"], case["fv"])
+    iq = synth.synth_leak(case["Fs"], case["x_t"], case["y_t"], case["fv"], S * case["nfr"] + 123)
+    ctx.set_option("raster_split", split)
+    try:
+        r = fast_vs_oracle(ctx, tsdr, O, iq, S, case["y_t"], case["x_t"], 0.1, True, RTOL)
+    finally:
+        ctx.set_option("raster_split", 0)
+    assert r["n_frames"] == case["nfr"] and not r["ties"]
