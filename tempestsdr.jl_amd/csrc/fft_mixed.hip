@@ -50,6 +50,11 @@ struct MixDesc {
   const float2 *src_aux;             // SRC_MULH: the factor array
   double src_w8;                     // SRC_POWER with M = 2*src_n not a power of two: 8/M (else 0)
   FftEpilogue epi;                   // last pass: autocorrelation epilogue when epi.out != nullptr
+  // rows mode as getWelch's accumulator (GetSpectrum.jl:36-52): nothing is stored per transform; every workgroup walks
+  // tiles blockIdx.x, blockIdx.x + gridDim.x, ... of `rows` segments, adds abs2 of every spectrum it forms in registers and
+  // leaves ONE partial power spectrum, acc[blockIdx.x * R + k] (natural frequency order).  rows_real: the rows are real f32.
+  float *acc;
+  int rows_real;
 };
 
 // a = k_1*(R_2..R_m) + ... + k_m  ->  k_1*W_1 + ... + k_m*W_m  (uniform per workgroup: scalar code)
@@ -214,10 +219,82 @@ __global__ __launch_bounds__(256, 4) void k_fft_mix(const float2 *__restrict__ i
     }
     kmap[e] = (unsigned short)k;
   }
-  const unsigned bid = blockIdx.x;
   const unsigned work = R << logT;
   const float invR = 1.0f / (float)R;
   constexpr int NB = 8;
+  if (d.mode == FFT_ROWS && d.acc) {
+    // ---- segment spectra that never leave the chip: sum over this workgroup's rows of |X_row[k]|^2
+    constexpr int NACC = 16;            // work = R << logT <= 4096 elements = 16 per thread
+    float a[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) a[i] = 0.f;
+    const unsigned ntiles = (d.rows + T - 1u) >> logT;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const size_t row0 = (size_t)tile * T;
+      __syncthreads();   // twR / kmap (first trip); the previous tile's spectra have been read (later trips)
+      for (unsigned w0 = tid; w0 < work; w0 += 256 * NB) {
+        float2 v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const unsigned w = min(w0 + 256 * u, work - 1u);
+          const unsigned t = (unsigned)(((float)w + 0.5f) * invR), j = w - t * R;
+          const size_t row = row0 + t;
+          if (d.rows_real) v[u] = row < d.rows ? make_float2(reinterpret_cast<const float *>(in)[row * R + j], 0.f) : make_float2(0.f, 0.f);
+          else v[u] = row < d.rows ? in[row * R + j] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const unsigned w = w0 + 256 * u;
+          if (w < work) {
+            const unsigned t = (unsigned)(((float)w + 0.5f) * invR), j = w - t * R;
+            buf[j * TP + t] = v[u];
+          }
+        }
+      }
+      __syncthreads();
+      unsigned L = R;
+      for (int s = 0; s < d.nst; ++s) {
+        const unsigned r = d.rad[s];
+        switch (r) {
+          case 2: mix_stage<2>(buf, twR, R, L, logT, TP, tid); break;
+          case 3: mix_stage<3>(buf, twR, R, L, logT, TP, tid); break;
+          case 4: mix_stage<4>(buf, twR, R, L, logT, TP, tid); break;
+          case 5: mix_stage<5>(buf, twR, R, L, logT, TP, tid); break;
+          case 8: mix_stage<8>(buf, twR, R, L, logT, TP, tid); break;
+          case 9: mix_stage<9>(buf, twR, R, L, logT, TP, tid); break;
+          case 10: mix_stage<10>(buf, twR, R, L, logT, TP, tid); break;
+          case 25: mix_stage<25>(buf, twR, R, L, logT, TP, tid); break;
+          default: mix_stage<16>(buf, twR, R, L, logT, TP, tid); break;
+        }
+        L /= r;
+      }
+      // thread-fixed (row of the tile, position) slots: the same every trip, so the sums stay in registers
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        const unsigned w = tid + 256u * i;
+        if (w < work) {
+          const unsigned t = (unsigned)(((float)w + 0.5f) * invR), p = w - t * R;
+          const float2 x = buf[p * TP + t];
+          a[i] += x.x * x.x + x.y * x.y;
+        }
+      }
+    }
+    __syncthreads();
+    float *F = reinterpret_cast<float *>(buf);   // [T][R] row-of-tile sums, then added over the T rows in order
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+      const unsigned w = tid + 256u * i;
+      if (w < work) F[w] = a[i];
+    }
+    __syncthreads();
+    for (unsigned p = tid; p < R; p += 256) {
+      float S = F[p];
+      for (unsigned t = 1; t < T; ++t) S += F[t * R + p];
+      d.acc[(size_t)blockIdx.x * R + kmap[p]] = S;
+    }
+    return;
+  }
+  const unsigned bid = blockIdx.x;
 
   size_t base = 0, tbase = 0, row0 = 0;
   unsigned tile = 0, a = 0, kt = 0, arest = 0, col0 = 0;
@@ -792,6 +869,73 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
   for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
   const unsigned bid = blockIdx.x;
   float2 v[G::VMAX];
+  if (MODE == FFT_LAST && d.acc) {
+    // ---- getWelch's accumulator (see MixDesc::acc): rows = segments, T of them per tile, nothing stored per transform.
+    // A thread's step-3 slot (kk, t3) is the same for every tile, so abs2 of its RC outputs accumulates in registers.
+    float acc[RC];
+#pragma unroll
+    for (int k3 = 0; k3 < RC; ++k3) acc[k3] = 0.f;
+    const unsigned ntiles = (d.rows + (unsigned)T - 1u) >> LOGT;
+    const int t1 = tid / R23, r23 = tid - t1 * R23;
+    const int t3 = tid & (T - 1), kk = tid >> LOGT;
+    for (unsigned tile = bid; tile < ntiles; tile += gridDim.x) {
+      const unsigned row1 = (tile << LOGT) + (unsigned)t1;
+      const bool ok1 = tid < G::S1 && row1 < d.rows;
+      if (d.rows_real) {
+        const float *src = reinterpret_cast<const float *>(in) + (size_t)row1 * R + r23;
+#pragma unroll
+        for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok1 ? make_float2(src[n1 * R23], 0.f) : make_float2(0.f, 0.f);
+      } else {
+        const float2 *src = in + (size_t)row1 * R + r23;
+#pragma unroll
+        for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok1 ? src[n1 * R23] : make_float2(0.f, 0.f);
+      }
+      __syncthreads();  // twR (first trip); the previous tile's step-3 reads (later trips)
+      if (tid < G::S1) {
+        dft_nat<RA>(v);
+        const int n2 = r23 / RC;
+#pragma unroll
+        for (int k1 = 0; k1 < RA; ++k1) {
+          float2 x = v[k1];
+          if (k1) x = cmul(x, twR[(n2 * k1) * RC]);
+          buf[k1 * PLANE + r23 * T + t1] = x;
+        }
+      }
+      __syncthreads();
+      if (tid < G::S2) {
+        const int t = tid & (T - 1), q = tid >> LOGT, k1 = q / RC, n3 = q - k1 * RC;
+        float2 *p = buf + k1 * PLANE + n3 * T + t;
+#pragma unroll
+        for (int n2 = 0; n2 < RB; ++n2) v[n2] = p[n2 * RC * T];
+        dft_nat<RB>(v);
+#pragma unroll
+        for (int k2 = 0; k2 < RB; ++k2) {
+          float2 x = v[k2];
+          if (k2 || k1) x = cmul(x, twR[n3 * (k1 + RA * k2)]);
+          p[k2 * RC * T] = x;
+        }
+      }
+      __syncthreads();
+      if (tid < G::S3 && (tile << LOGT) + (unsigned)t3 < d.rows) {
+        const int k2 = kk / RA, k1 = kk - k2 * RA;
+        const float2 *p = buf + k1 * PLANE + k2 * RC * T + t3;
+#pragma unroll
+        for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T];
+        dft_nat<RC>(v);
+#pragma unroll
+        for (int k3 = 0; k3 < RC; ++k3) acc[k3] += v[k3].x * v[k3].x + v[k3].y * v[k3].y;
+      }
+    }
+    // the T segments of a tile sit in T adjacent lanes: added by a fixed xor tree, lane t3 = 0 stores
+#pragma unroll
+    for (int k3 = 0; k3 < RC; ++k3) {
+      float sres = acc[k3];
+#pragma unroll
+      for (int off = 1; off < T; off <<= 1) sres += __shfl_xor(sres, off, 64);
+      if (tid < G::S3 && t3 == 0) d.acc[(size_t)bid * R + (unsigned)(kk + RA * RB * k3)] = sres;
+    }
+    return;
+  }
   size_t base = 0, tbase = 0;
   unsigned col0 = 0, a = 0, kt = 0, arest = 0;
   // ---- step 1 inputs
@@ -1411,6 +1555,70 @@ static int fft_mixed_ex(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, 
   return TSDR_OK;
 }
 
+
+// getWelch's accumulation for any 2^a 3^b 5^c segment length up to 4096 without writing a segment spectrum: *nparts partial
+// power spectra of N floats each (natural order) land in `part` (room for fft_rows_welch_parts() of them)
+unsigned fft_rows_welch_parts(tsdr_ctx *ctx) { return (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 3u; }
+int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, float *part, unsigned *nparts, bool *did) {
+  *did = false;
+  if (N < 2 || N > 4096 || nbSeg == 0 || nbSeg >= (size_t(1) << 31)) return TSDR_OK;
+  // the whole segment as ONE factor of the generic LDS-stage kernel (the pass planner caps factors at 256 / 2000: its costs
+  // are those of HBM-sized passes)
+  unsigned ex[3] = {0, 0, 0};
+  {
+    const unsigned pr[3] = {2, 3, 5};
+    size_t m = N;
+    for (int i = 0; i < 3; ++i)
+      while (m % pr[i] == 0) { m /= pr[i]; ++ex[i]; }
+    if (m != 1) return TSDR_OK;
+  }
+  std::vector<unsigned char> rad;
+  stage_radices(ex[0], ex[1], ex[2], rad);
+  if (rad.size() > MIX_MAX_STAGE) return TSDR_OK;
+  MixDesc d{};
+  d.dir = -1; d.N = N; d.src_mode = SRC_C2C; d.keep = N; d.mode = FFT_ROWS; d.scale = 1.0f;
+  d.R = (unsigned)N;
+  d.nst = (int)rad.size();
+  for (int s = 0; s < d.nst; ++s) d.rad[s] = rad[s];
+  const unsigned __int128 inv = ((unsigned __int128)1 << 64) / d.R;
+  d.r_hi = (unsigned)(inv >> 32);
+  d.r_lo = (unsigned)inv;
+  d.logT = floor_log2(4096u / d.R);
+  d.rows = (unsigned)nbSeg;
+  d.acc = part;
+  d.rows_real = is_complex ? 0 : 1;
+  if (const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : mix3_lookup(d.R)) {
+    // 500 / 1000 / 2000: the three-register-step kernel, 8 (4) segments per 832-thread workgroup
+    int rc3 = mix3_prepare(ctx, m3);
+    if (rc3) return rc3;
+    d.logT = m3->logT;
+    d.mode = FFT_LAST;
+    const unsigned ntiles3 = (unsigned)ceil_div(nbSeg, (size_t)1 << d.logT);
+    const unsigned per_cu3 = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / m3->lds);
+    const unsigned grid3 = std::min(ntiles3, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu3);
+    TSDR_LAUNCH(ctx, "welch_rows_acc3", m3->last, dim3(grid3), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
+    *nparts = grid3;
+    *did = true;
+    return TSDR_OK;
+  }
+  const size_t lds = mix_lds(d.R, d.logT);
+  if (lds > 64 * 1024) {  // (4096-point tiles + tables: above what a kernel gets without opting in)
+    static std::mutex mu;
+    static size_t opted = 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (lds > opted) {
+      TSDR_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_mix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      opted = lds;
+    }
+  }
+  const unsigned ntiles = (unsigned)ceil_div(nbSeg, (size_t)1 << d.logT);
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (size_t)(150 * 1024) / lds));
+  const unsigned grid = std::min(ntiles, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu);
+  TSDR_LAUNCH(ctx, "welch_rows_acc", k_fft_mix, dim3(grid), dim3(256), lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
+  *nparts = grid;
+  *did = true;
+  return TSDR_OK;
+}
 
 int fft_mixed(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, int src_mode,
               size_t src_n, size_t keep, const FftEpilogue *epi, const float2 *src_aux) {

@@ -505,6 +505,21 @@ int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, si
     TSDR_LAUNCH(ctx, "welch_finish", k_welch_finish, dim3(kSegN / 16), dim3(256), 0, (const float *)part, blocks, lin, y);
     return TSDR_OK;
   }
+  if (sizeFFT >= 2 && sizeFFT <= 4096 && len / sizeFFT > 0 && (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
+    // any other 2^a 3^b 5^c segment length that fits one workgroup's LDS: the segment transforms stay on the chip too --
+    // every workgroup adds abs2 of the spectra it forms and leaves one partial sum (round 4: the segment spectra of this
+    // route used to go through HBM, 5.1x the algorithmic traffic)
+    float *part = (float *)ctx->scratch(WS_FFT_C, (size_t)fft_rows_welch_parts(ctx) * sizeFFT * sizeof(float));
+    if (!part) return TSDR_ENOMEM;
+    unsigned nparts = 0;
+    bool did = false;
+    int rc = fft_rows_welch(ctx, sig, is_complex, sizeFFT, len / sizeFFT, part, &nparts, &did);
+    if (rc) return rc;
+    if (did) {
+      TSDR_LAUNCH(ctx, "welch_sum", k_welch_sum, dim3((unsigned)ceil_div(sizeFFT, 16)), dim3(256), 0, (const float *)part, sizeFFT, nparts, lin, y);
+      return TSDR_OK;
+    }
+  }
   float2 *X;
   size_t nbSeg;
   int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);

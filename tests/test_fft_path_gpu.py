@@ -280,9 +280,11 @@ def test_spectrum_too_long_raises(ctx):
         ctx.getSpectrum(1.0, np.ones(10, np.float32), N=11)
 
 
-@pytest.mark.parametrize("sizeFFT,cplx", [(1024, False), (1024, True), (256, True), (1000, False)])
+@pytest.mark.parametrize("sizeFFT,cplx", [(1024, False), (1024, True), (256, True), (1000, False), (1000, True), (2, True), (6, False),
+                                          (4096, True), (4096, False), (3000, True), (2048, False), (960, True), (17, True), (2000, True), (2000, False), (500, True),
+                                          (8192, True)])
 def test_welch_and_waterfall(ctx, sizeFFT, cplx):
-    L = sizeFFT * 37 + 123  # ragged tail is dropped
+    L = sizeFFT * 37 + min(123, sizeFFT - 1)  # ragged tail is dropped
     sig = crandn(L) if cplx else rng.standard_normal(L).astype(np.float32)
     _, y = ctx.getWelch(1.0, sig, sizeFFT=sizeFFT, lin=True)
     o = O.getWelch(sig, sizeFFT=sizeFFT, lin=True)
@@ -292,6 +294,20 @@ def test_welch_and_waterfall(ctx, sizeFFT, cplx):
     assert m.dtype == np.float64 and m.shape == (sizeFFT, 37) and m.flags.f_contiguous
     assert relmax(np.sqrt(m), np.sqrt(om)) < 4 * FFT_TOL
     assert t[1] == sizeFFT / 1.0
+
+
+def test_welch_general_size_on_chip_many_segments(ctx):
+    """getWelch at sizeFFT = 1000 over a whole C2 buffer (10 000 segments): the general 2^a 3^b 5^c route whose segment
+    spectra never leave the chip (every workgroup accumulates abs2 of the transforms it forms, one partial sum each) against
+    the oracle; real input too."""
+    L = 10_000_000
+    sig = crandn(L)
+    _, y = ctx.getWelch(20e6, sig, sizeFFT=1000, lin=True)
+    o = O.getWelch(sig, sizeFFT=1000, lin=True)
+    assert relmax(y, o) < 4 * FFT_TOL, relmax(y, o)
+    r = np.ascontiguousarray(sig.real[: 3000 * 1777 + 5])
+    _, yr = ctx.getWelch(20e6, r, sizeFFT=3000, lin=True)
+    assert relmax(yr, O.getWelch(r, sizeFFT=3000, lin=True)) < 4 * FFT_TOL
 
 
 def test_welch_waterfall_c2_buffer(ctx):

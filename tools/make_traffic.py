@@ -97,6 +97,8 @@ def main():
     doc[wl] = {}
     if spectra_keep:
         doc["spectra"] = spectra_keep
+    # (doc["_calibration"], written from tools/calib_fetch.sh's table, is kept as it is: the x2 correction was verified at 4, 8
+    # and 16 bytes per lane in round 4)
     for k in sorted(set(f) | set(w)):
         fk, wk = f.get(k, 0.0), w.get(k, 0.0)
         doc[wl][k] = {"fetch_size_kb": round(fk), "write_size_kb": round(wk), "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)}
