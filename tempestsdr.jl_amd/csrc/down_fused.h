@@ -59,6 +59,31 @@ __device__ __forceinline__ float wave_sum63(float v) {
   return v;
 }
 
+// Sums over the 64 lanes of FOUR values at once (round 4): two v_permlane32_swap + adds fold lanes l and l + 32 of (a, b)
+// and of (c, d) into one register each, one v_permlane16_swap + add folds rows of 16 lanes, four in-row DPP adds finish:
+// 10 instructions for four sums instead of 4 x 6.  Totals land in lane 15 (a), 31 (c), 47 (b), 63 (d).  Fixed order.
+// Must be called with all 64 lanes active.
+__device__ __forceinline__ float wave_sum4(float a, float b, float c, float d) {
+  auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  const float ab = __fadd_rn(__uint_as_float(p[0]), __uint_as_float(p[1]));   // lanes < 32: a[l] + a[l+32]; lanes >= 32: b
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(d), false, false);
+  const float cd = __fadd_rn(__uint_as_float(q[0]), __uint_as_float(q[1]));
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ab), __float_as_uint(cd), false, false);
+  float v = __fadd_rn(__uint_as_float(r[0]), __uint_as_float(r[1]));          // rows of 16 lanes: a | c | b | d
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_down_fused: sig_to_image |> downgradeImage without the raster.  Tile = 64 output rows x TC output columns;
 // the source lines those rows touch are staged in LDS; each output pixel evaluates its four raster taps (each
@@ -209,31 +234,61 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     sf_lo = (unsigned)__double2ll_rd(ax1.sf * 4294967296.0);   // sf < 1 on this route
     dyf = (float)dy;
   }
+  if (FX) {
+    // four columns per trip (this wavefront's columns are NT/64 apart): their table and sample reads are issued together,
+    // and the four column sums share one reduction
+    constexpr int CSTEP = NT / 64;
+    for (int cb = c0 + wave; cb < cend; cb += 4 * CSTEP) {
+      float vv[4];
+      long long cx[4];
+      float dxw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ct = min(cb + u * CSTEP, cend - 1) - c0;
+        dxw[u] = reinterpret_cast<const float *>(cdx)[ct];
+        cx[u] = reinterpret_cast<const long long *>(cxs)[ct];
+      }
+      float R[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int ln = 0; ln < 2; ++ln) {
+          const unsigned long long X = (unsigned long long)((ln ? B1 : B0) + cx[u]);
+          const unsigned j = (unsigned)(X >> 32), lo = (unsigned)X;
+          const float *p = reinterpret_cast<const float *>(ln ? row1 : row0) + j;
+          const float s0 = p[0], s1 = p[1], s2 = p[2];
+          const unsigned lo2 = lo + sf_lo;        // the next raster pixel: same window, or one sample on (sf <= 0.5)
+          const bool cy = lo2 < lo;
+          const float a2 = cy ? s1 : s0, b2 = cy ? s2 : s1;
+          const float t0 = __fmul_rn((float)lo, 0x1p-32f), t1 = __fmul_rn((float)lo2, 0x1p-32f);
+          // (1-t) a + t b as two FMAs, a - t a first: the samples are magnitudes (>= 0), so both terms are non-negative and
+          // each rounding is relative to the RESULT -- fma(t, b - a, a) rounds b - a, an error of 2^-24 |b - a| that is
+          // several ulp of a result much smaller than the step between its two samples
+          R[u][2 * ln] = lerp2(s0, s1, t0);
+          R[u][2 * ln + 1] = lerp2(a2, b2, t1);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = cb + u * CSTEP;
+        const float v = lerp2(lerp2(R[u][0], R[u][1], dxw[u]), lerp2(R[u][2], R[u][3], dxw[u]), dyf);
+        const bool colok = c < cend;
+        if (live && colok) o[(size_t)c * q.h_out] = v;
+        vv[u] = (live && colok) ? v : 0.0f;
+        if (PSUM) racc = __fadd_rn(racc, vv[u]);
+      }
+      if (PSUM) {
+        const float tot = wave_sum4(vv[0], vv[1], vv[2], vv[3]);   // lane 15: column u = 0, 31: u = 2, 47: u = 1, 63: u = 3
+        const int uu = lane == 15 ? 0 : lane == 31 ? 2 : lane == 47 ? 1 : 3;
+        const int c = cb + uu * CSTEP;
+        if ((lane & 15) == 15 && c < cend) pcol[c - c0] = tot;
+      }
+    }
+  } else {
   for (int c = c0 + wave; c < cend; c += NT / 64) {
     const int ct = c - c0;
     float v;
-    if (FX) {
-      const float dxf = reinterpret_cast<const float *>(cdx)[ct];
-      const long long cx = reinterpret_cast<const long long *>(cxs)[ct];
-      float R[4];
-#pragma unroll
-      for (int ln = 0; ln < 2; ++ln) {
-        const unsigned long long X = (unsigned long long)((ln ? B1 : B0) + cx);
-        const unsigned j = (unsigned)(X >> 32), lo = (unsigned)X;
-        const float *p = reinterpret_cast<const float *>(ln ? row1 : row0) + j;
-        const float s0 = p[0], s1 = p[1], s2 = p[2];
-        const unsigned lo2 = lo + sf_lo;        // the next raster pixel: same window, or one sample on (sf <= 0.5)
-        const bool cy = lo2 < lo;
-        const float a2 = cy ? s1 : s0, b2 = cy ? s2 : s1;
-        const float t0 = __fmul_rn((float)lo, 0x1p-32f), t1 = __fmul_rn((float)lo2, 0x1p-32f);
-        // (1-t) a + t b as two FMAs, a - t a first: the samples are magnitudes (>= 0), so both terms are non-negative and each
-        // rounding is relative to the RESULT -- fma(t, b - a, a) rounds b - a, an error of 2^-24 |b - a| that is several ulp
-        // of a result much smaller than the step between its two samples
-        R[2 * ln] = lerp2(s0, s1, t0);
-        R[2 * ln + 1] = lerp2(a2, b2, t1);
-      }
-      v = lerp2(lerp2(R[0], R[1], dxf), lerp2(R[2], R[3], dxf), dyf);
-    } else {
+    {
     const double dx = cdx[ct];
     float R00, R01, R10, R11;
     if (EXACT) {
@@ -270,6 +325,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
       const float tot = wave_sum63(m);
       if (lane == 63) pcol[ct] = tot;
     }
+  }
   }
   }
   if (PSUM) {
