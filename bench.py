@@ -535,14 +535,30 @@ def main():
     if args.pipeline == "off" and not args.no_pipeline_leg:
         pipeline = {}
         for raster in ((True, False) if not args.no_raster else (False,)):
+            # a context of its own per leg: the two arrangements use different internal streams, and HIP multiplexes more
+            # than four streams of a process onto its four hardware queues
+            ctxp = None
             try:
-                pl = FramesLeg(env, args.workload, args.precision, raster=raster, pipeline=True, share=main_leg, card=args.card)
+                ctxp = tsdr.Context(local_rank)
+                envp = dict(env)
+                envp["ctx"] = ctxp
+
+                def barrier_p(ctxp=ctxp):
+                    ctxp.synchronize()
+                    barrier()
+                envp["barrier"] = barrier_p
+                pl = FramesLeg(envp, args.workload, args.precision, raster=raster, pipeline=True, share=main_leg, card=args.card)
                 r = pl.run(args.steps, args.warmup, max(3, args.repeats // 3), profile=False)
                 pipeline["raster" if raster else "fused"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max",
                                                                                  "msps", "step_frac_of_hbm_peak", "sync_guard") if k in r}
+                pipeline["raster" if raster else "fused"]["arrangement"] = ("image launches on one internal stream, tails on a second, high-priority one"
+                                                                            if raster else "whole buffers alternate between two equal internal streams; only shift + IIR chained")
                 pl.free()
             except Exception as e:
                 pipeline["raster" if raster else "fused"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                if ctxp is not None:
+                    ctxp.close()
         pipeline["note"] = ("pipeline: on -- one context, one SyncXY / IIR state, results identical to one tsdr_frames_d per buffer "
                             "(tests/test_fast_mode_gpu.py:test_frames_pipeline_matches_sequential); compare with `value` (raster) and `fused`")
 

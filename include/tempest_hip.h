@@ -105,8 +105,11 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 600x800 image and projection sums; 1: rasters by the store-aligned ("sheared") raster-only kernel + images by the
  *                 raster-free kernel (two launches, IQ read twice: measured slower, kept as the A/B); 2: the same unsheared.
  *   "beta_waves"  wavefronts per workgroup of the vsync statistics kernel: 4 (default) or 8; identical results.
- *   "pipe_lanes" / "pipe_priority"  tsdr_frames_submit_d's internal streams (before the first submission only): 2 (default;
- *                 3 = shift + IIR on a stream of its own) / 1 (default; 0 = no stream priority for the tails).
+ *   "pipe_mode"   how tsdr_frames_submit_d arranges successive buffers on its internal streams: 0 = image launches on one stream,
+ *                 every buffer's tail on a second one of the highest priority; 1 = whole buffers alternate between equal
+ *                 streams, only the shift + IIR launches chained; -1 (default) = 0 when rasters are written, 1 when not
+ *                 (what measured best on C2).  "pipe_lanes": equal streams of arrangement 1 (2; 3 pays only with
+ *                 GPU_MAX_HW_QUEUES >= 8).  "pipe_priority": 0 = no stream priority for the tails (before the first use).
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
  * TSDR_BETA_WAVES / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY preset them, read once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
@@ -277,11 +280,13 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
                   int *sync_idx, int *n_frames);
 
 /* The same per-buffer body pipelined across buffers, for callers that stream successive buffers (the GUI loop of
- * GUI.jl:150-178 does: one buffer after the other from the SDR).  submit(k) only enqueues: the image launch (raster +
- * 600x800 images) of buffer k goes to an internal HIP stream that carries the image launches of all submissions back to
- * back, its tail (vsync statistics, sync guard, shift + IIR) to a second internal stream of the highest priority, which
- * waits for the image launch through an event -- so the latency-bound tail of buffer k runs beside the image launch of
- * buffer k+1 (C2, raster-free: 357 k vs 313 k frames/s).  Three image / key / projection slots rotate.
+ * GUI.jl:150-178 does: one buffer after the other from the SDR).  submit(k) only enqueues, on internal HIP streams, so
+ * that the latency-bound tail of a buffer (vsync statistics, sync guard, shift + IIR) runs beside the image launch of the
+ * next one.  With rasters: the image launches of all submissions back to back on one stream, every tail on a second one of
+ * the highest priority, which waits for its image launch through an event (C2: 182 k vs 171 k frames/s).  Without: whole
+ * buffers alternate between two equal streams, and only the shift + IIR launches -- the lagged s_y and the IIR recurrence
+ * -- are chained across them by events (390 k vs 347 k; option "pipe_mode").  Up to three image / key
+ * / projection slots rotate.
  * Ordering: a submission waits for whatever the context's stream holds at the time of the call (uploads, a producer's
  * kernels); tsdr_frames_flush -- which only enqueues -- orders the context's stream behind every submitted buffer, so
  * outputs are complete in stream order after the flush and on the host after tsdr_synchronize (which flushes).  Any

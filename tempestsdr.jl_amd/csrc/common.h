@@ -70,7 +70,7 @@ struct tsdr_ctx {
   // sync guard of the FAST frame loop (guard.h): relative top-2 margin below which a frame is re-evaluated exactly
   // (0: off); running totals {frames checked, frames re-evaluated} on the device
   float guard_thr = 2e-5f;
-  unsigned *guard_sync = nullptr;           // work-queue words of the guard kernel (zero between launches)
+  unsigned *guard_sync[4] = {};             // work-queue words of the guard kernel (zero between launches), one set per pipeline lane
   unsigned long long *guard_stats = nullptr;
   // adaptive route (option "sync_guard_auto"): when more than guard_auto_hi of the recent frames were flagged, re-evaluating
   // them one by one costs more than running whole buffers in the exact sequence, so the FAST frame loop does that until the
@@ -80,7 +80,6 @@ struct tsdr_ctx {
   float guard_auto_hi = 0.15f, guard_auto_lo = 0.05f;
   unsigned long long *guard_host = nullptr;  // pinned: checked << 32 | flagged
   unsigned guard_seen_c = 0, guard_seen_f = 0;
-  unsigned guard_grid_seen_f = 0; int guard_quiet = 0;   // sync_guard_d: launches since the mirror last showed a flagged frame
   bool guard_exact_now = false;
   unsigned long long guard_auto_buffers = 0, guard_auto_switches = 0;
   size_t guard_last_off = (size_t)-1;       // byte offset inside WS_GUARD of the most recent guarded call's top-2 records (tsdr_sync_guard_margins)
@@ -109,14 +108,17 @@ struct tsdr_ctx {
   unsigned long long pipe_n = 0;    // submissions since the last flush point
   unsigned long long pipe_seq = 0;  // submissions since the lanes were last run empty (slot = pipe_seq % kPipeSlots)
   size_t pipe_nb = 0;               // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
-  hipStream_t lane[3] = {nullptr, nullptr, nullptr};   // [0] image launches, [1] statistics + guard, [2] shift + IIR
-  hipEvent_t ev_stat[kPipeSlots] = {};
+  hipStream_t lane[4] = {};         // created when first used (frames.hip:lane_get)
   hipEvent_t ev_img[kPipeSlots] = {}, ev_tail[kPipeSlots] = {};  // recorded behind a slot's image launch / its shift + IIR
   bool ev_tail_used[kPipeSlots] = {};
   hipEvent_t lane_in = nullptr;     // "inputs ready" point of the context's stream
   int pipe_last_slot = -1;          // slot of the latest submission: its tail is behind everything submitted
   int opt_pipe_priority = 1;        // 1: the tail streams are created with the highest stream priority
-  int opt_pipe_lanes = 2;           // 3: shift + IIR on a stream of its own (measured: 348 k vs 357 k frames/s raster-free, 175 k vs 181 k with rasters)
+  int pipe_lane = 0;                // lane of the call being enqueued (per-lane guard queue words)
+  int opt_pipe_mode = -1;           // 0: image lane + tail lane; 1: whole buffers alternate between opt_pipe_lanes equal lanes, only
+                                    // shift + IIR chained; -1: 0 with rasters, 1 without
+  int pipe_sym_now = -1;            // arrangement of the submissions in flight
+  int opt_pipe_lanes = 2;           // equal lanes of the symmetric arrangement: 2, or 3 (pays only with GPU_MAX_HW_QUEUES >= 8: 401 k vs 390 k frames/s)
   int opt_beta_waves = 4;           // wavefronts per k_beta workgroup (4 or 8): alone the two tie; beside the pipeline's image kernel a 256-thread
                                     // workgroup fits the holes its retiring workgroups leave (raster-free 357 k vs 309 k frames/s)
 

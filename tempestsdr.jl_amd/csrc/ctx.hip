@@ -140,6 +140,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_SYNC_GUARD_AUTO")) ctx->opt_guard_auto = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_PRIORITY")) ctx->opt_pipe_priority = atoi(e);
   if (const char *e = getenv("TSDR_RASTER_SPLIT")) ctx->opt_raster_split = atoi(e);
+  if (const char *e = getenv("TSDR_PIPE_MODE")) ctx->opt_pipe_mode = atoi(e) < 0 ? -1 : atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;
   if (const char *e = getenv("TSDR_BETA_WAVES")) ctx->opt_beta_waves = atoi(e) == 8 ? 8 : 4;
   return ctx;
@@ -154,7 +155,6 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   for (auto &l : ctx->lane) if (l) (void)hipStreamDestroy(l);
   for (auto &e : ctx->ev_img) if (e) (void)hipEventDestroy(e);
   for (auto &e : ctx->ev_tail) if (e) (void)hipEventDestroy(e);
-  for (auto &e : ctx->ev_stat) if (e) (void)hipEventDestroy(e);
   if (ctx->lane_in) (void)hipEventDestroy(ctx->lane_in);
   for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
   for (auto &r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -163,7 +163,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->amax_keys) (void)hipFree(ctx->amax_keys);
   if (ctx->guard_stats) (void)hipFree(ctx->guard_stats);
-  if (ctx->guard_sync) (void)hipFree(ctx->guard_sync);
+  for (auto &q : ctx->guard_sync) if (q) (void)hipFree(q);
   if (ctx->guard_host) (void)hipHostFree(ctx->guard_host);
   if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
@@ -215,12 +215,20 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "fft_big")) ctx->opt_fft_big = value != 0;
   else if (!strcmp(name, "raster_split")) ctx->opt_raster_split = value < 0 || value > 2 ? 0 : value;
   else if (!strcmp(name, "beta_waves")) ctx->opt_beta_waves = value == 8 ? 8 : 4;
+  else if (!strcmp(name, "pipe_mode")) {
+    int rc = tsdr::pipe_drain(ctx);
+    if (rc) return rc;
+    ctx->opt_pipe_mode = value < 0 ? -1 : value != 0;
+  }
   else if (!strcmp(name, "pipe_lanes")) {
-    if (ctx->lane[0]) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_lanes must be set before the first tsdr_frames_submit_d");
+    int rc = tsdr::pipe_drain(ctx);
+    if (rc) return rc;
+    tsdr::pipe_sync_lanes(ctx);
+    ctx->pipe_sym_now = -1;   // (the slot rotation restarts)
     ctx->opt_pipe_lanes = value == 3 ? 3 : 2;
   }
   else if (!strcmp(name, "pipe_priority")) {   // takes effect when the pipeline's streams are created (first submission)
-    if (ctx->lane[0]) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_priority must be set before the first tsdr_frames_submit_d");
+    if (ctx->lane[2]) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_priority must be set before the first tsdr_frames_submit_d with rasters");
     ctx->opt_pipe_priority = value != 0;
   }
   else if (!strcmp(name, "sync_guard_ppb")) {

@@ -821,8 +821,8 @@ __global__ __launch_bounds__((Mix2Geom<RA, RB>::NT)) void k_fft_mid(const float2
 }
 
 typedef void (*mid_fn)(const float2 *, float2 *, MidDesc);
-struct MidEntry { unsigned R, RA; int tm, nt; mid_fn fn; };
-#define MID(RA_, RB_) { RA_ * RB_, RA_, Mix2Geom<RA_, RB_>::TM, Mix2Geom<RA_, RB_>::NT, k_fft_mid<RA_, RB_> }
+struct MidEntry { unsigned R, RA; int tm, nt; mid_fn fn; size_t lds3; };   // lds3: three-step kernels' dynamic LDS (0: two-step)
+#define MID(RA_, RB_) { RA_ * RB_, RA_, Mix2Geom<RA_, RB_>::TM, Mix2Geom<RA_, RB_>::NT, k_fft_mid<RA_, RB_>, 0 }
 // last forward factors that have the fused kernel (the planner puts the factor with the most twos last)
 static const MidEntry kMid[] = {MID(10, 20), MID(10, 10), MID(16, 16), MID(16, 10), MID(16, 9), MID(16, 8), MID(16, 5), MID(8, 8), MID(8, 5)};
 #undef MID
@@ -1192,7 +1192,8 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mid3(c
     }
   }
 }
-#define MID3(RA_, RB_, RC_, LT_) { RA_ * RB_ * RC_, 0, 1 << LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, k_fft_mid3<RA_, RB_, RC_, LT_> }
+#define MID3(RA_, RB_, RC_, LT_) { RA_ * RB_ * RC_, 0, 1 << LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, k_fft_mid3<RA_, RB_, RC_, LT_>, \
+                                   Mix3Geom<RA_, RB_, RC_, LT_>::LDS + 2 * (size_t)(1 << LT_) * 4 }
 static const MidEntry kMid3[] = {MID3(20, 10, 10, 2), MID3(10, 10, 10, 3)};
 #undef MID3
 static const MidEntry *mid3_lookup(unsigned R) {
@@ -1200,12 +1201,6 @@ static const MidEntry *mid3_lookup(unsigned R) {
     if (e.R == R) return &e;
   return nullptr;
 }
-static size_t mid3_lds(unsigned R, int tm) {
-  for (const Mix3Entry &e : kMix3)
-    if (e.R == R && (1 << e.logT) == tm) return e.lds + 2 * (size_t)tm * 4;
-  return 0;
-}
-
 typedef void (*mix2_fn)(const float2 *, float2 *, MixDesc);
 struct Mix2Entry { unsigned R, RA; int tm, nt; mix2_fn strided, last; };
 #define MIX2(RA_, RB_)                                                                                     \
@@ -1696,7 +1691,7 @@ int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_
   int rc = fft_mixed_ex(ctx, x, nullptr, Mc, 1, -1, 1.0f, src_mode, src_n, 0, nullptr, nullptr, &F, 0, &w);
   if (rc) return rc;
   if (me->RA == 0) {  // three-step kernel
-    const size_t lds = mid3_lds(m.R, me->tm);
+    const size_t lds = me->lds3;
     static std::mutex mu;
     static std::unordered_map<const void *, bool> done;
     {

@@ -31,6 +31,7 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
                  unsigned long long *keys, float *proj, const GuardArgs &g, bool *can, bool plan_only);
 int sync_workspace(tsdr_sync *s, int frames, int slot, int nslots, const ProjLayout *pl_in, float **proj,
                    unsigned long long **keys);
+int sync_use_lane(tsdr_sync *s, int lane);
 int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride, int h, int w, int frames,
                 const unsigned long long *keys, int do_align, float alpha, float *state, float *frames_out,
                 int *sync_idx);
@@ -248,21 +249,24 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
 }  // extern "C"
 
 namespace tsdr {
-static int lanes_create(tsdr_ctx *ctx) {
-  if (ctx->lane[0]) return TSDR_OK;
-  int lo = 0, hi = 0;
-  TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically: hi <= lo)
-  TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[0], hipStreamNonBlocking));
-  for (int l = 1; l < 3; ++l) {
-    if (ctx->opt_pipe_priority) TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->lane[l], hipStreamNonBlocking, hi));
-    else TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
+// lanes: [0], [1] (and [3] with "pipe_lanes" = 3) normal priority -- the symmetric mode's equal lanes, [0] also the
+// asymmetric mode's image lane; [2] highest priority -- the asymmetric mode's tail lane.  Created when first used.
+static int lane_get(tsdr_ctx *ctx, int i) {
+  if (!ctx->lane_in) {
+    for (int k = 0; k < tsdr_ctx::kPipeSlots; ++k) {
+      TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[k], hipEventDisableTiming));
+      TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[k], hipEventDisableTiming));
+    }
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
   }
-  for (int i = 0; i < tsdr_ctx::kPipeSlots; ++i) {
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stat[i], hipEventDisableTiming));
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[i], hipEventDisableTiming));
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[i], hipEventDisableTiming));
+  if (ctx->lane[i]) return TSDR_OK;
+  if (i == 2 && ctx->opt_pipe_priority) {
+    int lo = 0, hi = 0;
+    TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically: hi <= lo)
+    TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->lane[i], hipStreamNonBlocking, hi));
+  } else {
+    TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
   }
-  TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
   return TSDR_OK;
 }
 
@@ -284,8 +288,8 @@ void pipe_sync_lanes(tsdr_ctx *ctx) {
 
 struct LaneScope {  // launches of this scope go to a lane
   tsdr_ctx *ctx; hipStream_t saved;
-  LaneScope(tsdr_ctx *c, int lane) : ctx(c), saved(c->launch_stream) { c->launch_stream = c->lane[lane]; }
-  ~LaneScope() { ctx->launch_stream = saved; }
+  LaneScope(tsdr_ctx *c, int lane) : ctx(c), saved(c->launch_stream) { c->launch_stream = c->lane[lane]; c->pipe_lane = lane; }
+  ~LaneScope() { ctx->launch_stream = saved; ctx->pipe_lane = 0; }
 };
 }  // namespace tsdr
 
@@ -305,12 +309,16 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   const int F = (int)nb;
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   constexpr int NS = tsdr_ctx::kPipeSlots;
-  rc = lanes_create(ctx);
-  if (rc) return rc;
+  // Which arrangement: "pipe_mode" 0 = image lane + tail lane, 1 = equal lanes, -1 (default) = by what was measured on
+  // C2: with rasters the store-bound image launch leaves no room beside itself for a second one, and
+  // the tail lane hides the tail (182 k vs 171 k frames/s); without rasters two whole buffers side by side overlap
+  // better than image launch + tail (390 k vs 359 k)
+  const bool sym = ctx->opt_pipe_mode < 0 ? raster_out == nullptr : ctx->opt_pipe_mode != 0;
+  const int nl = ctx->opt_pipe_lanes == 3 ? 3 : 2;
   // The image slots sit nb frames apart, so a submission whose frame count differs from the one in flight (S or nEch
   // changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images a tail still has to read: the pipeline runs
   // empty first (a configuration change, not a steady-state event).
-  if (ctx->pipe_nb != nb) {
+  if (ctx->pipe_nb != nb || ctx->pipe_sym_now != (sym ? 1 : 0)) {   // (a change of arrangement likewise)
     rc = pipe_drain(ctx);
     if (rc) return rc;
     pipe_sync_lanes(ctx);
@@ -318,7 +326,9 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     ctx->pipe_seq = 0;
   }
   ctx->pipe_nb = nb;
-  const int slot = (int)(ctx->pipe_seq % (unsigned long long)NS);
+  ctx->pipe_sym_now = sym ? 1 : 0;
+  // symmetric: whole buffers alternate between nl equal lanes; slot = position in the rotation
+  const int slot = (int)(ctx->pipe_seq % (unsigned long long)(sym ? nl : NS));
   // (workspaces first: growing one synchronises and frees what the lanes may be using)
   float *img3 = (float *)ctx->scratch(WS_IMG, NS * nb * npx * 4);
   unsigned long long *keys3 = (unsigned long long *)ctx->scratch(WS_KEYS, NS * nb * 2 * 8);
@@ -338,6 +348,44 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     rc = sync_workspace(sync, F, slot, NS, plan.ncp ? &plan : nullptr, &proj, nullptr);
     if (rc) return rc;
   }
+  if (sym) {
+    // R(k) B(k) G(k) [shift + IIR of the previous buffer done] C(k), all on lane `slot`: a lane's next buffer is stream-ordered
+    // behind its previous one, and the only cross-lane dependency is the chain of shift + IIR launches (lagged s_y, IIR state)
+    const int li = slot == 2 ? 3 : slot;
+    rc = lane_get(ctx, li);
+    if (rc) return rc;
+    LaneScope lane_scope(ctx, li);
+    hipStream_t st = ctx->lane[li];
+    if (hipStreamQuery(ctx->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
+      TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_in, 0));
+    }
+    if (do_align) {
+      rc = sync_use_lane(sync, slot);
+      if (rc) return rc;
+    }
+    rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj,
+                           &got, false, keys);
+    if (rc) return rc;
+    if (do_align) {
+      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr);
+      if (rc) return rc;
+      if (gp.on) {
+        rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
+        if (rc) return rc;
+      }
+    }
+    if (ctx->pipe_last_slot >= 0 && ctx->pipe_last_slot != slot && ctx->ev_tail_used[ctx->pipe_last_slot])
+      TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_tail[ctx->pipe_last_slot], 0));
+    rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
+                     do_align ? sync_idx : nullptr);
+    if (rc) return rc;
+    TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
+  } else {
+  rc = lane_get(ctx, 0);
+  if (!rc) rc = lane_get(ctx, 2);
+  if (rc) return rc;
   {
     LaneScope image_lane(ctx, 0);
     // inputs: whatever the context's stream holds now (uploads, a producer's kernels, an earlier call's launches) comes
@@ -355,8 +403,8 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     TSDR_HIP(ctx, hipEventRecord(ctx->ev_img[slot], ctx->lane[0]));
   }
   {
-    LaneScope tail_lane(ctx, 1);
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[1], ctx->ev_img[slot], 0));
+    LaneScope tail_lane(ctx, 2);
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[2], ctx->ev_img[slot], 0));
     if (do_align) {
       rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr);
       if (rc) return rc;
@@ -365,18 +413,12 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
         if (rc) return rc;
       }
     }
-  }
-  {
-    const int cl = ctx->opt_pipe_lanes == 3 ? 2 : 1;
-    LaneScope iir_lane(ctx, cl);
-    if (cl == 2) {
-      TSDR_HIP(ctx, hipEventRecord(ctx->ev_stat[slot], ctx->lane[1]));
-      TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[2], ctx->ev_stat[slot], 0));
-    }
+    // (shift + IIR on a third stream of its own: 348 k vs 357 k frames/s raster-free, 175 k vs 181 k with rasters -- dropped)
     rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
                      do_align ? sync_idx : nullptr);
     if (rc) return rc;
-    TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[cl]));
+    TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
+  }
   }
   ctx->ev_tail_used[slot] = true;
   ctx->pipe_last_slot = slot;

@@ -42,8 +42,9 @@ struct tsdr_sync {
   int y_t, x_t;
   int wmin_y, wmax_y, wmin_x, wmax_x;
   float h[5];
-  float *beta_x = nullptr;  // device, (1+wmax_x-wmin_x) x x_t
+  float *beta_x = nullptr;  // device, (1+wmax_x-wmin_x) x x_t   (the current set: one of bset[])
   float *beta_y = nullptr;  // device, (1+wmax_y-wmin_y) x y_t
+  float *bset[4][2] = {};   // [pipeline lane][x / y]: sync_use_lane
   int *pending = nullptr;   // device: [cur] = s_y the next vsync call will return (argmax of beta_y); double-buffered
   int cur = 0;
 };
@@ -680,7 +681,6 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
 // number of resident workgroups.  Hand-over between items of different CUs: every storing wavefront drains its stores,
 // workgroup barrier, one lane release-fences and bumps the frame's counter; the consumer polls the counter, acquire-
 // fences, barrier (MI355X_MICROARCH.md, inter-workgroup visibility).  The last workgroup to leave zeroes the queue words.
-constexpr int kGuardQuiet = 4;
 struct GuardSync {          // device words, all zero between launches
   unsigned ticket, exited;
   unsigned done[1];         // [2 * frames]: items A / B finished per LIST position
@@ -759,11 +759,10 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
         if (blockIdx.x == 0) {
           atomicAdd(&a.g.stats[0], (unsigned long long)a.frames);
           if (n) atomicAdd(&a.g.stats[1], (unsigned long long)n);
-          // guard launches of one context are stream-ordered and this lane is the only writer: plain read-modify-write
-          const unsigned long long w = a.g.stats[2];
-          const unsigned long long nw = ((unsigned long long)((unsigned)(w >> 32) + (unsigned)a.frames) << 32) |
-                                        (unsigned long long)((unsigned)w + (unsigned)n);
-          a.g.stats[2] = nw;
+          // {checked << 32 | flagged} in one word (guard launches of two pipeline lanes may run side by side: atomic; the
+          // mirror below may then be overwritten by the older of two values, which the next launch corrects)
+          const unsigned long long dw = ((unsigned long long)(unsigned)a.frames << 32) | (unsigned long long)(unsigned)n;
+          const unsigned long long nw = atomicAdd(&a.g.stats[2], dw) + dw;
           if (a.g.host) __hip_atomic_store(a.g.host, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
@@ -855,9 +854,10 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     const int nf = std::min(kGuardChunk, frames - f0);
     // queue words: zero between launches (the kernel restores that itself)
     const size_t words = 2 + 2 * (size_t)kGuardChunk;
-    if (!ctx->guard_sync) {
-      TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_sync, words * 4));
-      TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_sync, 0, words * 4, ctx->launch_stream));
+    unsigned *&qwords = ctx->guard_sync[ctx->pipe_lane & 3];   // (guard launches of different pipeline lanes may run side by side)
+    if (!qwords) {
+      TSDR_HIP(ctx, hipMalloc((void **)&qwords, words * 4));
+      TSDR_HIP(ctx, hipMemsetAsync(qwords, 0, words * 4, ctx->launch_stream));
     }
     a.g = g;
     a.g.top2 = g.top2 + (size_t)f0 * (size_t)(g.nbx + g.nby);
@@ -871,23 +871,15 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     beta_args(s, a.proj, pl, keys + (size_t)f0 * 2, nf, &a.B, &nbb, &lds_beta, nullptr);
     a.B.write_frame = (f0 + nf == frames) ? nf - 1 : -1;
     a.nB = (y + 63) >> 6; a.nC = (int)nbb;
-    a.sync = ctx->guard_sync;
+    a.sync = qwords;
     a.lds_bytes = (a.lds_bytes + 15) & ~(size_t)15;
     const size_t lds = std::max(std::max(a.lds_bytes + (size_t)a.dq.TC * 65 * 4, kProjLds), lds_beta);
     a.lds_total = lds;
-    // one workgroup per CU (64 / 128 / 512 measured no better) -- while frames are being flagged.  The launch's cost when
-    // nothing is flagged is getting 512-thread workgroups onto every CU, which takes 5 us on an idle GPU and 30-90 us
-    // beside the pipeline's image kernel (rocprofv3 trace, round 4): after kGuardQuiet launches in a row whose
-    // predecessors flagged nothing (the pinned mirror of the counters, read without synchronising) the grid shrinks to an
-    // eighth.  The queue works with any number of workgroups, so this changes how fast a flagged frame is redone,
-    // never what is computed.
-    unsigned grid = g.count_only ? 1u : (unsigned)ncu;
-    if (!g.count_only && ctx->guard_host) {
-      const unsigned fl = (unsigned)__atomic_load_n(ctx->guard_host, __ATOMIC_RELAXED);
-      if (fl != ctx->guard_grid_seen_f) { ctx->guard_grid_seen_f = fl; ctx->guard_quiet = 0; }
-      else if (ctx->guard_quiet < 1000000) ++ctx->guard_quiet;
-      if (ctx->guard_quiet >= kGuardQuiet) grid = std::max(8u, (unsigned)ncu / 8u);
-    }
+    // one workgroup per CU: 64 / 128 / 512 measured no better.  (Round 4, dropped: an eighth of the grid after a few launches
+    // that flagged nothing -- the launch's cost beside the pipeline's image kernel is finding room for ONE 512-thread
+    // workgroup with 52 KiB of LDS, not their number, so it bought nothing there and cost C3, where a frame is flagged every
+    // other buffer, 0.11 instead of 0.057 ms per step.)
+    const unsigned grid = g.count_only ? 1u : (unsigned)ncu;
     TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
   }
   return TSDR_OK;
@@ -928,6 +920,26 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
   return TSDR_OK;
 }
 
+// Pipelined frame loop, symmetric mode (frames.hip): the beta matrices k_beta / k_guard leave for the LAST frame of a buffer go
+// to a set of their own per lane, since the statistics of two buffers may run side by side; the state's current matrices
+// are those of the lane submitted last.
+int sync_use_lane(tsdr_sync *s, int lane) {
+  tsdr_ctx *ctx = s->ctx;
+  lane &= 3;
+  if (!s->bset[lane][0]) {
+    const size_t nbx = (size_t)(1 + s->wmax_x - s->wmin_x) * s->x_t, nby = (size_t)(1 + s->wmax_y - s->wmin_y) * s->y_t;
+    float *bx = nullptr, *by = nullptr;
+    if (hipMalloc((void **)&bx, nbx * 4) != hipSuccess || hipMalloc((void **)&by, nby * 4) != hipSuccess) {
+      if (bx) (void)hipFree(bx);
+      return set_err(ctx, TSDR_ENOMEM, "sync state allocation failed");
+    }
+    s->bset[lane][0] = bx; s->bset[lane][1] = by;
+  }
+  s->beta_x = s->bset[lane][0];
+  s->beta_y = s->bset[lane][1];
+  return TSDR_OK;
+}
+
 }  // namespace tsdr
 
 using namespace tsdr;
@@ -952,11 +964,12 @@ int tsdr_sync_create(tsdr_ctx *ctx, int y_t, int x_t, tsdr_sync **out) {
   s->wmin_x = (int)ceil(5.0 / 100.0 * (double)x_t);
   s->wmax_x = (int)floor((double)x_t / 4.0);
   const size_t nbx = (size_t)(1 + s->wmax_x - s->wmin_x) * x_t, nby = (size_t)(1 + s->wmax_y - s->wmin_y) * y_t;
-  if (hipMalloc((void **)&s->beta_x, nbx * 4) != hipSuccess || hipMalloc((void **)&s->beta_y, nby * 4) != hipSuccess ||
+  if (hipMalloc((void **)&s->bset[0][0], nbx * 4) != hipSuccess || hipMalloc((void **)&s->bset[0][1], nby * 4) != hipSuccess ||
       hipMalloc((void **)&s->pending, 16) != hipSuccess) {
     tsdr_sync_free(s);
     return set_err(ctx, TSDR_ENOMEM, "sync state allocation failed");
   }
+  s->beta_x = s->bset[0][0]; s->beta_y = s->bset[0][1];
   int rc = tsdr_sync_reset(s);
   if (rc) { tsdr_sync_free(s); return rc; }
   *out = s;
@@ -986,8 +999,7 @@ void tsdr_sync_free(tsdr_sync *s) {
     (void)pipe_drain(s->ctx);  // the deferred stage reads this state's pending s_y: enqueue it before the state goes
     (void)hipStreamSynchronize(s->ctx->stream);
   }
-  if (s->beta_x) (void)hipFree(s->beta_x);
-  if (s->beta_y) (void)hipFree(s->beta_y);
+  for (auto &b : s->bset) for (float *p : b) if (p) (void)hipFree(p);
   if (s->pending) (void)hipFree(s->pending);
   delete s;
 }

@@ -19,7 +19,7 @@ export sig_to_image, downgradeImage, naiveResampler, init_resampler
 export calculate_autocorrelation, zoom_autocorr
 export getSpectrum, getWelch, getWaterfall
 export SyncXY, vsync
-export hip_frames!           # fused GUI.jl:163-178 loop body (optional fast path)
+export hip_frames!, hip_frames_submit!, hip_frames_flush, hip_synchronize   # fused GUI.jl:163-178 loop body (optional fast path; pipelined form)
 export hip_extract_configuration, sync_guard_stats, sync_guard_auto   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
 export hip_set_precision, hip_set_option                              # TSDR_EXACT / TSDR_FAST and the library's options, per task context
 
@@ -210,6 +210,26 @@ function hip_frames!(imageOut::Matrix{Float32}, sigId::Vector{ComplexF32}, sync:
                         sync.c.h, sync.h, sigId, length(sigId), S, y_t, x_t, α, do_align ? 1 : 0, imageOut, frames, C_NULL, idx, n), "hip_frames!")
     return frames, idx
 end
+
+"""
+    hip_frames_submit!(d_imageOut, d_sigId, nEch, sync, S, y_t, x_t, α; d_frames, d_raster = C_NULL, d_idx = C_NULL, do_align = true) -> nb
+    hip_frames_flush()
+
+The loop body for callers that stream buffers and keep them on the device (`tsdr_dev_alloc` / `tsdr_upload`): enqueue-only,
+pipelined across buffers -- the image launch of this buffer runs beside the vsync statistics / shift + IIR of the previous
+one (`tsdr_frames_submit_d`).  Every argument `d_*` is a device pointer; up to three submissions are in flight, each with
+its own `d_frames` / `d_raster` / `d_idx`.  Outputs are complete after `hip_frames_flush()` + `hip_synchronize()`.
+"""
+function hip_frames_submit!(d_imageOut::Ptr{Cvoid}, d_sigId::Ptr{Cvoid}, nEch::Integer, sync::SyncXY{Float32}, S, y_t, x_t, α::Float32;
+                            d_frames::Ptr{Cvoid}, d_raster::Ptr{Cvoid} = C_NULL, d_idx::Ptr{Cvoid} = C_NULL, do_align = true)
+    n = Ref{Cint}(0)
+    check(sync.c, ccall((:tsdr_frames_submit_d, LIB), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Csize_t, Cint, Cint, Cfloat, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
+                        sync.c.h, sync.h, d_sigId, nEch, S, y_t, x_t, α, do_align ? 1 : 0, d_imageOut, d_frames, d_raster, d_idx, n), "hip_frames_submit!")
+    return Int(n[])
+end
+hip_frames_flush() = (c = ctx(); check(c, ccall((:tsdr_frames_flush, LIB), Cint, (Ptr{Cvoid},), c.h), "hip_frames_flush"))
+hip_synchronize() = (c = ctx(); check(c, ccall((:tsdr_synchronize, LIB), Cint, (Ptr{Cvoid},), c.h), "hip_synchronize"))
 
 # ---- fused configuration search (GUI.jl:67-81) ------------------------------------------------------
 """
