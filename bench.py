@@ -413,6 +413,7 @@ def main():
     ap.add_argument("--pipeline", choices=["on", "off"], default="off",
                     help="on: the headline leg goes through tsdr_frames_submit_d (the tail of buffer k beside the image launch of "
                          "buffer k+1); off (default): one tsdr_frames_d per buffer, and the pipelined legs are reported as `pipeline`")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the two-contexts-on-one-GPU leg")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the `pipeline` sub-legs (tsdr_frames_submit_d on the same buffers)")
     ap.add_argument("--precision", default="fast", choices=["fast", "exact"], help="tsdr_precision of the frame loop")
     ap.add_argument("--card", default="box", choices=["box", "plateau"],
@@ -564,7 +565,7 @@ def main():
 
     # ---- two capture streams on this GPU (deployment figure; not `value`)
     two = None
-    if solo and not args.no_extra:
+    if solo and not args.no_extra and not args.no_two_streams:
         try:
             two = two_streams(env, tsdr, local_rank, main_leg, args.workload, max(100, 5 * args.steps))
         except Exception as e:
@@ -684,6 +685,21 @@ def main():
                 extra[name.lower()]["fused"] = {k: r2[k] for k in ("value", "ms_per_step", "step_frac_of_hbm_peak", "kernels_ms_per_step")
                                                 if k in r2}
                 fl2.free()
+                # the same buffer through tsdr_frames_submit_d (a context of its own, see `pipeline` above)
+                ctxq = tsdr.Context(local_rank)
+                try:
+                    envq = dict(env)
+                    envq["ctx"] = ctxq
+                    envq["barrier"] = (lambda c=ctxq: (c.synchronize(), barrier()))
+                    pq = {}
+                    for ras in (True, False):
+                        lq = FramesLeg(envq, name, "fast", raster=ras, pipeline=True, share=leg)
+                        rq = lq.run(max(5, args.steps // 5), 2, 3, profile=False)
+                        pq["raster" if ras else "fused"] = {k: rq[k] for k in ("value", "ms_per_step") if k in rq}
+                        lq.free()
+                    extra[name.lower()]["pipeline"] = pq
+                finally:
+                    ctxq.close()
                 leg.free()
             except Exception as e:
                 extra[name.lower()] = {"error": f"{type(e).__name__}: {e}"}

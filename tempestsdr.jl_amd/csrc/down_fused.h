@@ -94,6 +94,9 @@ struct DownParams {
   int y_t, x_t, h_out, w_out;
   int TC, NL, W, tiles_c;
   int lpl_log;
+  int sparse = 0;                   // 1: only the two source lines of every output row are staged (row r: staged rows 2r, 2r+1) --
+                                    // for vertical ratios above 2, where the lines BETWEEN them would be more than half the tile
+  int xcd_tpx = 0, xcd_tiles = 0;   // k_down_fused's XCD-aware 1-D grid: tiles per XCD and frame (0: plain (tile, frame) grid), tiles per frame
   // PSUM (FAST frame loop without a raster): projection partial sums of the (h_out, w_out) image and the frame's argmax keys
   float *proj = nullptr;        // per frame: colpart[row blocks][w_out] | rowpart[tiles_c][h_out]  (sync_layout.h)
   size_t proj_stride = 0;
@@ -157,10 +160,12 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   // tile's source-line and raster-pixel ranges (uniform)
   const int ly0 = (int)rs_pos(ay, (double)(r0 + 1), dtmp);
   const int ly1 = (int)rs_pos(ay, (double)(min(r0 + 63, q.h_out - 1) + 1), dtmp) + 1;
-  const int nl = ly1 - ly0 + 1;
+  const int nl = q.sparse ? 2 * min(64, q.h_out - r0) : ly1 - ly0 + 1;
   const int pxa = (int)rs_pos(axx, (double)(c0 + 1), dtmp);
   for (int i = tid; i < nl; i += NT) {
-    const unsigned flat = (unsigned)(ly0 + i) * (unsigned)q.x_t + (unsigned)pxa;
+    // source line of staged row i: dense -- ly0 + i; sparse -- the upper (i even) or lower tap line of output row r0 + i/2
+    const int li = q.sparse ? (int)rs_pos(ay, (double)(r0 + (i >> 1) + 1), dtmp) + (i & 1) : ly0 + i;
+    const unsigned flat = (unsigned)li * (unsigned)q.x_t + (unsigned)pxa;
     int k;
     if (EXACT) k = (int)rs_pos(ax1, (double)(flat + 1u), dtmp);
     else if (FX) k = (int)floor(fma(ax1.sf, (double)flat + 0.5, -0.5)) - 1;   // may be -1 / -2 on the frame's first line: the
@@ -215,7 +220,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   const int rr_ = live ? r : q.h_out - 1;       // (PSUM: lanes past the image follow the last row and contribute 0)
   double dy;
   const int ky = (int)rs_pos(ay, (double)(rr_ + 1), dy);
-  const int i0 = ky - ly0;
+  const int i0 = q.sparse ? 2 * (rr_ - r0) : ky - ly0;
   const char *row0 = base + (size_t)i0 * Wp * SB;
   const char *row1 = row0 + (size_t)Wp * SB;
   const int kf0 = kfirst[i0], kf1 = kfirst[i0 + 1];

@@ -703,7 +703,17 @@ template <bool CPLX, int MODE, int SUMS = DS_NONE>
 __global__ __launch_bounds__(kDownNT) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
                                                     float *__restrict__ out, size_t out_stride, size_t lds_main) {
   extern __shared__ double lds_dn[];
-  down_fused_body<CPLX, MODE, kDownNT, SUMS>(in, in_stride, q, out, out_stride, (int)blockIdx.x, (int)blockIdx.y, lds_dn, nullptr,
+  int tile = (int)blockIdx.x, f = (int)blockIdx.y;
+  if (q.xcd_tpx) {
+    // XCD-aware order (1-D grid): workgroup b runs on XCD b mod 8; each XCD takes a contiguous range of a frame's tiles --
+    // neighbouring column tiles share the 128-byte lines at the ends of their staged sample runs, and tiles of one row block
+    // re-read none of them from HBM when they meet in one L2
+    const unsigned b = blockIdx.x, xcd = b & 7u, sidx = b >> 3;
+    f = (int)(sidx / (unsigned)q.xcd_tpx);
+    tile = (int)(xcd * (unsigned)q.xcd_tpx + (sidx - (unsigned)f * (unsigned)q.xcd_tpx));
+    if (tile >= q.xcd_tiles) return;
+  }
+  down_fused_body<CPLX, MODE, kDownNT, SUMS>(in, in_stride, q, out, out_stride, tile, f, lds_dn, nullptr,
                                          reinterpret_cast<float *>(reinterpret_cast<char *>(lds_dn) + lds_main));
 }
 
@@ -973,7 +983,11 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
   pl.mode = DM_EXACT;
   const double sf = (double)S / ((double)y_t * (double)x_t);
   const double sfy = (double)y_t / (double)h_out, sfx = (double)x_t / (double)w_out;
-  const long NL = (long)(63.0 * sfy) + 3;
+  const long NLd = (long)(63.0 * sfy) + 3;
+  // FAST: above a vertical ratio of ~2 the lines between an output row's two tap lines are more than half of the tile's
+  // span: stage just the 2 x 64 tap lines (C5: 128 instead of 239)
+  const bool sparse = !exact && NLd > 128;
+  const long NL = sparse ? 128 : NLd;
   // 64-column tiles (4096 pixels per 256-thread workgroup) with f32 staging: measured at C2 against the former preference
   // (32 columns at most, {a, slope} f64 pairs when they fit 32 KiB -- which held the tile to 16 columns): 50 vs 65 us for the
   // FAST kernel; 128 columns: 58 us.  The EXACT tiling is the sync guard's as well and stays as it was.
@@ -994,6 +1008,7 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
         // first one's three-sample window); one more staged sample for that window
         pl.mode = exact ? DM_EXACT : (sf <= 0.5 ? DM_FAST_FX : DM_FAST_F32);
         pl.q.S = (unsigned)S; pl.q.y_t = y_t; pl.q.x_t = x_t; pl.q.h_out = h_out; pl.q.w_out = w_out;
+        pl.q.sparse = sparse ? 1 : 0;
         pl.q.TC = TC; pl.q.NL = (int)NL; pl.q.W = (int)W; pl.q.tiles_c = (int)ceil_div((size_t)w_out, (size_t)TC);
         // staging lanes per line: a lane issues its loads four at a time, lpl samples apart, so a line costs
         // ceil(W / 4 lpl) * 4 lpl load slots -- the power of two that wastes the fewest (round 4: the former rule counted
@@ -1036,6 +1051,11 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
     }
     if (plan_only) return TSDR_OK;
     dim3 grid((unsigned)(ceil_div((size_t)h_out, 64) * (size_t)pl.q.tiles_c), (unsigned)frames);
+    if (ctx->opt_down_xcd && !exact) {
+      pl.q.xcd_tiles = (int)grid.x;
+      pl.q.xcd_tpx = (int)ceil_div((size_t)grid.x, 8);
+      grid = dim3((unsigned)(8 * pl.q.xcd_tpx * frames), 1);
+    }
     const size_t lds_main = (pl.lds + 15) & ~(size_t)15;
 #define DOWNK(C, M, SUMS, NAME, LDS) \
   TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS>), grid, dim3(kDownNT), LDS, in, in_stride, pl.q, out, out_stride, lds_main)

@@ -6,15 +6,20 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 sub = sys.argv[2] if len(sys.argv) > 2 else None
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in rows]
 ks.sort()
+bursts = None
 if sub:
-    # the pipelined region: kernels named `sub` that ran on a queue other than the one most of the run used
-    import collections as _c
-    main_q = _c.Counter(k[3] for k in ks if "tsdr::" in k[2] and sub not in k[2]).most_common(1)[0][0] if False else None
-    lanes = _c.Counter(k[3] for k in ks if sub in k[2])
-    laneq = [q for q, _ in lanes.most_common()][-1] if len(lanes) > 1 else list(lanes)[0]
-    idx = [i for i, k in enumerate(ks) if sub in k[2] and k[3] == laneq]
-    ks = ks[idx[len(idx) // 4]: idx[-1] + 1]   # steady state: skip the first quarter
-    ks = [k for k in ks if "tsdr::" in k[2]]
+    # the pipelined regions: bursts of kernels on queues other than the first library kernel's (the context's own stream
+    # carries the non-pipelined legs of the same run); a gap of more than 0.5 ms ends a burst
+    lib = [k for k in ks if "tsdr::" in k[2]]
+    first_q = lib[0][3]
+    lanes = [k for k in lib if k[3] != first_q]
+    bursts = []
+    for k in lanes:
+        if bursts and k[0] - bursts[-1][1] < 500_000:
+            bursts[-1][1] = max(bursts[-1][1], k[1])
+        else:
+            bursts.append([k[0], k[1]])
+    ks = [k for k in lib if any(lo <= k[0] and k[1] <= hi for lo, hi in bursts)]
 agg = collections.OrderedDict()
 for s, e, n, q in ks:
     n = n.split("(")[0][-60:]
@@ -26,9 +31,15 @@ ev = []
 for s, e, n, q in ks:
     ev.append((s, 1)); ev.append((e, -1))
 ev.sort()
-depth, last, hist = 0, ev[0][0], collections.Counter()
-for t, d in ev:
-    hist[min(depth, 2)] += t - last
-    last = t; depth += d
+hist = collections.Counter()
+if bursts is None:
+    bursts = [[ev[0][0], ev[-1][0]]]
+for lo, hi in bursts:
+    depth, last = 0, lo
+    for t, d in ev:
+        if t < lo or t > hi:
+            continue
+        hist[min(depth, 2)] += t - last
+        last = t; depth += d
 tot = sum(hist.values())
-print("span %.3f ms: idle %.1f %%, one kernel %.1f %%, two or more %.1f %%" % (tot / 1e6, 100 * hist[0] / tot, 100 * hist[1] / tot, 100 * hist[2] / tot))
+print("pipelined span %.3f ms in %d burst(s): idle %.1f %%, one kernel %.1f %%, two or more %.1f %%" % (tot / 1e6, len(bursts), 100 * hist[0] / tot, 100 * hist[1] / tot, 100 * hist[2] / tot))
