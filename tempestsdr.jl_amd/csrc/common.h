@@ -65,6 +65,8 @@ struct tsdr_ctx {
   int opt_fft_big = 1;      // mixed-radix planner may use factors of 500 / 1000 / 2000 (three-register-step kernels)
   int opt_vsync_current_sy = 0;  // 1: vsync / the frame loop return s_y of the CURRENT image (the corrected ordering, off by default)
   int opt_fast_walk_only = 0;    // 1: the raster-free FAST frame path runs the raster walk with out == null (round 2's route; A/B)
+  int opt_down_spp_max_pct = 200; // raster-free FAST route: k_down_fused up to this many samples per raster pixel (percent), the raster walk above
+                                  // (round 4: 50 -> 200 once wide rows stage with 16 loads in flight: C3 0.40 -> 0.24 ms per buffer)
   int opt_down_xcd = 1;      // raster-free FAST kernel: XCD-aware tile order
   int opt_raster_split = 0;  // FAST frame loop with rasters: 1 = sheared raster-only kernel + raster-free image kernel, 2 = the same unsheared (A/B)
   int opt_ac_fuse_mid = 1;  // autocorrelation: last forward pass + power spectrum + first inverse pass as one launch

@@ -2,6 +2,8 @@
 // k_down_fused (the raster-free frame path) and sync.hip's sync-guard kernel, which re-derives single frames in the
 // exact operation sequence.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace tsdr {
@@ -94,6 +96,7 @@ struct DownParams {
   int y_t, x_t, h_out, w_out;
   int TC, NL, W, tiles_c;
   int lpl_log;
+  int ld16 = 0;                     // staging: 16 loads in flight per lane instead of 4 (wide rows)
   int sparse = 0;                   // 1: only the two source lines of every output row are staged (row r: staged rows 2r, 2r+1) --
                                     // for vertical ratios above 2, where the lines BETWEEN them would be more than half the tile
   int xcd_tpx = 0, xcd_tiles = 0;   // k_down_fused's XCD-aware 1-D grid: tiles per XCD and frame (0: plain (tile, frame) grid), tiles per frame
@@ -184,29 +187,35 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     } else { cdx[tid] = dx; cxs[tid] = ax1.sf * (double)kx; }
   }
   __syncthreads();
-  {  // stage the source lines: loads of up to four samples are issued before any |IQ| math
+  {  // stage the source lines: a lane's loads of one trip (4, or 16 for wide rows: q.ld16) are issued before any |IQ| math --
+     // with 4 in flight a wide tile (C3: 121 samples per line) is a chain of dependent round trips, 28 us per tile
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
-    for (int i = sub; i < nl; i += nsub) {
-      const int kf = kfirst[i];
-      for (int jb = j0; jb < q.W; jb += 4 * lpl) {
-        float re[4], im[4];
+    auto stage_rows = [&](auto ldc) {
+      constexpr int LD = decltype(ldc)::value;
+      for (int i = sub; i < nl; i += nsub) {
+        const int kf = kfirst[i];
+        for (int jb = j0; jb < q.W; jb += LD * lpl) {
+          float re[LD], im[LD];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned k = (unsigned)min(max(kf + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
-          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
-          else { re[u] = src[k]; im[u] = 0.f; }
-        }
+          for (int u = 0; u < LD; ++u) {
+            const unsigned k = (unsigned)min(max(kf + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
+            if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
+            else { re[u] = src[k]; im[u] = 0.f; }
+          }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int j = jb + u * lpl;
-          if (j < q.W) {
-            const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
-            reinterpret_cast<float *>(base)[i * Wp + j] = a;
+          for (int u = 0; u < LD; ++u) {
+            const int j = jb + u * lpl;
+            if (j < q.W) {
+              const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
+              reinterpret_cast<float *>(base)[i * Wp + j] = a;
+            }
           }
         }
       }
-    }
+    };
+    if (!EXACT && q.ld16) stage_rows(std::integral_constant<int, 16>{});
+    else stage_rows(std::integral_constant<int, 4>{});
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;

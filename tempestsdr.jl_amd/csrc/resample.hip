@@ -1013,9 +1013,12 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
         // staging lanes per line: a lane issues its loads four at a time, lpl samples apart, so a line costs
         // ceil(W / 4 lpl) * 4 lpl load slots -- the power of two that wastes the fewest (round 4: the former rule counted
         // ceil(W / lpl) * lpl and, for W = 29, chose 32 lanes per line: three of every four loads were clamped duplicates)
+        // wide rows (many samples per raster pixel): 16 loads in flight per lane, 8 lanes per line
+        const long LD = (!exact && W >= 48) ? 16 : 4;
+        pl.q.ld16 = LD == 16 ? 1 : 0;
         int best = 2; long best_slots = 1L << 60;
         for (int lg = 2; lg <= 6; ++lg) {
-          const long chunk = 4L << lg, slots = (long)ceil_div((size_t)W, (size_t)chunk) * chunk;
+          const long chunk = LD << lg, slots = (long)ceil_div((size_t)W, (size_t)chunk) * chunk;
           if (slots < best_slots || (slots == best_slots && lg > best)) { best = lg; best_slots = slots; }
         }
         pl.q.lpl_log = best;
@@ -1114,12 +1117,14 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
   if (!raster && ctx->precision == TSDR_FAST && cplx && !ctx->opt_fast_walk_only) {
     ProjLayout pl{};
     const DownPlan dp = plan_down(S, y_t, x_t, h_out, w_out, false);
-    // ... where there are few samples per raster pixel and a tile of at least 32 columns fits (C2: 0.115 samples per pixel, 64
-    // columns, 0.102 vs 0.123 ms per buffer; C5: 0.084, 32 columns because of its 239 source lines per tile, 0.138 vs 0.279 ms).
-    // At C3's 1.15 samples per pixel staging dominates either kernel and the walk wins (0.420 vs 0.461 ms): it keeps the route
-    // above 0.5 samples per pixel.
+    // ... where a tile of at least 32 columns fits (C2: 0.115 samples per raster pixel, 64 columns, 0.102 vs 0.123 ms per buffer
+    // in round 3; C5: 0.084, 0.138 vs 0.279 ms), or, above 0.5 samples per raster pixel, one of 16 (C3: 1.15 samples per pixel --
+    // the walk won there, 0.420 vs 0.461 ms, while the tap kernel staged its 121-sample rows four loads at a time: a chain of
+    // dependent round trips, 28 us per tile.  With 16 loads in flight per lane: 186 us against the walk's 323 + k_proj's 24,
+    // 0.243 vs 0.403 ms per buffer).  Option "down_spp_max_pct" (default 200) bounds the ratio; the walk keeps the rest.
     const double spp = (double)S / ((double)y_t * (double)x_t);   // samples per raster pixel
-    if (dp.fused && dp.q.TC >= 32 && spp <= 0.5 && !(y_t == h_out && x_t == w_out) && check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 2 && x_t >= 2) {
+    if (dp.fused && dp.q.TC >= (spp > 0.5 ? 16 : 32) && spp <= (double)ctx->opt_down_spp_max_pct * 0.01 && !(y_t == h_out && x_t == w_out) &&
+        check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 2 && x_t >= 2) {
       int rc = down_frames_d(ctx, in, cplx, in_stride, S, y_t, x_t, h_out, w_out, frames, down, down_stride, proj, got ? &pl : nullptr,
                              plan_only, keys);
       if (rc) return rc;
