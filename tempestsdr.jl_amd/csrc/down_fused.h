@@ -2,8 +2,6 @@
 // k_down_fused (the raster-free frame path) and sync.hip's sync-guard kernel, which re-derives single frames in the
 // exact operation sequence.
 #pragma once
-#include <type_traits>
-
 #include "common.h"
 
 namespace tsdr {
@@ -96,7 +94,7 @@ struct DownParams {
   int y_t, x_t, h_out, w_out;
   int TC, NL, W, tiles_c;
   int lpl_log;
-  int ld16 = 0;                     // staging: 16 loads in flight per lane instead of 4 (wide rows)
+  int ld16 = 0;                     // staging: 16 loads in flight per lane instead of 4 (wide rows): selects the LD = 16 kernel
   int sparse = 0;                   // 1: only the two source lines of every output row are staged (row r: staged rows 2r, 2r+1) --
                                     // for vertical ratios above 2, where the lines BETWEEN them would be more than half the tile
   int xcd_tpx = 0, xcd_tiles = 0;   // k_down_fused's XCD-aware 1-D grid: tiles per XCD and frame (0: plain (tile, frame) grid), tiles per frame
@@ -137,7 +135,9 @@ __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
 // every slot is written by exactly one lane, nothing is cleared; tile 0 clears the frame's two argmax keys.  psum_lds:
 // (NT + TC) floats of LDS beyond lds_dn's region.
 enum { DS_NONE = 0, DS_COLSUM = 1, DS_PSUM = 2 };
-template <bool CPLX, int MODE, int NT, int SUMS = DS_NONE>
+// LD: staging loads in flight per lane and trip (4; 16 for wide rows -- a template parameter, not a run-time branch: the
+// kernel's register allocation is the maximum over its paths, and 24 more VGPRs cost the 4-load geometries 18 %)
+template <bool CPLX, int MODE, int NT, int SUMS = DS_NONE, int LD = 4>
 __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
                                        float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn,
                                        float *__restrict__ colpart = nullptr, float *colT = nullptr) {
@@ -191,31 +191,26 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
      // with 4 in flight a wide tile (C3: 121 samples per line) is a chain of dependent round trips, 28 us per tile
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
-    auto stage_rows = [&](auto ldc) {
-      constexpr int LD = decltype(ldc)::value;
-      for (int i = sub; i < nl; i += nsub) {
-        const int kf = kfirst[i];
-        for (int jb = j0; jb < q.W; jb += LD * lpl) {
-          float re[LD], im[LD];
+    for (int i = sub; i < nl; i += nsub) {
+      const int kf = kfirst[i];
+      for (int jb = j0; jb < q.W; jb += LD * lpl) {
+        float re[LD], im[LD];
 #pragma unroll
-          for (int u = 0; u < LD; ++u) {
-            const unsigned k = (unsigned)min(max(kf + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
-            if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
-            else { re[u] = src[k]; im[u] = 0.f; }
-          }
+        for (int u = 0; u < LD; ++u) {
+          const unsigned k = (unsigned)min(max(kf + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
+          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
+          else { re[u] = src[k]; im[u] = 0.f; }
+        }
 #pragma unroll
-          for (int u = 0; u < LD; ++u) {
-            const int j = jb + u * lpl;
-            if (j < q.W) {
-              const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
-              reinterpret_cast<float *>(base)[i * Wp + j] = a;
-            }
+        for (int u = 0; u < LD; ++u) {
+          const int j = jb + u * lpl;
+          if (j < q.W) {
+            const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
+            reinterpret_cast<float *>(base)[i * Wp + j] = a;
           }
         }
       }
-    };
-    if (!EXACT && q.ld16) stage_rows(std::integral_constant<int, 16>{});
-    else stage_rows(std::integral_constant<int, 4>{});
+    }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63;

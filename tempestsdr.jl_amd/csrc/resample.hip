@@ -589,6 +589,9 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
       }
     }
     if (sub < NL) consume(sub, re, im);
+    // (Round 4, tried: the remaining lines' loads three lines at a time -- C3's tiles are four dependent round trips per
+    // thread.  The kernel's store addressing (scalar base, "s" asm constraint) does not survive the extra register
+    // pressure: the build fails, and with the base forced through readfirstlane the kernel faults.  Left as it was.)
     for (int r = sub + nsub; r < NL; r += nsub) {
       issue(r, re, im);
       consume(r, re, im);
@@ -699,7 +702,7 @@ __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__
 // grid = (tiles, frames)
 // (256 threads per 64 x 64-pixel tile: 512 threads measured 55.9 us, 512 threads on 64 x 128 58.5 us, 128 threads 70.4 us, against 54.3 us)
 constexpr int kDownNT = 256;
-template <bool CPLX, int MODE, int SUMS = DS_NONE>
+template <bool CPLX, int MODE, int SUMS = DS_NONE, int LD = 4>
 __global__ __launch_bounds__(kDownNT) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
                                                     float *__restrict__ out, size_t out_stride, size_t lds_main) {
   extern __shared__ double lds_dn[];
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(kDownNT) void k_down_fused(const float *__restrict_
     tile = (int)(xcd * (unsigned)q.xcd_tpx + (sidx - (unsigned)f * (unsigned)q.xcd_tpx));
     if (tile >= q.xcd_tiles) return;
   }
-  down_fused_body<CPLX, MODE, kDownNT, SUMS>(in, in_stride, q, out, out_stride, tile, f, lds_dn, nullptr,
+  down_fused_body<CPLX, MODE, kDownNT, SUMS, LD>(in, in_stride, q, out, out_stride, tile, f, lds_dn, nullptr,
                                          reinterpret_cast<float *>(reinterpret_cast<char *>(lds_dn) + lds_main));
 }
 
@@ -1062,18 +1065,28 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
     const size_t lds_main = (pl.lds + 15) & ~(size_t)15;
 #define DOWNK(C, M, SUMS, NAME, LDS) \
   TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS>), grid, dim3(kDownNT), LDS, in, in_stride, pl.q, out, out_stride, lds_main)
+#define DOWNK16(C, M, SUMS, NAME, LDS) \
+  TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS, 16>), grid, dim3(kDownNT), LDS, in, in_stride, pl.q, out, out_stride, lds_main)
+    const size_t lds_ps = lds_main + (kDownNT + (size_t)pl.q.TC) * 4;
     if (cplx) {
       if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, DS_NONE, "down_fused_iq_exact", pl.lds); }
       else if (psum) {
         pl.q.proj = proj; pl.q.proj_stride = proj_floats(h_out, w_out, *got); pl.q.keys = keys;
-        if (pl.mode == DM_FAST_FX) { DOWNK(true, DM_FAST_FX, DS_PSUM, "down_fused_iq_sums", lds_main + (kDownNT + (size_t)pl.q.TC) * 4); }
-        else { DOWNK(true, DM_FAST_F32, DS_PSUM, "down_fused_iq_sums", lds_main + (kDownNT + (size_t)pl.q.TC) * 4); }
+        if (pl.mode == DM_FAST_FX) {
+          if (pl.q.ld16) { DOWNK16(true, DM_FAST_FX, DS_PSUM, "down_fused_iq_sums", lds_ps); } else { DOWNK(true, DM_FAST_FX, DS_PSUM, "down_fused_iq_sums", lds_ps); }
+        } else {
+          if (pl.q.ld16) { DOWNK16(true, DM_FAST_F32, DS_PSUM, "down_fused_iq_sums", lds_ps); } else { DOWNK(true, DM_FAST_F32, DS_PSUM, "down_fused_iq_sums", lds_ps); }
+        }
       }
-      else if (pl.mode == DM_FAST_FX) { DOWNK(true, DM_FAST_FX, DS_NONE, "down_fused_iq", pl.lds); }
+      else if (pl.mode == DM_FAST_FX) {
+        if (pl.q.ld16) { DOWNK16(true, DM_FAST_FX, DS_NONE, "down_fused_iq", pl.lds); } else { DOWNK(true, DM_FAST_FX, DS_NONE, "down_fused_iq", pl.lds); }
+      }
+      else if (pl.q.ld16) { DOWNK16(true, DM_FAST_F32, DS_NONE, "down_fused_iq", pl.lds); }
       else { DOWNK(true, DM_FAST_F32, DS_NONE, "down_fused_iq", pl.lds); }
     } else {
       DOWNK(false, DM_EXACT, DS_NONE, "down_fused_f32_exact", pl.lds);
     }
+#undef DOWNK16
 #undef DOWNK
     return TSDR_OK;
   }
