@@ -104,6 +104,8 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *   "raster_split" 0 (default): the TSDR_FAST frame loop with rasters is ONE launch that walks every raster pixel and forms raster,
  *                 600x800 image and projection sums; 1: rasters by the store-aligned ("sheared") raster-only kernel + images by the
  *                 raster-free kernel (two launches, IQ read twice: measured slower, kept as the A/B); 2: the same unsheared.
+ *   "down_spp_max_pct" the raster-free TSDR_FAST route uses the tap kernel up to this many samples per raster pixel, in percent
+ *                 (default 200), the raster walk with out == NULL above; "down_xcd" 1 (default): XCD-aware tile order of that kernel.
  *   "beta_waves"  wavefronts per workgroup of the vsync statistics kernel: 4 (default) or 8; identical results.
  *   "pipe_mode"   how tsdr_frames_submit_d arranges successive buffers on its internal streams: 0 = image launches on one stream,
  *                 every buffer's tail on a second one of the highest priority; 1 = whole buffers alternate between equal
@@ -111,7 +113,8 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 (what measured best on C2).  "pipe_lanes": equal streams of arrangement 1 (2; 3 pays only with
  *                 GPU_MAX_HW_QUEUES >= 8).  "pipe_priority": 0 = no stream priority for the tails (before the first use).
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
- * TSDR_BETA_WAVES / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY preset them, read once in tsdr_create. */
+ * TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT
+ * preset them, read once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
 /* running totals of the sync guard on this context: frames whose margins were checked / frames flagged (re-evaluated in
  * the TSDR_EXACT sequence, one by one or as part of a whole exact buffer).  Synchronises; reset != 0 zeroes the totals. */

@@ -191,22 +191,34 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
      // with 4 in flight a wide tile (C3: 121 samples per line) is a chain of dependent round trips, 28 us per tile
     const int lpl = 1 << q.lpl_log;
     const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
-    for (int i = sub; i < nl; i += nsub) {
-      const int kf = kfirst[i];
-      for (int jb = j0; jb < q.W; jb += LD * lpl) {
-        float re[LD], im[LD];
+    // LN lines per trip (two when a lane has few loads per line): the loads of both are in flight before either is consumed --
+    // with 32 lines per pass a C2 tile (121 lines, 4 loads per lane and line) was four dependent round trips
+    constexpr int LN = LD <= 4 ? 2 : 1;
+    for (int i = sub; i < nl; i += LN * nsub) {
+      int kf[LN];
 #pragma unroll
-        for (int u = 0; u < LD; ++u) {
-          const unsigned k = (unsigned)min(max(kf + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
-          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
-          else { re[u] = src[k]; im[u] = 0.f; }
+      for (int n = 0; n < LN; ++n) kf[n] = kfirst[min(i + n * nsub, nl - 1)];
+      for (int jb = j0; jb < q.W; jb += LD * lpl) {
+        float re[LN][LD], im[LN][LD];
+#pragma unroll
+        for (int n = 0; n < LN; ++n) {
+#pragma unroll
+          for (int u = 0; u < LD; ++u) {
+            const unsigned k = (unsigned)min(max(kf[n] + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
+            if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[n][u] = z.x; im[n][u] = z.y; }
+            else { re[n][u] = src[k]; im[n][u] = 0.f; }
+          }
         }
 #pragma unroll
-        for (int u = 0; u < LD; ++u) {
-          const int j = jb + u * lpl;
-          if (j < q.W) {
-            const float a = !CPLX ? re[u] : EXACT ? abs_iq<true>(re[u], im[u]) : abs_iq_rn(re[u], im[u]);
-            reinterpret_cast<float *>(base)[i * Wp + j] = a;
+        for (int n = 0; n < LN; ++n) {
+          const int in = i + n * nsub;
+#pragma unroll
+          for (int u = 0; u < LD; ++u) {
+            const int j = jb + u * lpl;
+            if (j < q.W && in < nl) {
+              const float a = !CPLX ? re[n][u] : EXACT ? abs_iq<true>(re[n][u], im[n][u]) : abs_iq_rn(re[n][u], im[n][u]);
+              reinterpret_cast<float *>(base)[in * Wp + j] = a;
+            }
           }
         }
       }

@@ -12,9 +12,9 @@ NAMES = {  # kernel-name substring -> bench.py's launch name
     "k_raster_fast<true, true, true, 32, false": "down_walk_iq",
     "k_raster_tile<true, true>": "raster_down_iq_exact",
     "k_shift_iir": "shift_iir", "k_proj": "sync_proj", "k_beta": "sync_beta", "k_tail": "sync_beta+shift_iir",
-    "k_down_fused<true, 0, 0>": "down_fused_iq_exact", "k_down_fused<true, 2, 2>": "down_fused_iq_sums",
-    "k_down_fused<true, 2, 0>": "down_fused_iq", "k_guard": "sync_guard",
-    "k_down_fused<true, 3, 2>": "down_fused_iq_sums", "k_down_fused<true, 3, 0>": "down_fused_iq",
+    "k_down_fused<true, 0, 0": "down_fused_iq_exact", "k_down_fused<true, 2, 2": "down_fused_iq_sums",
+    "k_down_fused<true, 2, 0": "down_fused_iq", "k_guard": "sync_guard",
+    "k_down_fused<true, 3, 2": "down_fused_iq_sums", "k_down_fused<true, 3, 0": "down_fused_iq",
     "k_raster_shear<true>": "raster_sheared_iq", "k_raster_shear<false>": "raster_unsheared_iq",
     "k_seg1024<false": "welch_seg1024", "k_seg1024<true": "waterfall_seg1024",
 }
