@@ -375,8 +375,9 @@ def frames_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, frames_ou
 
 def frames_submit_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, frames_out=None, raster_out=None,
                     sync_idx=None):
-    """frames_d as a two-stage pipeline across successive buffers: only enqueues; the raster stage of this
-    buffer overlaps the vsync/IIR stage of the previous one.  Outputs are complete after frames_flush(ctx)."""
+    """frames_d pipelined across successive buffers on the library's internal streams: only enqueues; the tail of a
+    buffer (statistics, guard, shift + IIR) runs beside the image launch of the next.  Up to three submissions in flight, each
+    with its own outputs.  Outputs are complete after frames_flush(ctx) in stream order / ctx.synchronize() on the host."""
     n = C.c_int(0)
     ctx.call("tsdr_frames_submit_d", C.c_void_p(sync.h if sync is not None else 0), _ptr(iq), int(nEch), int(S), int(y_t),
              int(x_t), C.c_float(alpha), int(bool(do_align)), _ptr(state), _ptr(frames_out), _ptr(raster_out),

@@ -178,7 +178,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
 
 int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream) {
   if (!ctx) return TSDR_EINVAL;
-  {  // the pipeline's deferred stage belongs to the old stream
+  {  // buffers submitted to the pipeline are ordered through the old stream
     int rc = tsdr::pipe_drain(ctx);
     if (rc) return rc;
   }
@@ -210,7 +210,7 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "ac_fuse_mid")) ctx->opt_ac_fuse_mid = value != 0;
   else if (!strcmp(name, "fast_walk_only")) ctx->opt_fast_walk_only = value != 0;
   else if (!strcmp(name, "vsync_current_sy")) {
-    int rc = tsdr::pipe_drain(ctx);   // a deferred shift + IIR stage was submitted under the old setting
+    int rc = tsdr::pipe_drain(ctx);   // (submitted buffers keep the old setting; later calls are ordered behind them)
     if (rc) return rc;
     ctx->opt_vsync_current_sy = value != 0;
   }
@@ -343,7 +343,7 @@ void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes) {
 int tsdr_dev_free(tsdr_ctx *ctx, void *dev) {
   if (!ctx) return TSDR_EINVAL;
   if (dev) {
-    int rc = tsdr::pipe_drain(ctx);  // the deferred pipeline stage may still have to write into this buffer
+    int rc = tsdr::pipe_drain(ctx);  // a submitted buffer may still have to write into this allocation
     if (rc) return rc;
     TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     TSDR_HIP(ctx, hipFree(dev));

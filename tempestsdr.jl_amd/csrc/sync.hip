@@ -996,7 +996,7 @@ int tsdr_sync_reset(tsdr_sync *s) {
 void tsdr_sync_free(tsdr_sync *s) {
   if (!s) return;
   if (s->ctx) {
-    (void)pipe_drain(s->ctx);  // the deferred stage reads this state's pending s_y: enqueue it before the state goes
+    (void)pipe_drain(s->ctx);  // submitted buffers read this state's pending s_y: they come first
     (void)hipStreamSynchronize(s->ctx->stream);
   }
   for (auto &b : s->bset) for (float *p : b) if (p) (void)hipFree(p);

@@ -113,10 +113,14 @@ def test_frames_many_frames(ctx, tsdr, synth, precision):
     assert np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
 
 
-def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
-    """tsdr_frames_submit_d / tsdr_frames_flush (raster stage of buffer k+1 in flight with the vsync/IIR stage of
-    buffer k) must return, bit for bit, what one tsdr_frames_d call per buffer returns: same kernels, same
-    order per stage, and the SyncXY / imageOut state threaded through the buffers."""
+@pytest.mark.parametrize("want_raster", [True, False])
+@pytest.mark.parametrize("mode", [-1, 0, 1])
+def test_frames_pipeline_matches_sequential(ctx, tsdr, synth, want_raster, mode):
+    """tsdr_frames_submit_d / tsdr_frames_flush (the tail of a buffer in flight beside the image launch of the next, on the
+    library's internal streams) must return, bit for bit, what one tsdr_frames_d call per buffer returns: same kernels,
+    and the SyncXY / imageOut state threaded through the buffers.  Both arrangements ("pipe_mode" 0: image lane + tail
+    lane; 1: whole buffers on alternating equal lanes; -1: the default choice by whether rasters are written), with and
+    without rasters, five buffers so that the three slots wrap."""
     from tempestsdr_jl_amd import api
     Fs, x_t, y_t, fv, nfr, nbuf = 2.0e6, 1056, 628, 60.0, 4, 5
     S = synth.samples_per_frame(Fs, fv)
@@ -128,7 +132,7 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
         d_state = ctx.upload(np.zeros(npx, np.float32))
         d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
         d_fr = [ctx.dev_alloc(nfr * npx * 4) for _ in bufs]
-        d_ra = [ctx.dev_alloc(nfr * P * 4) for _ in bufs]
+        d_ra = [ctx.dev_alloc(nfr * P * 4) if want_raster else None for _ in bufs]
         d_ix = [ctx.dev_alloc(nfr * 8) for _ in bufs]
         try:
             for b in range(nbuf):
@@ -138,24 +142,29 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth):
             if pipelined and flush:
                 api.frames_flush(ctx)
             ctx.synchronize()  # header contract: complete after tsdr_synchronize even without a flush
-            return ([ctx.download(p, (nfr * npx,), np.uint32) for p in d_fr], [ctx.download(p, (nfr * P,), np.uint32) for p in d_ra],
+            return ([ctx.download(p, (nfr * npx,), np.uint32) for p in d_fr],
+                    [ctx.download(p, (nfr * P,), np.uint32) for p in d_ra] if want_raster else [],
                     [ctx.download(p, (nfr * 2,), np.int32) for p in d_ix], ctx.download(d_state, (npx,), np.uint32))
         finally:
-            for p in [d_state] + d_iq + d_fr + d_ra + d_ix:
+            for p in [d_state] + d_iq + d_fr + [r for r in d_ra if r is not None] + d_ix:
                 ctx.dev_free(p)
 
     a = run(False)
-    for b in (run(True), run(True, flush=False)):
-        for k in range(3):
-            for x, y in zip(a[k], b[k]):
-                assert np.array_equal(x, y)
-        assert np.array_equal(a[3], b[3])
+    ctx.set_option("pipe_mode", mode)
+    try:
+        for b in (run(True), run(True, flush=False)):
+            for k in range(3):
+                for x, y in zip(a[k], b[k]):
+                    assert np.array_equal(x, y)
+            assert np.array_equal(a[3], b[3])
+    finally:
+        ctx.set_option("pipe_mode", -1)
 
 
 def test_pipeline_pending_stage_is_drained_by_other_entry_points(ctx, tsdr, synth):
-    """The shift + IIR stage of the last submitted buffer is deferred.  Entry points that use the same SyncXY / IIR
-    state outside the pipeline (tsdr_vsync_d here, tsdr_frames_d) and tsdr_sync_free must enqueue it first: the results
-    equal the strictly sequential ones and nothing runs on freed memory."""
+    """Submitted buffers run on the pipeline's internal streams.  Entry points that use the same SyncXY / IIR state
+    outside the pipeline (tsdr_vsync_d here, tsdr_frames_d) and tsdr_sync_free must order themselves behind them first: the
+    results equal the strictly sequential ones and nothing runs on freed memory."""
     from tempestsdr_jl_amd import api
     Fs, x_t, y_t, fv, nfr = 2.0e6, 1056, 628, 60.0, 3
     S = synth.samples_per_frame(Fs, fv)
@@ -176,7 +185,7 @@ def test_pipeline_pending_stage_is_drained_by_other_entry_points(ctx, tsdr, synt
             out = (ctx.download(d_fr, (nfr * npx,), np.uint32), ctx.download(d_ix, (nfr * 2,), np.int32),
                    ctx.download(d_state, (npx,), np.uint32), tuple(int(v) for v in s_yx))
             f(ctx, sync, d_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, None, d_ix)
-            sync.close()                    # frees the state with a stage still deferred
+            sync.close()                    # frees the state with submitted work possibly still in flight
             ctx.synchronize()
             return out
         finally:
