@@ -385,3 +385,46 @@ def test_frames_fast_sheared_raster_route(ctx, tsdr, synth, case, split):
     finally:
         ctx.set_option("raster_split", 0)
     assert r["n_frames"] == case["nfr"] and not r["ties"]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_frames_pipeline_without_alignment_and_mixed_with_one_call(ctx, tsdr, synth, mode):
+    """tsdr_frames_submit_d with do_align = 0 (no statistics, no guard: image launch + IIR only), and submissions
+    interleaved with plain tsdr_frames_d calls on the same IIR state: the context's stream and the pipeline's internal
+    streams must hand the state over in call order."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y_t, fv, nfr, nbuf = 2.0e6, 1056, 628, 60.0, 3, 6
+    S = synth.samples_per_frame(Fs, fv)
+    npx = 600 * 800
+    bufs = [synth.synth_leak(Fs, x_t, y_t, fv, S * nfr, n0=b * S * nfr) for b in range(nbuf)]
+
+    def run(kinds, do_align):
+        sync = tsdr.SyncXY(ctx, 600, 800) if do_align else None
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
+        d_fr = [ctx.dev_alloc(nfr * npx * 4) for _ in bufs]
+        d_ix = [ctx.dev_alloc(nfr * 8) for _ in bufs]
+        try:
+            for b, kind in enumerate(kinds):
+                f = api.frames_submit_d if kind == "s" else api.frames_d
+                assert f(ctx, sync, d_iq[b], bufs[b].size, S, y_t, x_t, np.float32(0.25), do_align, d_state, d_fr[b], None,
+                         d_ix[b] if do_align else None) == nfr
+            ctx.synchronize()
+            return [ctx.download(p, (nfr * npx,), np.uint32) for p in d_fr], ctx.download(d_state, (npx,), np.uint32)
+        finally:
+            if sync is not None:
+                sync.close()
+            for p in [d_state] + d_iq + d_fr + d_ix:
+                ctx.dev_free(p)
+
+    ctx.set_option("pipe_mode", mode)
+    try:
+        for do_align in (False, True):
+            want = run("dddddd", do_align)
+            for kinds in ("ssssss", "sdsdds", "ddssss"):
+                got = run(kinds, do_align)
+                for x, y in zip(want[0], got[0]):
+                    assert np.array_equal(x, y), (kinds, do_align)
+                assert np.array_equal(want[1], got[1]), (kinds, do_align)
+    finally:
+        ctx.set_option("pipe_mode", -1)
