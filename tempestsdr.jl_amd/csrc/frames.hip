@@ -286,6 +286,14 @@ void pipe_sync_lanes(tsdr_ctx *ctx) {
   for (auto l : ctx->lane) if (l) (void)hipStreamSynchronize(l);
 }
 
+// A submission that fails half-way has launches on the lanes that no later drain would order (pipe_n is not advanced):
+// the error path waits for the lanes on the host, so that the state handed back is quiescent.
+struct SubmitGuard {
+  tsdr_ctx *ctx; bool ok = false;
+  explicit SubmitGuard(tsdr_ctx *c) : ctx(c) {}
+  ~SubmitGuard() { if (!ok) pipe_sync_lanes(ctx); }
+};
+
 struct LaneScope {  // launches of this scope go to a lane
   tsdr_ctx *ctx; hipStream_t saved;
   LaneScope(tsdr_ctx *c, int lane) : ctx(c), saved(c->launch_stream) { c->launch_stream = c->lane[lane]; c->pipe_lane = lane; }
@@ -338,6 +346,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   float *proj = nullptr;
   ProjLayout plan{}, got{};
   PrecisionScope scope(ctx);
+  SubmitGuard submitted(ctx);
   GuardPlan gp;
   rc = guard_prepare(ctx, sync, S, y_t, x_t, do_align, F, slot, NS, &gp);
   if (rc) return rc;
@@ -424,6 +433,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   ctx->pipe_last_slot = slot;
   ++ctx->pipe_seq;
   ++ctx->pipe_n;
+  submitted.ok = true;
   return TSDR_OK;
 }
 
