@@ -230,22 +230,30 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
 // Half of a buffer's sequence is a latency-bound tail (vsync statistics, sync guard, shift + IIR: chains of LDS and L2
 // latencies that leave most of the machine idle) behind one throughput-bound launch (raster / images).  Two independent
 // capture streams on one GPU fill each other's gaps (round 3: +29 % raster-free, +7 % with rasters); the same overlap is
-// available to ONE capture stream, because the tail of buffer k and the image launch of buffer k+1 are independent:
-//     image lane:  R(k)      R(k+1)            R(k+2)  ...          back to back
-//     tail lane :       [R(k) done] B(k) G(k) C(k)  [R(k+1) done] B(k+1) ...
-// The image launches of successive submissions go to one internal HIP stream, the tails to a second one created with
-// the highest stream priority -- its few, short-lived workgroups take the slots the image kernel's workgroups free
-// instead of queueing behind thousands of them (without the priority, shift + IIR beside the image kernel is stretched
-// to the image kernel's length: rocprofv3 trace in profiles/r04_*).  Hand-overs: one event per buffer from the image lane
-// to the tail lane (its latency delays the tail, which has the slack, never the image lane), and one from the tail of
-// submission k to the image launch of submission k+3, which reuses its image / key / projection slot -- long satisfied
-// when it is reached.  The sequential couplings of the loop (lagged s_y, IIR recurrence) all sit in shift + IIR, i.e. in
-// stream order on the tail lane.
+// available to ONE capture stream, because everything that couples successive buffers -- the lagged s_y, the IIR
+// recurrence -- sits in shift + IIR.  Two arrangements on internal HIP streams ("lanes"), chosen per submission by whether
+// rasters are written (option "pipe_mode"; measurements: DESIGN.md section 4):
+//
+//  A (with rasters)   image lane:  R(k)      R(k+1)            R(k+2)  ...          back to back
+//                     tail lane :       [R(k) done] B(k) G(k) C(k)  [R(k+1) done] B(k+1) ...
+//    The tail lane has the highest stream priority: its few, short-lived workgroups take the slots the image kernel's
+//    workgroups free instead of queueing behind thousands of them.  Hand-overs: one event per buffer from the image lane to
+//    the tail lane (its latency delays the tail, which has the slack, never the image lane), and one from the tail of
+//    submission k to the image launch of submission k+3, which reuses its image / key / projection slot -- long satisfied
+//    when it is reached.  The shift + IIR launches are in stream order on the tail lane.
+//
+//  B (raster-free)    lane 0:  R(k)   B(k)   G(k)   [C(k-1) done] C(k)      R(k+2) ...
+//                     lane 1:      R(k+1) B(k+1) G(k+1)       [C(k) done] C(k+1)     ...
+//    Whole buffers alternate between equal lanes; only shift + IIR waits, through an event, for the previous buffer's on the
+//    other lane.  Two raster-free image launches overlap each other well (one's staging under the other's pixel loop); two
+//    raster launches do not (both held by the store stream), which is why A serves them.  The statistics of two buffers may
+//    run side by side here: beta matrices, guard queue words and workspaces exist per lane.
+//
 // The caller's inputs are ordered through the context's stream: a submission waits for whatever that stream holds at
-// the time of the call, and tsdr_frames_flush orders the context's stream behind everything submitted.
+// the time of the call (nothing when it is idle, the steady state), and tsdr_frames_flush orders the context's stream
+// behind everything submitted.
 // History (rounds 1-3, measured and dropped): R on one stream and B + C on another without priorities (the two launches
-// slowed each other down); B(k) + C(k-1) as one launch ("k_tail": 43 us = 17 + 22, no overlap inside the launch); round 4's
-// first form, whole buffers alternating between two equal streams (+10 % raster-free, 0 % with rasters).
+// slowed each other down); B(k) + C(k-1) as one launch ("k_tail": 43 us = 17 + 22, no overlap inside the launch).
 }  // extern "C"
 
 namespace tsdr {
