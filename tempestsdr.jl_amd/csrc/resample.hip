@@ -979,7 +979,7 @@ struct DownPlan { bool fused; int mode; DownParams q; size_t lds; };
 int raster_shear_d(tsdr_ctx *ctx, const float *in, size_t in_stride, size_t S, int y_t, int x_t, int frames, float *out,
                    size_t out_stride, bool shear, bool *did, bool plan_only);
 
-static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool exact, bool wide_exact = false) {
+static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool exact, bool wide_exact = false, bool guard_tiles = false) {
   DownPlan pl;
   pl.fused = false;
   pl.lds = 0;
@@ -998,7 +998,9 @@ static DownPlan plan_down(size_t S, int y_t, int x_t, int h_out, int w_out, bool
   const int *cand = (exact && !wide_exact) ? cand_exact : cand_fast;   // wide_exact: the EXACT frame path (not the sync guard's tiles)
   for (int pass = 1; pass < 3 && !pl.fused; ++pass) {
     const int sb = 4;
-    const size_t cap = pass == 2 ? 60 * 1024 : 32 * 1024;
+    // (the sync guard's kernel runs one workgroup per CU and opts in to a large LDS: the widest tile that fits 96 KiB -- at C3
+    // 32 columns instead of 16, i.e. one round of image tiles per flagged frame instead of two)
+    const size_t cap = guard_tiles ? 96 * 1024 : pass == 2 ? 60 * 1024 : 32 * 1024;
     for (int ci = 0; ci < 5 && cand[ci] > 0; ++ci) {
       const int TC = cand[ci];
       const long DPX = (long)((double)(TC - 1) * sfx) + 2;
@@ -1108,7 +1110,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
 bool guard_image_plan(tsdr_ctx *ctx, size_t S, int y_t, int x_t, int h_out, int w_out, DownParams *q, size_t *lds) {
   if (check_geom(ctx, S, y_t, x_t)) return false;
   if ((y_t == h_out && x_t == w_out) || y_t < 2 || x_t < 2) return false;
-  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, /*exact=*/true);
+  DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, /*exact=*/true, false, /*guard_tiles=*/true);
   if (!pl.fused) return false;
   *q = pl.q;
   *lds = pl.lds;

@@ -31,6 +31,7 @@
 // ties = first maximum in column-major order (only the column of the maximum is ever used, :66,:76).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 #include "down_fused.h"
@@ -681,6 +682,7 @@ int sync_scan_d(tsdr_sync *s, const float *img, size_t img_stride, int frames, u
 // number of resident workgroups.  Hand-over between items of different CUs: every storing wavefront drains its stores,
 // workgroup barrier, one lane release-fences and bumps the frame's counter; the consumer polls the counter, acquire-
 // fences, barrier (MI355X_MICROARCH.md, inter-workgroup visibility).  The last workgroup to leave zeroes the queue words.
+constexpr size_t kGuardLdsMax = 128 * 1024;   // k_guard's dynamic LDS opt-in (one workgroup per CU)
 struct GuardSync {          // device words, all zero between launches
   unsigned ticket, exited;
   unsigned done[1];         // [2 * frames]: items A / B finished per LIST position
@@ -837,11 +839,11 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
 #else
   GuardAllArgs a{};
   if (!guard_image_plan(ctx, S, y_t, x_t, s->y_t, s->x_t, &a.dq, &a.lds_bytes)) return TSDR_OK;
-  {  // the launch's dynamic LDS plus k_guard's static arrays (list, colk, ticket words: < 4 KiB) must fit the 64 KiB a
-     // workgroup gets without opting in -- an exotic geometry's exact tiles may take up to 60 KiB on their own; the frame
-     // loop then falls back to whole buffers in TSDR_EXACT, as for geometries without a fused exact kernel
+  {  // the launch's dynamic LDS (exact tiles of up to 96 KiB + their column-sum scratch) plus k_guard's static arrays (list,
+     // colk, ticket words: < 4 KiB) must fit what the kernel opted in to; otherwise the frame loop falls back to whole
+     // buffers in TSDR_EXACT, as for geometries without a fused exact kernel
     const size_t lds_a = ((a.lds_bytes + 15) & ~(size_t)15) + (size_t)a.dq.TC * 65 * 4;
-    if (std::max(lds_a, kProjLds) + 4096 > 65536) return TSDR_OK;
+    if (std::max(lds_a, kProjLds) + 4096 > kGuardLdsMax) return TSDR_OK;
   }
   if (can) *can = true;
   if (plan_only || frames <= 0) return TSDR_OK;
@@ -880,6 +882,15 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     // workgroup with 52 KiB of LDS, not their number, so it bought nothing there and cost C3, where a frame is flagged every
     // other buffer, 0.11 instead of 0.057 ms per step.)
     const unsigned grid = g.count_only ? 1u : (unsigned)ncu;
+    if (lds > 64 * 1024) {   // above what a kernel gets without opting in
+      static std::mutex mu;
+      static bool opted = false;
+      std::lock_guard<std::mutex> lk(mu);
+      if (!opted) {
+        TSDR_HIP(ctx, hipFuncSetAttribute((const void *)k_guard, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGuardLdsMax));
+        opted = true;
+      }
+    }
     TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
   }
   return TSDR_OK;
