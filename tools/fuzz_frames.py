@@ -1,7 +1,8 @@
 """Development aid (GPU box): the FAST frame loop with the sync guard on random geometries of the synthetic leak (both
 blanking profiles), several buffers in a row (IIR state and the pending s_y carried across calls), through the one-call
 entry point and the software pipeline (submit / flush) -- against the CPU oracle frame by frame: identical sync indices on
-every frame, frames within 6e-7 relative, and the guard's counters consistent."""
+every frame, frames within 1e-6 relative (the tests assert 6e-7 on their fixed cases; over ~400 random cases the raster-free
+kernel's f32 blends reached 6.65e-7; north_star's bar is 1e-5), and the guard's counters consistent."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -74,9 +75,9 @@ for it in range(ncase):
     assert gidx == oidx, ("sync indices", it, S, y_t, x_t, card, pipelined, [(i, a, b) for i, (a, b) in enumerate(zip(gidx, oidx)) if a != b][:4])
     for f, (a, b) in enumerate(zip(gframes, oframes)):
         e = relerr(a, b); worst = max(worst, e); case_worst = max(case_worst, e)
-        assert e < 6e-7, ("frame", it, f, S, y_t, x_t, card, pipelined, e)
+        assert e < 1e-6, ("frame", it, f, S, y_t, x_t, card, pipelined, e)
     e = relerr(gstate, ostate); worst = max(worst, e)
-    assert e < 6e-7, ("state", it, e)
+    assert e < 1e-6, ("state", it, e)
     c, fl = ctx.sync_guard_stats()
     assert c in (0, nbuf * nfr), (c, nbuf * nfr)   # 0: a geometry the guard does not cover runs in TSDR_EXACT
     tot_checked += c; tot_flagged += fl
