@@ -66,7 +66,7 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
  *   TSDR_EXACT: the reference's evaluation order -- f64 source coordinate sf*i+off and f64 weights,
  *               one rounding to f32 per value; bit-identical to the CPU oracle.
  *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend (within
- *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp): pixels within ~3 ulp
+ *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp) in the raster walk, 32.32 fixed-point coordinates + f32 blends in the raster-free kernel: pixels within a few ulp
  *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing reached 6.65e-7) of TSDR_EXACT; ~2.5x fewer
  *               VALU cycles.  Default.  The images' projection
  *               sums are then formed inside the raster kernel (per-tile partial sums, added in tile order)
