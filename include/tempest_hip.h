@@ -67,7 +67,7 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
  *               one rounding to f32 per value; bit-identical to the CPU oracle.
  *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend (within
  *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp) in the raster walk, 32.32 fixed-point coordinates + f32 blends in the raster-free kernel: pixels within a few ulp
- *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing reached 6.65e-7) of TSDR_EXACT; ~2.5x fewer
+ *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing and white noise reach 4.7e-7) of TSDR_EXACT; ~2.5x fewer
  *               VALU cycles.  Default.  The images' projection
  *               sums are then formed inside the raster kernel (per-tile partial sums, added in tile order)
  *               instead of by a second pass over the images in the reference's row order, so beta differs from
@@ -104,7 +104,8 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 re-evaluated one by one.
  *   "raster_split" 0 (default): the TSDR_FAST frame loop with rasters is ONE launch that walks every raster pixel and forms raster,
  *                 600x800 image and projection sums; 1: rasters by the store-aligned ("sheared") raster-only kernel + images by the
- *                 raster-free kernel (two launches, IQ read twice: measured slower, kept as the A/B); 2: the same unsheared.
+ *                 raster-free kernel (two launches, IQ read twice: measured slower, kept as the A/B;
+ *                 rasters and images then round independently -- white noise: 7e-7 where the default stays below 5e-7); 2: the same unsheared.
  *   "down_spp_max_pct" the raster-free TSDR_FAST route uses the tap kernel up to this many samples per raster pixel, in percent
  *                 (default 200), the raster walk with out == NULL above; "down_xcd" 1 (default): XCD-aware tile order of that kernel.
  *   "beta_waves"  wavefronts per workgroup of the vsync statistics kernel: 4 (default) or 8; identical results.

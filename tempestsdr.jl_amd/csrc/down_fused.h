@@ -31,9 +31,6 @@ __device__ inline float fast_blend(float a, float b, double d) {
   return (float)fma(d, (double)b - (double)a, (double)a);
 }
 
-// (1-t) a + t b, 0 <= t <= 1, in f32 with two FMAs (see DM_FAST_FX)
-__device__ __forceinline__ float lerp2(float a, float b, float t) { return __fmaf_rn(t, b, __fmaf_rn(-t, a, a)); }
-
 // sum over the 64 lanes by the fixed DPP tree (row_shr 1, 2, 4, 8, then row_bcast 15 and 31); the total lands in lane 63.
 // Each step is ONE in-place v_add_f32_dpp -- v[i] += v[i - k] on the lanes the step reaches; lanes it does not reach (out of
 // their row: bound_ctrl reads 0; masked by row / bank mask: not written) keep their value, i.e. add 0.  Written as assembly
@@ -182,7 +179,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     const int kx = (int)rs_pos(axx, (double)(c + 1), dx);
     ckx[tid] = kx;
     if (FX) {  // the same table slots: weight as f32, sf*kx in 32.32 fixed point
-      reinterpret_cast<float *>(cdx)[tid] = (float)dx;
+      reinterpret_cast<float2 *>(cdx)[tid] = make_float2((float)dx, (float)(1.0 - dx));
       reinterpret_cast<long long *>(cxs)[tid] = __double2ll_rd(ax1.sf * (double)kx * 4294967296.0);
     } else { cdx[tid] = dx; cxs[tid] = ax1.sf * (double)kx; }
   }
@@ -248,12 +245,12 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   // FX: 32.32 fixed-point coordinates of the two lines' first raster pixel, relative to the staged rows' first samples
   long long B0 = 0, B1 = 0;
   unsigned sf_lo = 0u;
-  float dyf = 0.f;
+  float dys = 0.f, uys = 0.f;
   if (FX) {
     B0 = __double2ll_rd(xrow * 4294967296.0) - ((long long)kf0 << 32);
     B1 = __double2ll_rd((xrow + xline) * 4294967296.0) - ((long long)kf1 << 32);
     sf_lo = (unsigned)__double2ll_rd(ax1.sf * 4294967296.0);   // sf < 1 on this route
-    dyf = (float)dy;
+    dys = (float)(dy * 0x1p-32); uys = (float)((1.0 - dy) * 0x1p-32);
   }
   if (FX) {
     // four columns per trip (this wavefront's columns are NT/64 apart): their table and sample reads are issued together,
@@ -262,11 +259,12 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     for (int cb = c0 + wave; cb < cend; cb += 4 * CSTEP) {
       float vv[4];
       long long cx[4];
-      float dxw[4];
+      float dxw[4], uxw[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int ct = min(cb + u * CSTEP, cend - 1) - c0;
-        dxw[u] = reinterpret_cast<const float *>(cdx)[ct];
+        const float2 w2 = reinterpret_cast<const float2 *>(cdx)[ct];   // {dx, 1 - dx}, each rounded from f64
+        dxw[u] = w2.x; uxw[u] = w2.y;
         cx[u] = reinterpret_cast<const long long *>(cxs)[ct];
       }
       float R[4][4];
@@ -281,18 +279,22 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
           const unsigned lo2 = lo + sf_lo;        // the next raster pixel: same window, or one sample on (sf <= 0.5)
           const bool cy = lo2 < lo;
           const float a2 = cy ? s1 : s0, b2 = cy ? s2 : s1;
-          const float t0 = __fmul_rn((float)lo, 0x1p-32f), t1 = __fmul_rn((float)lo2, 0x1p-32f);
-          // (1-t) a + t b as two FMAs, a - t a first: the samples are magnitudes (>= 0), so both terms are non-negative and
-          // each rounding is relative to the RESULT -- fma(t, b - a, a) rounds b - a, an error of 2^-24 |b - a| that is
-          // several ulp of a result much smaller than the step between its two samples
-          R[u][2 * ln] = lerp2(s0, s1, t0);
-          R[u][2 * ln + 1] = lerp2(a2, b2, t1);
+          // 2^32 ((1-t) a + t b) = U a + T b with T = lo and U = ~lo EACH converted from its own integer (complements to
+          // 2^32 - 1): the samples are magnitudes (>= 0), so both terms are non-negative and carry a relative error of 2^-24
+          // whatever t is.  fma(t, b - a, a) rounds b - a, and a - t a with the ROUNDED t is off by up to 2^-25 a: either is
+          // many ulp of a pixel much smaller than one of its samples (white noise: 1.4e-6).  The factor 2^-32 rides in the
+          // row weights of the last blend, so the precise weights cost one instruction per tap.
+          const float T0 = (float)lo, U0 = (float)~lo, T1 = (float)lo2, U1 = (float)~lo2;
+          R[u][2 * ln] = __fmaf_rn(T0, s1, __fmul_rn(U0, s0));
+          R[u][2 * ln + 1] = __fmaf_rn(T1, b2, __fmul_rn(U1, a2));
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = cb + u * CSTEP;
-        const float v = lerp2(lerp2(R[u][0], R[u][1], dxw[u]), lerp2(R[u][2], R[u][3], dxw[u]), dyf);
+        const float top = __fmaf_rn(dxw[u], R[u][1], __fmul_rn(uxw[u], R[u][0]));
+        const float bot = __fmaf_rn(dxw[u], R[u][3], __fmul_rn(uxw[u], R[u][2]));
+        const float v = __fmaf_rn(dys, bot, __fmul_rn(uys, top));   // (dys, uys carry the taps' 2^-32)
         const bool colok = c < cend;
         if (live && colok) o[(size_t)c * q.h_out] = v;
         vv[u] = (live && colok) ? v : 0.0f;
