@@ -855,6 +855,14 @@ struct Mix3Geom {
   static constexpr int PLANE = RB * RC * T + T;
   static constexpr int VMAX = RA > RB ? (RA > RC ? RA : RC) : (RB > RC ? RB : RC);
   static constexpr size_t LDS = ((size_t)RA * PLANE + R) * sizeof(float2);
+  // Exchange-tile position of (second digit, third digit n3, column t) within a k1 plane: (n2 RC + n3) T + (t ^ swz(n3)).
+  // The passes that read their rows contiguously (FFT_LAST, the fused middle's forward half, getWelch's accumulator) write
+  // step 1 with the lanes of a wavefront running along n3: unswizzled that is a stride of T float2 -- 16 (8) lanes of a
+  // 16-lane group on the same bank pair, 7.7 (3.8) LDS passes per ds_write_b64 for T = 8 (4), SQ_LDS_BANK_CONFLICT = 3400
+  // cycles per workgroup.  The column is XORed with n3 / 2: 2.0 (1.9) passes there, and the other three access patterns
+  // (step-1 writes with the column fastest, steps 2 and 3: lanes along t, then n3 or k1) stay conflict-free -- n3 is
+  // constant per thread in step 2 and a compile-time constant in step 3, so the swizzle costs a handful of XORs per pass.
+  static __device__ __forceinline__ int swz(int n3) { return (n3 >> 1) & (T - 1); }
 };
 
 template <int RA, int RB, int RC, int LOGT, int MODE>
@@ -898,13 +906,13 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
         for (int k1 = 0; k1 < RA; ++k1) {
           float2 x = v[k1];
           if (k1) x = cmul(x, twR[(n2 * k1) * RC]);
-          buf[k1 * PLANE + r23 * T + t1] = x;
+          buf[k1 * PLANE + r23 * T + (t1 ^ G::swz(r23 - n2 * RC))] = x;
         }
       }
       __syncthreads();
       if (tid < G::S2) {
         const int t = tid & (T - 1), q = tid >> LOGT, k1 = q / RC, n3 = q - k1 * RC;
-        float2 *p = buf + k1 * PLANE + n3 * T + t;
+        float2 *p = buf + k1 * PLANE + n3 * T + (t ^ G::swz(n3));
 #pragma unroll
         for (int n2 = 0; n2 < RB; ++n2) v[n2] = p[n2 * RC * T];
         dft_nat<RB>(v);
@@ -918,9 +926,9 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
       __syncthreads();
       if (tid < G::S3 && (tile << LOGT) + (unsigned)t3 < d.rows) {
         const int k2 = kk / RA, k1 = kk - k2 * RA;
-        const float2 *p = buf + k1 * PLANE + k2 * RC * T + t3;
+        const float2 *p = buf + k1 * PLANE + k2 * RC * T;
 #pragma unroll
-        for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T];
+        for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T + (t3 ^ G::swz(n3))];
         dft_nat<RC>(v);
 #pragma unroll
         for (int k3 = 0; k3 < RC; ++k3) acc[k3] += v[k3].x * v[k3].x + v[k3].y * v[k3].y;
@@ -977,14 +985,14 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
     for (int k1 = 0; k1 < RA; ++k1) {
       float2 x = v[k1];
       if (k1) x = cmul(x, twR[(n2 * k1) * RC]);  // W_{RA RB}^(n2 k1)
-      buf[k1 * PLANE + r23 * T + t1] = x;
+      buf[k1 * PLANE + r23 * T + (t1 ^ G::swz(r23 - n2 * RC))] = x;
     }
   }
   __syncthreads();
   // ---- step 2: slot (k1, n3, t), in place
   if (tid < G::S2) {
     const int t = tid & (T - 1), q = tid >> LOGT, k1 = q / RC, n3 = q - k1 * RC;
-    float2 *p = buf + k1 * PLANE + n3 * T + t;
+    float2 *p = buf + k1 * PLANE + n3 * T + (t ^ G::swz(n3));
 #pragma unroll
     for (int n2 = 0; n2 < RB; ++n2) v[n2] = p[n2 * RC * T];
     dft_nat<RB>(v);
@@ -1002,9 +1010,9 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
   const bool ok3 = tid < G::S3;
   if (ok3) {
     const int k2 = kk / RA, k1 = kk - k2 * RA;
-    const float2 *p = buf + k1 * PLANE + k2 * RC * T + t3;
+    const float2 *p = buf + k1 * PLANE + k2 * RC * T;
 #pragma unroll
-    for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T];
+    for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T + (t3 ^ G::swz(n3))];
     dft_nat<RC>(v);
   }
   if (MODE == FFT_STRIDED) {
@@ -1113,13 +1121,13 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mid3(c
       for (int k1 = 0; k1 < RA; ++k1) {
         float2 x = v[k1];
         if (k1) x = cmul(x, twR[(n2 * k1) * RC]);
-        buf[k1 * PLANE + r23 * T + t1] = x;
+        buf[k1 * PLANE + r23 * T + (t1 ^ G::swz(r23 - n2 * RC))] = x;
       }
     }
     __syncthreads();
     if (tid < G::S2) {
       const int t = tid & (T - 1), q = tid >> LOGT, k1 = q / RC, n3 = q - k1 * RC;
-      float2 *p = buf + k1 * PLANE + n3 * T + t;
+      float2 *p = buf + k1 * PLANE + n3 * T + (t ^ G::swz(n3));
 #pragma unroll
       for (int n2 = 0; n2 < RB; ++n2) v[n2] = p[n2 * RC * T];
       dft_nat<RB>(v);
@@ -1133,9 +1141,9 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mid3(c
     __syncthreads();
     if (tid < G::S3) {
       const int t = tid & (T - 1), kk = tid >> LOGT, k2 = kk / RA, k1 = kk - k2 * RA;
-      const float2 *p = buf + k1 * PLANE + k2 * RC * T + t;
+      const float2 *p = buf + k1 * PLANE + k2 * RC * T;
 #pragma unroll
-      for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T];
+      for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T + (t ^ G::swz(n3))];
       dft_nat<RC>(v);
     }
   };

@@ -41,12 +41,13 @@ def test_search_full_size(ctx, synth, name):
     assert min(mg, mo) > 10 * 2e-4, (mg, mo)   # the decision margin is far above the 2e-4 dB the two may differ by
 
 
-def test_full_c3_buffer_bitexact(ctx, tsdr, synth):
-    """BASELINE config C3 at full size: one 0.5 s buffer at 200 MS/s (1e8 IQ samples, 800 MB, 30 frames of
-    2576x1125@60 down-sampled 1.15:1) through tsdr_frames in EXACT mode against the oracle: sync indices, a checksum
-    of every frame, first and last raster and the final IIR state bit for bit; the beta margin of the last frame is
-    printed."""
-    wl = synth.WORKLOADS["C3"]
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_full_buffer_bitexact(ctx, tsdr, synth, name):
+    """BASELINE configs C3 and C5 at full size -- C3: one 0.5 s buffer at 200 MS/s (1e8 IQ samples, 800 MB, 30 frames of
+    2576x1125@60 down-sampled 1.15:1); C5: 0.5 s of 4400x2250@60 (4K60) at 50 MS/s, 30 rasters of 9.9e6 pixels -- through
+    tsdr_frames in EXACT mode against the oracle: sync indices, a checksum of every frame, first and last raster and the
+    final IIR state bit for bit; the beta margin of the last frame is printed.  (C2: tests/test_frame_path_gpu.py.)"""
+    wl = synth.WORKLOADS[name]
     Fs, x_t, y_t, fv = wl["Fs"], wl["x_t"], wl["y_t"], wl["fv"]
     n = int(round(wl["acquisition"] * Fs))
     S = synth.samples_per_frame(Fs, fv)
@@ -70,4 +71,4 @@ def test_full_c3_buffer_bitexact(ctx, tsdr, synth):
     assert np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
     for w in ("x", "y"):
         assert np.array_equal(g_sync.beta(w).view(np.uint32), o_sync.beta(w).view(np.uint32)), w
-        print(f"C3 last frame beta_{w}: argmax column, margin = {beta_margin(o_sync.beta(w))}")
+        print(f"{name} last frame beta_{w}: argmax column, margin = {beta_margin(o_sync.beta(w))}")
