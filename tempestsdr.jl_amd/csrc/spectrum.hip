@@ -14,6 +14,7 @@ struct tsdr_resampler {
   double2 *H = nullptr;    // initLPF's H: ComplexF64 as in the reference (the Float64 window promotes it, Resampler.jl:93-97)
   double2 *Hs = nullptr;   // (H[k] + conj H[N-k]) / 2 for k <= N/2: the filter of the real part (half-size route), or null
   float2 *work = nullptr;  // containerFFT / inFFT / outFFT, device
+  double2 *tw = nullptr;   // half-size route: {cos, sin}(2 pi e / N) for e < 1024, then for e = 1024 h (h <= N / 2048 + 1)
 };
 
 namespace tsdr {
@@ -298,35 +299,41 @@ __global__ __launch_bounds__(256) void k_c64_to_c32(const double2 *__restrict__ 
 //   A = (S[k] + conj S[M-k]) / 2,  B = conj(W_N^k) (S[k] - conj S[M-k]) / 2,   M = N/2
 //   Zc[k] = gain (A + i B),  Zc[M-k] = gain (conj A + i conj B)
 // One thread per pair (k, M-k), k <= M/2.
-__device__ inline double2 resamp_X(const float2 *__restrict__ P, size_t Nh, size_t Nb, size_t j, double w8) {
-  const bool up = j > Nh;  // X[j] = conj X[Nb - j]
-  const size_t jj = up ? Nb - j : j;
+// {cos, sin}(2 pi e / N), e <= N / 2, as the product of the two table entries e = 1024 h + l (tsdr_resampler::tw): two loads
+// out of L2 and four multiply-adds instead of a 100-instruction f64 sincospi -- of which the kernel needs three per output
+// pair and which was all of its time (16 us of f64 VALU work for 52 MB of traffic)
+__device__ inline double2 resamp_tw(const double2 *__restrict__ tw, size_t e) {
+  const double2 b = tw[e & 1023u], a = tw[1024u + (e >> 10)];
+  return make_double2(fma(a.x, b.x, -(a.y * b.y)), fma(a.y, b.x, a.x * b.y));
+}
+
+__device__ inline double2 resamp_X(const float2 *__restrict__ P, size_t Nh, size_t Nb, size_t j, const double2 *__restrict__ tw, unsigned up) {
+  const bool upper = j > Nh;  // X[j] = conj X[Nb - j]
+  const size_t jj = upper ? Nb - j : j;
   const float2 a = P[jj == Nh ? 0 : jj], b = P[jj == 0 || jj == Nh ? 0 : Nh - jj];
   const double ex = 0.5 * ((double)a.x + (double)b.x), ey = 0.5 * ((double)a.y - (double)b.y);
   const double dx = 0.5 * ((double)a.x - (double)b.x), dy = 0.5 * ((double)a.y + (double)b.y);  // (P[j] - conj P[Nh-j]) / 2
   const double ox = dy, oy = -dx;                                                                  // times -i
-  double sn, cs;
-  sincospi(2.0 * (double)jj / (double)Nb, &sn, &cs);  // W_Nb^jj = cs - i sn
-  const double xr = ex + (cs * ox + sn * oy), xi = ey + (cs * oy - sn * ox);
-  (void)w8;
-  return make_double2(xr, up ? -xi : xi);
+  const double2 w = resamp_tw(tw, jj * up);  // W_Nb^jj = W_N^(up jj) = w.x - i w.y
+  const double xr = ex + (w.x * ox + w.y * oy), xi = ey + (w.x * oy - w.y * ox);
+  return make_double2(xr, upper ? -xi : xi);
 }
 
 __global__ __launch_bounds__(256) void k_resamp_mid(const float2 *__restrict__ P, const double2 *__restrict__ Hs, size_t Nb, size_t N,
-                                                    double gain, float2 *__restrict__ Zc) {
+                                                    double gain, const double2 *__restrict__ tw, unsigned up, float2 *__restrict__ Zc) {
   const size_t Nh = Nb / 2, M = N / 2;
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k <= M / 2; k += (size_t)gridDim.x * blockDim.x) {
     const size_t k2 = M - k;
-    const double2 x1 = resamp_X(P, Nh, Nb, k % Nb, 0.0), x2 = resamp_X(P, Nh, Nb, k2 % Nb, 0.0);
+    // (N < 2^30: tsdr_resampler_init)
+    const double2 x1 = resamp_X(P, Nh, Nb, (unsigned)k % (unsigned)Nb, tw, up), x2 = resamp_X(P, Nh, Nb, (unsigned)k2 % (unsigned)Nb, tw, up);
     const double2 h1 = Hs[k], h2 = Hs[k2];
     // the products are rounded to ComplexF32 like the reference's in-place inFFT[n] = inFFT[n] * H[n]
     const double s1x = (double)(float)(x1.x * h1.x - x1.y * h1.y), s1y = (double)(float)(x1.x * h1.y + x1.y * h1.x);
     const double s2x = (double)(float)(x2.x * h2.x - x2.y * h2.y), s2y = (double)(float)(x2.x * h2.y + x2.y * h2.x);
     const double ax = 0.5 * (s1x + s2x), ay = 0.5 * (s1y - s2y);
     const double dx = 0.5 * (s1x - s2x), dy = 0.5 * (s1y + s2y);
-    double sn, cs;
-    sincospi(2.0 * (double)k / (double)N, &sn, &cs);  // conj(W_N^k) = cs + i sn
-    const double bx = cs * dx - sn * dy, by = cs * dy + sn * dx;
+    const double2 w = resamp_tw(tw, k);  // conj(W_N^k) = w.x + i w.y
+    const double bx = w.x * dx - w.y * dy, by = w.x * dy + w.y * dx;
     // A + iB = (ax - by) + i (ay + bx);   conj A + i conj B = (ax + by) + i (-ay + bx)
     Zc[k] = make_float2((float)(gain * (ax - by)), (float)(gain * (ay + bx)));
     if (k2 < M && k2 != k) Zc[k2] = make_float2((float)(gain * (ax + by)), (float)(gain * (bx - ay)));
@@ -660,6 +667,16 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
   int rc = finish();
   (void)hipFree(scratch);
   if (rc) { tsdr_resampler_free(r); return rc; }
+  if (r->Hs) {  // twiddle tables of k_resamp_mid (resamp_tw): evaluated in long double, rounded once
+    const size_t nhi = N / 2048 + 2;
+    std::vector<double2> tw(1024 + nhi);
+    const long double w0 = 6.283185307179586476925286766559005768L / (long double)N;
+    for (size_t e = 0; e < 1024; ++e) tw[e] = make_double2((double)cosl(w0 * (long double)e), (double)sinl(w0 * (long double)e));
+    for (size_t h = 0; h < nhi; ++h) tw[1024 + h] = make_double2((double)cosl(w0 * (long double)(1024 * h)), (double)sinl(w0 * (long double)(1024 * h)));
+    if (hipMalloc((void **)&r->tw, tw.size() * sizeof(double2)) != hipSuccess) { tsdr_resampler_free(r); return set_err(ctx, TSDR_ENOMEM, "init_resampler: allocation failed"); }
+    e = hipMemcpy(r->tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tsdr_resampler_free(r); return hip_fail(ctx, e, "init_resampler upload"); }
+  }
   *out = r;
   return TSDR_OK;
 }
@@ -685,7 +702,7 @@ int tsdr_resampler_run_d(tsdr_resampler *r, const float *in, size_t n_in, float 
     int rc = fft_any(ctx, in, 1, P, Nh, 1, -1);
     if (rc) return rc;
     TSDR_LAUNCH(ctx, "resampler_mid", k_resamp_mid, dim3(stream_grid(ctx, M / 2 + 1)), dim3(256), 0, (const float2 *)P,
-                (const double2 *)r->Hs, r->bufferSize, N, (double)(2 * r->up), r->work);
+                (const double2 *)r->Hs, r->bufferSize, N, (double)(2 * r->up), (const double2 *)r->tw, (unsigned)r->up, r->work);
     return fft_any(ctx, reinterpret_cast<const float *>(r->work), 1, reinterpret_cast<float2 *>(out), M, 1, +1);
   }
   float2 *tmp = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
@@ -770,6 +787,7 @@ void tsdr_resampler_free(tsdr_resampler *r) {
   if (r->H) (void)hipFree(r->H);
   if (r->Hs) (void)hipFree(r->Hs);
   if (r->work) (void)hipFree(r->work);
+  if (r->tw) (void)hipFree(r->tw);
   delete r;
 }
 
