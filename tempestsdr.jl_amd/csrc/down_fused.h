@@ -222,7 +222,8 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
     }
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63;
+  // (wave-uniform on purpose: the column loop's counters, table addresses and bounds then live in scalar registers)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = r0 + lane;
   if (SUMS == DS_NONE && r >= q.h_out) return;  // (no barrier follows in the body)
   float racc = 0.0f;   // PSUM: this wavefront's sum of row r over its columns
