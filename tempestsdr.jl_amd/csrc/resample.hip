@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
     const RsAxis ay = q.ay, axx = q.axx;
     // wave 0 builds the row table (two rounds when NR > 64), wave 1 the column table; the valid entries of
     // each are contiguous, so one ballot per round yields first index and count
-    const int wv = tid >> 6, ln = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     if (wv == 0) {
       const int rbase = max(0, (int)floor(((double)l0 + 0.5) * q.inv_sfy - 0.5) - 2);
       const bool last = (tl == q.tiles_l - 1);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
   }
   __syncthreads();
   {
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (uniform: the pixel loop's bounds are scalar)
     const int l = l0 + lane;
     const int pw = q.TP >> 2;
     const int pbeg = p0 + wave * pw, pend = min(pbeg + pw, q.x_t);
