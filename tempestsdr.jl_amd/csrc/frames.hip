@@ -400,42 +400,42 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     if (rc) return rc;
     TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
   } else {
-  rc = lane_get(ctx, 0);
-  if (!rc) rc = lane_get(ctx, 2);
-  if (rc) return rc;
-  {
-    LaneScope image_lane(ctx, 0);
-    // inputs: whatever the context's stream holds now (uploads, a producer's kernels, an earlier call's launches) comes
-    // first.  An idle stream -- the steady state of a caller that only submits -- needs no fence.
-    if (hipStreamQuery(ctx->stream) != hipSuccess) {
-      (void)hipGetLastError();  // (hipErrorNotReady is a status here, not a failure for the next launch check to find)
-      TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
-      TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->lane_in, 0));
-    }
-    // this slot's previous user: submission k - NS, whose tail read its images / keys / sums
-    if (ctx->ev_tail_used[slot]) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->ev_tail[slot], 0));
-    rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj,
-                           &got, false, keys);
+    rc = lane_get(ctx, 0);
+    if (!rc) rc = lane_get(ctx, 2);
     if (rc) return rc;
-    TSDR_HIP(ctx, hipEventRecord(ctx->ev_img[slot], ctx->lane[0]));
-  }
-  {
-    LaneScope tail_lane(ctx, 2);
-    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[2], ctx->ev_img[slot], 0));
-    if (do_align) {
-      rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr);
-      if (rc) return rc;
-      if (gp.on) {
-        rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
-        if (rc) return rc;
+    {
+      LaneScope image_lane(ctx, 0);
+      // inputs: whatever the context's stream holds now (uploads, a producer's kernels, an earlier call's launches) comes
+      // first.  An idle stream -- the steady state of a caller that only submits -- needs no fence.
+      if (hipStreamQuery(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();  // (hipErrorNotReady is a status here, not a failure for the next launch check to find)
+        TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
+        TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->lane_in, 0));
       }
+      // this slot's previous user: submission k - NS, whose tail read its images / keys / sums
+      if (ctx->ev_tail_used[slot]) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->ev_tail[slot], 0));
+      rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj,
+                             &got, false, keys);
+      if (rc) return rc;
+      TSDR_HIP(ctx, hipEventRecord(ctx->ev_img[slot], ctx->lane[0]));
     }
-    // (shift + IIR on a third stream of its own: 348 k vs 357 k frames/s raster-free, 175 k vs 181 k with rasters -- dropped)
-    rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
-                     do_align ? sync_idx : nullptr);
-    if (rc) return rc;
-    TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
-  }
+    {
+      LaneScope tail_lane(ctx, 2);
+      TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[2], ctx->ev_img[slot], 0));
+      if (do_align) {
+        rc = sync_scan_d(sync, img, npx, F, keys, proj, got.ncp ? &got : nullptr, gp.on ? gp.top2 : nullptr);
+        if (rc) return rc;
+        if (gp.on) {
+          rc = guard_run(ctx, sync, gp, iq, S, y_t, x_t, F, img, keys, proj);
+          if (rc) return rc;
+        }
+      }
+      // (shift + IIR on a third stream of its own: 348 k vs 357 k frames/s raster-free, 175 k vs 181 k with rasters -- dropped)
+      rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
+                       do_align ? sync_idx : nullptr);
+      if (rc) return rc;
+      TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
+    }
   }
   ctx->ev_tail_used[slot] = true;
   ctx->pipe_last_slot = slot;
