@@ -388,9 +388,17 @@ __device__ inline void down_event(DownInfo &di, int j, float R00, float R01) {
 // a chunk.  The chunk's values stay in registers for the output columns whose left tap they are (the scan of
 // the wave-uniform column mask is a handful of scalar bit tests per chunk).  Chunking rather than unrolling the
 // whole segment keeps the kernel at 64 VGPRs, i.e. eight waves per SIMD.
-template <bool F32W, bool OUT, bool DOWNR, int PW>
+// REC4 (F32W only): the row holds plain samples; a pixel is ((D - r) a + r b) / D with both weights exact integers in f32 --
+// the convex form, so that each term carries a relative error whatever r is (see DM_FAST_FX in down_fused.h) -- four
+// instructions instead of two, for a quarter of the LDS: what lets C3's wide tiles (39 samples x 127 lines) share a CU.
+__device__ __forceinline__ float rec4_pixel(float ref, float Df, float invD, float2 s) {
+  return __fmul_rn(__fmaf_rn(ref, s.y, __fmul_rn(__fsub_rn(Df, ref), s.x)), invD);
+}
+__device__ __forceinline__ float2 rec4_read(const float *row, int kk) { return make_float2(row[kk], row[kk + 1]); }
+
+template <bool F32W, bool OUT, bool DOWNR, int PW, bool REC4 = false>
 __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, bool extra,
-                                      float *__restrict__ ob, int loff, size_t ostride, DownInfo &di) {
+                                      float *__restrict__ ob, int loff, size_t ostride, DownInfo &di, float invD = 0.f) {
   // ob is wave-uniform (first pixel of the segment, line 0 of the frame), loff the lane's line: the store then
   // takes a scalar base advanced by scalar adds and a fixed VGPR offset -- no per-pixel VALU address math
   constexpr int CH = PW >= 4 ? 4 : PW;
@@ -398,9 +406,11 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
   const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
   const float rstepf = (float)fa.rstep, Df = (float)fa.D;
   float rf = (float)r;
+  const float *row1 = reinterpret_cast<const float *>(rowv);
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   double2 s2 = make_double2(0.0, 0.0);
-  if (F32W) s4 = row4[kk]; else s2 = row2[kk];
+  float2 s1 = make_float2(0.f, 0.f);
+  if (REC4) s1 = rec4_read(row1, kk); else if (F32W) s4 = row4[kk]; else s2 = row2[kk];
   float last = 0.f;  // last pixel of the previous chunk
   unsigned long long mm = di.colmask << 1;  // column mask aligned to the chunks: bit j+1 = column j (wave-uniform)
   for (int cb = 0; cb < PW; cb += CH) {
@@ -420,11 +430,11 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
         kk += (int)fa.qstep + (c ? 1 : 0);
         r = c ? r2 - fa.D : r2;
       }
-      float4 n4 = s4; double2 n2 = s2;
-      if (F32W) n4 = row4[kk]; else n2 = row2[kk];  // next pixel's record; in range by the W bound
-      v[i] = F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
+      float4 n4 = s4; double2 n2 = s2; float2 n1 = s1;
+      if (REC4) n1 = rec4_read(row1, kk); else if (F32W) n4 = row4[kk]; else n2 = row2[kk];  // next pixel's record; in range by the W bound
+      v[i] = REC4 ? rec4_pixel(ref, Df, invD, s1) : F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
       if (OUT) { store_saddr(ob, (unsigned)loff * 4u, v[i]); ob += ostride; }
-      s4 = n4; s2 = n2;
+      s4 = n4; s2 = n2; s1 = n1;
     }
     if (DOWNR) {
       const unsigned bits = (unsigned)mm;  // bit j: column cb-1+j is completed by pixel cb+j
@@ -437,16 +447,16 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
     }
   }
   if (DOWNR && extra && ((di.colmask >> (PW - 1)) & 1ull)) {
-    const float ve = F32W ? fmaf(rf, s4.z, fmaf(rf, s4.y, s4.x)) : (float)fma((double)r, s2.y, s2.x);
+    const float ve = REC4 ? rec4_pixel(rf, Df, invD, s1) : F32W ? fmaf(rf, s4.z, fmaf(rf, s4.y, s4.x)) : (float)fma((double)r, s2.y, s2.x);
     down_event<F32W>(di, PW - 1, last, ve);
   }
 }
 
 // Edge cases (segment cut by the frame end, first pixels of a frame where x0 < 0): the same walk as a plain loop.
 // n_own pixels are stored; one more is evaluated (not stored) when `extra`.
-template <bool F32W, bool CLAMP, bool OUT, bool DOWNR>
+template <bool F32W, bool CLAMP, bool OUT, bool DOWNR, bool REC4 = false>
 __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ rowv, int kk, unsigned r, int n_own, bool extra,
-                                  float *__restrict__ o, size_t ostride, DownInfo &di) {
+                                  float *__restrict__ o, size_t ostride, DownInfo &di, float invD = 0.f) {
   const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
   const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
   const int n = n_own + (extra ? 1 : 0);
@@ -458,7 +468,8 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
     const float ref = CLAMP ? (kk < 0 ? 0.f : rf) : rf;
     const unsigned reu = CLAMP ? (kk < 0 ? 0u : r) : r;
     float v;
-    if (F32W) { const float4 s4 = row4[ks]; v = fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)); }
+    if (REC4) v = rec4_pixel(ref, Df, invD, rec4_read(reinterpret_cast<const float *>(rowv), ks));
+    else if (F32W) { const float4 s4 = row4[ks]; v = fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)); }
     else { const double2 s2 = row2[ks]; v = (float)fma((double)reu, s2.y, s2.x); }
     if (OUT) { if (i < n_own && (!CLAMP || o)) { *o = v; o += ostride; } }
     if (DOWNR) { if (i > 0 && ((di.colmask >> (i - 1)) & 1ull)) down_event<F32W>(di, i - 1, prev, v); }
@@ -484,7 +495,8 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
 // so its first and last 128-byte lines are shared with the segments above and below; when those belong to other
 // workgroups the halves reach L2 ~20 us apart, longer than a line survives there under this write stream, and are
 // written back as partial lines twice.  Stacking VW waves makes VW-1 of every VW seams internal to a workgroup.
-template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT, int VW>
+// REC4: the staged lines are plain f32 samples (fast_walk_full) instead of {a, slope hi, slope lo} records
+template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT, int VW, bool REC4 = false>
 __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__restrict__ in, size_t in_stride, TileParams q,
                                                      FastAx fa, FastInc fi, float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
@@ -492,9 +504,10 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
   const int Wp = q.W | 1;
   float4 *smp4 = reinterpret_cast<float4 *>(lds_d);      // F32W : [NL][Wp] {a, slope hi, slope lo, -}
   double2 *smp2 = reinterpret_cast<double2 *>(lds_d);    // !F32W: [NL][Wp] {a, slope} in f64
+  float *smp1 = reinterpret_cast<float *>(lds_d);        // REC4 : [NL][Wp] a
   constexpr int LSTEP = DOWN ? 63 : 64;              // line pitch of vertically stacked waves
   constexpr int NL = LSTEP * (VW - 1) + 64;            // lines of the tile
-  char *after = reinterpret_cast<char *>(lds_d) + (size_t)NL * Wp * 16;
+  char *after = reinterpret_cast<char *>(lds_d) + (REC4 ? (((size_t)NL * Wp * 4 + 15) & ~(size_t)15) : (size_t)NL * Wp * 16);
   double *rdyd = reinterpret_cast<double *>(after);      // DOWN: per-line row weight, per-pixel column weight
   double *cdxd = rdyd + (DOWN ? NL : 0);
   int *rrow = reinterpret_cast<int *>(cdxd + (DOWN ? q.TP + 1 : 0));
@@ -543,7 +556,7 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         re[t] = 0.f; im[t] = 0.f;
-        if (t <= cs) {
+        if (REC4 ? t < cs : t <= cs) {
           const unsigned ks = min(kf + (unsigned)min(jb + t, q.W - 1), q.S - 1u);
           if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[ks]; re[t] = z.x; im[t] = z.y; }
           else re[t] = src[ks];
@@ -553,11 +566,13 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
     auto consume = [&](int r, const float (&re)[5], const float (&im)[5]) {
       float a[5];
 #pragma unroll
-      for (int t = 0; t < 5; ++t) a[t] = (CPLX && t <= cs) ? abs_iq<false>(re[t], im[t]) : re[t];
+      for (int t = 0; t < 5; ++t) a[t] = (CPLX && (REC4 ? t < cs : t <= cs)) ? abs_iq<false>(re[t], im[t]) : re[t];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int j = jb + t;
-        if (t < cs && j < q.W) {
+        if (REC4) {
+          if (t < cs && j < q.W) smp1[r * Wp + j] = a[t];
+        } else if (t < cs && j < q.W) {
           const double sl = ((double)a[t + 1] - (double)a[t]) * fa.invDd;
           if (F32W) {
             const float hi = (float)sl;
@@ -634,14 +649,15 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
       di.proj = q.proj != nullptr;
       di.lane = lane;
     }
-    const void *row = F32W ? (const void *)(smp4 + (lbase + lane) * Wp) : (const void *)(smp2 + (lbase + lane) * Wp);
+    const void *row = REC4 ? (const void *)(smp1 + (lbase + lane) * Wp)
+                           : F32W ? (const void *)(smp4 + (lbase + lane) * Wp) : (const void *)(smp2 + (lbase + lane) * Wp);
     const int kk = k - kf;
     const bool full = n_own == PW && (!DOWN || extra || wave == 3);
-    if (num0 < 0) fast_walk2<F32W, true, OUT, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
-    else if (!full) fast_walk2<F32W, false, OUT, DOWN>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di);
+    if (num0 < 0) fast_walk2<F32W, true, OUT, DOWN, REC4>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di, fi.invD);
+    else if (!full) fast_walk2<F32W, false, OUT, DOWN, REC4>(fa, row, kk, r, n_own, extra, o, (size_t)q.y_t, di, fi.invD);
     else {
       float *ob = OUT ? out + (size_t)f * out_stride + (size_t)pbeg * q.y_t : nullptr;
-      fast_walk_full<F32W, OUT, DOWN, PW>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di);
+      fast_walk_full<F32W, OUT, DOWN, PW, REC4>(fa, row, kk, r, extra, ob, l, (size_t)q.y_t, di, fi.invD);
     }
     }
   }
@@ -823,10 +839,21 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   int tp_max = (want_down && exact) ? 64 : 128;
   // staged-sample budget per tile: EXACT 4 B/sample (<= 48 KiB), FAST 16 B/sample (<= 47 samples per line = 47 KiB;
   // only down-sampling ratios get near it, up-sampling tiles stage ~11-18 samples per line)
-  const long w_cap = exact ? 191 : 47;
-  for (int TP = tp_max; TP >= 4; TP >>= 1) {
-    const long W = (long)((double)(TP - 1) * sf) + 4;
-    if (W <= w_cap) { tiled = true; q.TP = TP; q.W = (int)W; break; }
+  // (FAST with plain f32 samples -- REC4, k_raster_fast: the f32 walk with the in-walk downgrade -- 4 B/sample: <= 94 samples
+  // per line, i.e. C3's 1.15 samples per raster pixel get 64-pixel tiles, and with them the in-walk projection sums)
+  const bool rec4_ok = !exact && want_down && ctx->opt_raster_rec4 != 0 && 2 * P < (size_t(1) << 24) && y_t > h_out && x_t > w_out;
+  auto pick_tp = [&](long w_cap) {
+    tiled = false;
+    for (int TP = tp_max; TP >= 4; TP >>= 1) {
+      const long W = (long)((double)(TP - 1) * sf) + 4;
+      if (W <= w_cap) { tiled = true; q.TP = TP; q.W = (int)W; break; }
+    }
+  };
+  pick_tp(exact ? 191 : rec4_ok ? 94 : 47);
+  if (rec4_ok && tiled && q.W > 47) {
+    // the wider budget only holds for the plan REC4 serves: in-walk downgrade (TP >= 32) and the 32-bit advances (<= 128 tiles per axis)
+    const int vw = y_t >= 2 * 64 ? 2 : 1;
+    if (q.TP < 32 || (y_t - 2) / (63 * vw) + 1 > 128 || (x_t - 2) / (q.TP - 1) + 1 > 128) pick_tp(47);
   }
   if (tiled && !exact) {  // FAST: k_raster_fast
     // the in-walk downgrade needs ratios strictly above 1 (a line / pixel is then the top-left tap of at most one
@@ -842,6 +869,15 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
     q.inv_tiles_p = 1.0f / (float)q.tiles_p;
     if (!dn && !out) return TSDR_OK;  // nothing to do here; caller falls back to k_down_fused
+    // f32 walk and 32-bit position advance: D = 2P < 2^24 and few enough tiles that the advances stay below 2^32
+    const bool w32 = 2 * P < (size_t(1) << 24) && q.tiles_l <= 128 && q.tiles_p <= 128;
+    // Staged samples as plain f32 (REC4, k_raster_fast) instead of 16-byte records wherever the f32 walk with the in-walk
+    // downgrade runs: C3's tiles (39 samples x 127 lines) were 79 KB of records, ONE 512-thread workgroup per CU with nothing
+    // to cover its staging (357 -> 244 us per buffer with 20 KB of samples); C2's 42 KB -> 14 KB is worth 4-6 % of its
+    // store-bound launch.  One more sample per line: a pixel reads (k, k + 1).
+    const bool rec4 = rec4_ok && w32 && dn;
+    if (!rec4 && q.W > 47) return set_err(ctx, TSDR_EINVAL, "raster: tile plan needs the f32-sample walk");  // (pick_tp above rules it out)
+    if (rec4) q.W += 1;
     // staging lanes per line: the power of two that wastes the fewest lane slots with <= 4 samples per lane
     int best = -1; long best_slots = 1L << 60;
     for (int lg = 2; lg <= 6; ++lg) {
@@ -852,7 +888,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     }
     q.lpl_log = best;
     q.cs = (int)ceil_div((size_t)q.W, (size_t)1 << best);
-    size_t lds = (size_t)NL * (size_t)(q.W | 1) * 16 + 16;
+    size_t lds = rec4 ? (((size_t)NL * (size_t)(q.W | 1) * 4 + 15) & ~(size_t)15) + 16 : (size_t)NL * (size_t)(q.W | 1) * 16 + 16;
     // the images' projection partial sums come out of the same walk when the caller has room for them
     // (with narrower tiles -- down-sampling ratios such as C3's -- the per-workgroup part of the sums is spread over
     // four times as many workgroups and costs more than the separate pass over the images: 0.382 vs 0.354 ms)
@@ -872,8 +908,6 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     if (plan_only) { if (did_down) *did_down = dn; return TSDR_OK; }
     const FastAx fa = fast_axis(S, P);
     const FastInc fi = fast_inc(S, P, x_t, q.own_l, q.own_p);
-    // f32 walk and 32-bit position advance: D = 2P < 2^24 and few enough tiles that the advances stay below 2^32
-    const bool w32 = 2 * P < (size_t(1) << 24) && q.tiles_l <= 128 && q.tiles_p <= 128;
     const size_t units = (size_t)q.frames * q.tiles_p;
     const size_t G = (size_t)q.xcd_group;
     const size_t upx = ceil_div(units, 8 * G) * G;  // units per XCD slot
@@ -890,9 +924,20 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
                   dim3(256 * VWK), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);                   \
     }                                                                                                                 \
   } while (0)
+#define FASTK2R(PW, VWK)                                                                                              \
+  do {                                                                                                                \
+    if (out) {                                                                                                        \
+      TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast<true, true, true, PW, true, VWK, true>), grid, dim3(256 * VWK), lds, in,  \
+                  in_stride, q, fa, fi, out, out_stride, down, down_stride);                                          \
+    } else {                                                                                                          \
+      TSDR_LAUNCH(ctx, "down_walk_iq", (k_raster_fast<true, true, true, PW, false, VWK, true>), grid, dim3(256 * VWK), lds, in,   \
+                  in_stride, q, fa, fi, out, out_stride, down, down_stride);                                          \
+    }                                                                                                                 \
+  } while (0)
 #define FASTK1(C, W32, D, PW, NAME)                                                                                   \
   do {                                                                                                                \
-    if (VW == 2) FASTK2(C, W32, D, PW, 2, NAME);                                                                 \
+    if (rec4 && (PW == 8 || PW == 16 || PW == 32)) { if (VW == 2) FASTK2R(PW, 2); else FASTK2R(PW, 1); }            \
+    else if (VW == 2) FASTK2(C, W32, D, PW, 2, NAME);                                                                 \
     else FASTK2(C, W32, D, PW, 1, NAME);                                                                              \
   } while (0)
 #define FASTK(C, W32, D, NAME)                                                                                        \
@@ -914,6 +959,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     }
 #undef FASTK1
 #undef FASTK2
+#undef FASTK2R
 #undef FASTK
     return TSDR_OK;
   }
