@@ -860,7 +860,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     // output row / column); otherwise the raster is produced here and the caller downgrades separately
     const bool dn = want_down && q.TP >= 32 && y_t > h_out && x_t > w_out;
     // wavefronts stacked vertically per workgroup (see k_raster_fast).  Measured on C2: 1 -> 0.121 ms, 2 -> 0.118 ms,
-    // 4 (1024 threads, 77 KiB LDS) -> 0.131 ms
+    // 4 (1024 threads, 77 KiB LDS) -> 0.131 ms; again with f32 samples (REC4, 12 KiB): 130 / 124 / 138 us for the launch
     int VW = y_t >= 2 * 64 ? 2 : 1;
     const int lstep = dn ? 63 : 64, NL = lstep * (VW - 1) + 64;
     q.own_l = lstep * VW;
