@@ -394,6 +394,11 @@ __device__ inline void down_event(DownInfo &di, int j, float R00, float R01) {
 __device__ __forceinline__ float rec4_pixel(float ref, float Df, float invD, float2 s) {
   return __fmul_rn(__fmaf_rn(ref, s.y, __fmul_rn(__fsub_rn(Df, ref), s.x)), invD);
 }
+// (the integer walk, D >= 2^24: the weights are conversions of the two integers -- relative error 2^-24 each, which is all the
+// convex form needs)
+__device__ __forceinline__ float rec4_pixel_u(unsigned r, unsigned D, float invD, float2 s) {
+  return __fmul_rn(__fmaf_rn((float)r, s.y, __fmul_rn((float)(D - r), s.x)), invD);
+}
 __device__ __forceinline__ float2 rec4_read(const float *row, int kk) { return make_float2(row[kk], row[kk + 1]); }
 
 template <bool F32W, bool OUT, bool DOWNR, int PW, bool REC4 = false>
@@ -432,7 +437,8 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
       }
       float4 n4 = s4; double2 n2 = s2; float2 n1 = s1;
       if (REC4) n1 = rec4_read(row1, kk); else if (F32W) n4 = row4[kk]; else n2 = row2[kk];  // next pixel's record; in range by the W bound
-      v[i] = REC4 ? rec4_pixel(ref, Df, invD, s1) : F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
+      v[i] = REC4 ? (F32W ? rec4_pixel(ref, Df, invD, s1) : rec4_pixel_u(reu, fa.D, invD, s1))
+                  : F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
       if (OUT) { store_saddr(ob, (unsigned)loff * 4u, v[i]); ob += ostride; }
       s4 = n4; s2 = n2; s1 = n1;
     }
@@ -447,7 +453,8 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
     }
   }
   if (DOWNR && extra && ((di.colmask >> (PW - 1)) & 1ull)) {
-    const float ve = REC4 ? rec4_pixel(rf, Df, invD, s1) : F32W ? fmaf(rf, s4.z, fmaf(rf, s4.y, s4.x)) : (float)fma((double)r, s2.y, s2.x);
+    const float ve = REC4 ? (F32W ? rec4_pixel(rf, Df, invD, s1) : rec4_pixel_u(r, fa.D, invD, s1))
+                          : F32W ? fmaf(rf, s4.z, fmaf(rf, s4.y, s4.x)) : (float)fma((double)r, s2.y, s2.x);
     down_event<F32W>(di, PW - 1, last, ve);
   }
 }
@@ -468,7 +475,10 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
     const float ref = CLAMP ? (kk < 0 ? 0.f : rf) : rf;
     const unsigned reu = CLAMP ? (kk < 0 ? 0u : r) : r;
     float v;
-    if (REC4) v = rec4_pixel(ref, Df, invD, rec4_read(reinterpret_cast<const float *>(rowv), ks));
+    if (REC4) {
+      const float2 s1 = rec4_read(reinterpret_cast<const float *>(rowv), ks);
+      v = F32W ? rec4_pixel(ref, Df, invD, s1) : rec4_pixel_u(reu, fa.D, invD, s1);
+    }
     else if (F32W) { const float4 s4 = row4[ks]; v = fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)); }
     else { const double2 s2 = row2[ks]; v = (float)fma((double)reu, s2.y, s2.x); }
     if (OUT) { if (i < n_own && (!CLAMP || o)) { *o = v; o += ostride; } }
@@ -841,7 +851,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   // only down-sampling ratios get near it, up-sampling tiles stage ~11-18 samples per line)
   // (FAST with plain f32 samples -- REC4, k_raster_fast: the f32 walk with the in-walk downgrade -- 4 B/sample: <= 94 samples
   // per line, i.e. C3's 1.15 samples per raster pixel get 64-pixel tiles, and with them the in-walk projection sums)
-  const bool rec4_ok = !exact && want_down && ctx->opt_raster_rec4 != 0 && 2 * P < (size_t(1) << 24) && y_t > h_out && x_t > w_out;
+  const bool rec4_ok = !exact && want_down && ctx->opt_raster_rec4 != 0 && 2 * P < (size_t(1) << 32) && y_t > h_out && x_t > w_out;
   auto pick_tp = [&](long w_cap) {
     tiled = false;
     for (int TP = tp_max; TP >= 4; TP >>= 1) {
@@ -851,9 +861,8 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   };
   pick_tp(exact ? 191 : rec4_ok ? 94 : 47);
   if (rec4_ok && tiled && q.W > 47) {
-    // the wider budget only holds for the plan REC4 serves: in-walk downgrade (TP >= 32) and the 32-bit advances (<= 128 tiles per axis)
-    const int vw = y_t >= 2 * 64 ? 2 : 1;
-    if (q.TP < 32 || (y_t - 2) / (63 * vw) + 1 > 128 || (x_t - 2) / (q.TP - 1) + 1 > 128) pick_tp(47);
+    // the wider budget only holds for the plan REC4 serves: the in-walk downgrade (TP >= 32)
+    if (q.TP < 32) pick_tp(47);
   }
   if (tiled && !exact) {  // FAST: k_raster_fast
     // the in-walk downgrade needs ratios strictly above 1 (a line / pixel is then the top-left tap of at most one
@@ -875,7 +884,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     // downgrade runs: C3's tiles (39 samples x 127 lines) were 79 KB of records, ONE 512-thread workgroup per CU with nothing
     // to cover its staging (357 -> 244 us per buffer with 20 KB of samples); C2's 42 KB -> 14 KB is worth 4-6 % of its
     // store-bound launch.  One more sample per line: a pixel reads (k, k + 1).
-    const bool rec4 = rec4_ok && w32 && dn;
+    const bool rec4 = rec4_ok && dn;
     if (!rec4 && q.W > 47) return set_err(ctx, TSDR_EINVAL, "raster: tile plan needs the f32-sample walk");  // (pick_tp above rules it out)
     if (rec4) q.W += 1;
     // staging lanes per line: the power of two that wastes the fewest lane slots with <= 4 samples per lane
@@ -924,19 +933,19 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
                   dim3(256 * VWK), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);                   \
     }                                                                                                                 \
   } while (0)
-#define FASTK2R(PW, VWK)                                                                                              \
+#define FASTK2R(W32, PW, VWK)                                                                                         \
   do {                                                                                                                \
     if (out) {                                                                                                        \
-      TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast<true, true, true, PW, true, VWK, true>), grid, dim3(256 * VWK), lds, in,  \
+      TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast<true, W32, true, PW, true, VWK, true>), grid, dim3(256 * VWK), lds, in,   \
                   in_stride, q, fa, fi, out, out_stride, down, down_stride);                                          \
     } else {                                                                                                          \
-      TSDR_LAUNCH(ctx, "down_walk_iq", (k_raster_fast<true, true, true, PW, false, VWK, true>), grid, dim3(256 * VWK), lds, in,   \
+      TSDR_LAUNCH(ctx, "down_walk_iq", (k_raster_fast<true, W32, true, PW, false, VWK, true>), grid, dim3(256 * VWK), lds, in,    \
                   in_stride, q, fa, fi, out, out_stride, down, down_stride);                                          \
     }                                                                                                                 \
   } while (0)
 #define FASTK1(C, W32, D, PW, NAME)                                                                                   \
   do {                                                                                                                \
-    if (rec4 && (PW == 8 || PW == 16 || PW == 32)) { if (VW == 2) FASTK2R(PW, 2); else FASTK2R(PW, 1); }            \
+    if (rec4 && D && (PW == 8 || PW == 16 || PW == 32)) { if (VW == 2) FASTK2R(W32, PW, 2); else FASTK2R(W32, PW, 1); } \
     else if (VW == 2) FASTK2(C, W32, D, PW, 2, NAME);                                                                 \
     else FASTK2(C, W32, D, PW, 1, NAME);                                                                              \
   } while (0)
