@@ -65,9 +65,11 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
 /* Arithmetic of the steady-state frame loop (tsdr_frames*, i.e. IQ -> raster -> 600x800 image):
  *   TSDR_EXACT: the reference's evaluation order -- f64 source coordinate sf*i+off and f64 weights,
  *               one rounding to f32 per value; bit-identical to the CPU oracle.
- *   TSDR_FAST : exact-rational source coordinate carried in integers + one f64 FMA per blend (within
- *               1 ulp of TSDR_EXACT) and hardware sqrt for |IQ| (1.5 ulp) in the raster walk, 32.32 fixed-point coordinates + f32 blends in the raster-free kernel: pixels within a few ulp
- *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing and white noise reach 4.7e-7) of TSDR_EXACT; ~2.5x fewer
+ *   TSDR_FAST : hardware sqrt for |IQ| (1.5 ulp); in the raster walk the exact-rational source coordinate carried in
+ *               integers and the pixel in the convex form ((D - r) a + r b) / D in f32, both weights exact (the image's 2-D
+ *               blend one f64 FMA per step); in the raster-free kernel 32.32 fixed-point coordinates and f32 blends with
+ *               each weight converted from its own integer: pixels within a few ulp of TSDR_EXACT
+ *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing and white noise reach 4.9e-7); ~2.5x fewer
  *               VALU cycles.  Default.  The images' projection
  *               sums are then formed inside the raster kernel (per-tile partial sums, added in tile order)
  *               instead of by a second pass over the images in the reference's row order, so beta differs from
@@ -102,6 +104,8 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 of the tap-based kernel with its own partial sums.  Default 0.  Results within the FAST tolerance either way.
  *   "sync_guard_auto" 1 (default): the adaptive whole-buffer TSDR_EXACT route described above; 0: flagged frames are always
  *                 re-evaluated one by one.
+ *   "raster_rec4" 1 (default): the TSDR_FAST raster walk stages |IQ| as plain f32 samples (a quarter of the LDS of the
+ *                 {a, slope hi, slope lo} records of rounds 1-3, which 0 brings back: the A/B).
  *   "raster_split" 0 (default): the TSDR_FAST frame loop with rasters is ONE launch that walks every raster pixel and forms raster,
  *                 600x800 image and projection sums; 1: rasters by the store-aligned ("sheared") raster-only kernel + images by the
  *                 raster-free kernel (two launches, IQ read twice: measured slower, kept as the A/B;
