@@ -406,7 +406,9 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
                                       float *__restrict__ ob, int loff, size_t ostride, DownInfo &di, float invD = 0.f) {
   // ob is wave-uniform (first pixel of the segment, line 0 of the frame), loff the lane's line: the store then
   // takes a scalar base advanced by scalar adds and a fixed VGPR offset -- no per-pixel VALU address math
-  constexpr int CH = PW >= 4 ? 4 : PW;
+  // (eight per chunk where the f32 walk has 32-pixel segments -- C2: 118.6-121.5 -> 111.7-113.0 us for the launch on one box;
+  // C3 (16-pixel segments) and C5 (integer walk) measured 2 % better with four, 16 was no better than 8)
+  constexpr int CH = (F32W && PW >= 32) ? 8 : PW >= 4 ? 4 : PW;
   const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
   const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
   const float rstepf = (float)fa.rstep, Df = (float)fa.D;
