@@ -840,8 +840,8 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   q.S = (unsigned)S; q.y_t = y_t; q.x_t = x_t; q.frames = frames;
   // pairs of strips.  Measured on C2 -- round 2 (16-byte sample records, 3 workgroups per CU): G=1 0.138 ms, G=4 0.132 ms, G=41 0.146 ms;
   // round 4 (f32 samples, 4 per CU), the launch alone on two boxes: G=1 115.3, G=2 110.9 / 114.9, G=4 113.7 / 117.4, G=8 118.4, G=16 120.5 us
-  // (C3: no difference; C5: G=2 1 % behind G=4)
-  q.xcd_group_log = 1;
+  // (C3: no difference; C5: G=2 1 % behind G=4).  The EXACT tile kernel (two workgroups per CU fewer) keeps four: 146.5 against 148.3 us
+  q.xcd_group_log = exact ? 2 : 1;
   q.xcd_group = 1 << q.xcd_group_log;
   q.ax = rs_axis(S, (size_t)y_t * x_t);
   if (h_out > 0 && w_out > 0) {
