@@ -404,6 +404,26 @@ def test_frames_fast_sheared_raster_route(ctx, tsdr, synth, case, split):
     assert r["n_frames"] == case["nfr"] and not r["ties"]
 
 
+@pytest.mark.parametrize("case", [
+    dict(Fs=20e6, x_t=2576, y_t=1125, fv=60.0, nfr=3),     # C2: f32 walk, 128-pixel tiles
+    dict(Fs=200e6, x_t=2576, y_t=1125, fv=60.0, nfr=2),    # C3: 1.15 samples per raster pixel -- 64-pixel tiles only with f32 samples
+    dict(Fs=50e6, x_t=4400, y_t=2250, fv=60.0, nfr=2),     # C5: 2P >= 2^24, the integer walk
+])
+def test_frames_fast_raster_sample_formats(ctx, tsdr, synth, case):
+    """Option "raster_rec4": the raster walk on plain f32 samples (default since round 4; the pixel in the convex form with the
+    two integer weights) and, with 0, on the {a, slope hi, slope lo} records of rounds 1-3 (kept as the A/B): both against the
+    oracle -- identical sync indices, rasters and frames within the FAST tolerance."""
+    S = synth.samples_per_frame(case["Fs"], case["fv"])
+    iq = synth.synth_leak(case["Fs"], case["x_t"], case["y_t"], case["fv"], S * case["nfr"] + 77)
+    for rec4 in (0, 1):
+        ctx.set_option("raster_rec4", rec4)
+        try:
+            r = fast_vs_oracle(ctx, tsdr, O, iq, S, case["y_t"], case["x_t"], 0.1, True, RTOL)
+        finally:
+            ctx.set_option("raster_rec4", 1)
+        assert r["n_frames"] == case["nfr"] and not r["ties"], rec4
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_frames_pipeline_without_alignment_and_mixed_with_one_call(ctx, tsdr, synth, mode):
     """tsdr_frames_submit_d with do_align = 0 (no statistics, no guard: image launch + IIR only), and submissions
