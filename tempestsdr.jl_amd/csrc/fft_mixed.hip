@@ -852,6 +852,7 @@ struct Mix3Geom {
   static constexpr int S1 = RB * RC * T, S2 = RA * RC * T, S3 = RA * RB * T;
   static constexpr int SMAX = S1 > S2 ? (S1 > S3 ? S1 : S3) : (S2 > S3 ? S2 : S3);
   static constexpr int NT = (SMAX + 63) / 64 * 64;
+  static_assert(NT <= 1024, "three-step kernel: a step has more slots than a workgroup has threads");
   static constexpr int PLANE = RB * RC * T + T;
   static constexpr int VMAX = RA > RB ? (RA > RC ? RA : RC) : (RB > RC ? RB : RC);
   static constexpr size_t LDS = ((size_t)RA * PLANE + R) * sizeof(float2);
@@ -1062,6 +1063,26 @@ static const Mix3Entry kMix3[] = {MIX3(10, 10, 10, 3), MIX3(20, 10, 10, 2), MIX3
 #undef MIX3
 static const Mix3Entry *mix3_lookup(unsigned R) {
   for (const Mix3Entry &e : kMix3)
+    if (e.R == R) return &e;
+  return nullptr;
+}
+// getWelch's accumulator only (fft_rows_welch: the FFT_LAST kernel with MixDesc::acc; the pass planner does not see these):
+// the power-of-two segment lengths next to the 1024 that k_seg1024 serves -- 2048 = 16 x 16 x 8 (two segments per tile),
+// 4096 = 16 x 16 x 16 (one), 512 = 8 x 8 x 8 (eight), 256 = 8 x 8 x 4 (eight), 128 -- and the round lengths that split into
+// three of the register DFT sizes (4000, 3200, 2500, 1600, 1280, 1200, 768; 960 = 20 x 16 x 3 measured slower than the
+// generic kernel: 108 against 88 us); everything else: the generic LDS-stage kernel
+#define WELCH3(RA_, RB_, RC_, LT_)                                                                                          \
+  { RA_ * RB_ * RC_, LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, Mix3Geom<RA_, RB_, RC_, LT_>::LDS,                               \
+    k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST>, k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST> }
+static const Mix3Entry kWelch3[] = {
+    WELCH3(16, 16, 8, 1), WELCH3(16, 16, 16, 0), WELCH3(8, 8, 8, 3), WELCH3(8, 8, 4, 3), WELCH3(8, 4, 4, 4),   // 2048 4096 512 256 128
+    WELCH3(20, 20, 10, 0), WELCH3(25, 10, 10, 0), WELCH3(20, 16, 10, 0), WELCH3(20, 10, 8, 1),                  // 4000 2500 3200 1600
+    WELCH3(16, 16, 5, 1), WELCH3(20, 20, 3, 1), WELCH3(16, 16, 3, 2),                                           // 1280 1200 768
+};
+#undef WELCH3
+static const Mix3Entry *welch3_lookup(unsigned R) {
+  if (const Mix3Entry *e = mix3_lookup(R)) return e;
+  for (const Mix3Entry &e : kWelch3)
     if (e.R == R) return &e;
   return nullptr;
 }
@@ -1590,8 +1611,8 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
   d.rows = (unsigned)nbSeg;
   d.acc = part;
   d.rows_real = is_complex ? 0 : 1;
-  if (const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : mix3_lookup(d.R)) {
-    // 500 / 1000 / 2000: the three-register-step kernel, 8 (4) segments per 832-thread workgroup
+  if (const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : welch3_lookup(d.R)) {
+    // 500 / 1000 / 2000 (and 256 / 512 / 2048 / 4096 / 4000): the three-register-step kernel, 8 (4, 2, 1) segments per workgroup
     int rc3 = mix3_prepare(ctx, m3);
     if (rc3) return rc3;
     d.logT = m3->logT;

@@ -282,7 +282,10 @@ def test_spectrum_too_long_raises(ctx):
 
 @pytest.mark.parametrize("sizeFFT,cplx", [(1024, False), (1024, True), (256, True), (1000, False), (1000, True), (2, True), (6, False),
                                           (4096, True), (4096, False), (3000, True), (2048, False), (960, True), (17, True), (2000, True), (2000, False), (500, True),
-                                          (8192, True)])
+                                          (8192, True),
+                                          # the other segment lengths with a three-step accumulator kernel (fft_mixed.hip:kWelch3)
+                                          (128, True), (512, False), (512, True), (2048, True), (768, True), (1200, False), (1280, True), (1600, True),
+                                          (2500, True), (3200, False), (4000, True)])
 def test_welch_and_waterfall(ctx, sizeFFT, cplx):
     L = sizeFFT * 37 + min(123, sizeFFT - 1)  # ragged tail is dropped
     sig = crandn(L) if cplx else rng.standard_normal(L).astype(np.float32)
