@@ -297,6 +297,7 @@ int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_
                        float scale, size_t keep, const FftEpilogue *epi, bool *done);
 unsigned fft_rows_welch_parts(tsdr_ctx *ctx);
 int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, float *part, unsigned *nparts, bool *did);
+int fft_rows_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, double *wf, bool *did);
 bool fft_mixed_ok(size_t N);
 int fft_passes(size_t N);
 int ensure_tw_small(tsdr_ctx *ctx);  // builds ctx->tw_small: W_4096^e for e < 4096  // launches a length-N transform takes (0: not a 2^a 3^b 5^c length)

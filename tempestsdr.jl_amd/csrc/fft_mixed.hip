@@ -55,6 +55,9 @@ struct MixDesc {
   // leaves ONE partial power spectrum, acc[blockIdx.x * R + k] (natural frequency order).  rows_real: the rows are real f32.
   float *acc;
   int rows_real;
+  // ... or getWaterfall's writer (GetSpectrum.jl:54-66; three-step kernels only): Float64(abs2) of every spectrum straight from
+  // the registers to wf[segment * R + fftshift position], acc unused (non-null only to select the branch)
+  double *wf;
 };
 
 // a = k_1*(R_2..R_m) + ... + k_m  ->  k_1*W_1 + ... + k_m*W_m  (uniform per workgroup: scalar code)
@@ -878,7 +881,7 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
   for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
   const unsigned bid = blockIdx.x;
   float2 v[G::VMAX];
-  if (MODE == FFT_LAST && d.acc) {
+  if (MODE == FFT_LAST && (d.acc || d.wf)) {
     // ---- getWelch's accumulator (see MixDesc::acc): rows = segments, T of them per tile, nothing stored per transform.
     // A thread's step-3 slot (kk, t3) is the same for every tile, so abs2 of its RC outputs accumulates in registers.
     float acc[RC];
@@ -931,10 +934,21 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
 #pragma unroll
         for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T + (t3 ^ G::swz(n3))];
         dft_nat<RC>(v);
+        if (d.wf) {
+          double *row = d.wf + (size_t)((tile << LOGT) + (unsigned)t3) * R;
 #pragma unroll
-        for (int k3 = 0; k3 < RC; ++k3) acc[k3] += v[k3].x * v[k3].x + v[k3].y * v[k3].y;
+          for (int k3 = 0; k3 < RC; ++k3) {
+            int j = kk + RA * RB * k3 + R / 2;   // fftshift: frequency k lands at (k + floor(R / 2)) mod R
+            if (j >= R) j -= R;
+            __builtin_nontemporal_store((double)(v[k3].x * v[k3].x + v[k3].y * v[k3].y), &row[j]);   // written once
+          }
+        } else {
+#pragma unroll
+          for (int k3 = 0; k3 < RC; ++k3) acc[k3] += v[k3].x * v[k3].x + v[k3].y * v[k3].y;
+        }
       }
     }
+    if (d.wf) return;
     // the T segments of a tile sit in T adjacent lanes: added by a fixed xor tree, lane t3 = 0 stores
 #pragma unroll
     for (int k3 = 0; k3 < RC; ++k3) {
@@ -1618,8 +1632,11 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
     d.logT = m3->logT;
     d.mode = FFT_LAST;
     const unsigned ntiles3 = (unsigned)ceil_div(nbSeg, (size_t)1 << d.logT);
-    const unsigned per_cu3 = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / m3->lds);
-    const unsigned grid3 = std::min(ntiles3, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu3);
+    // (at most fft_rows_welch_parts() workgroups -- the caller's buffer holds that many partial spectra --, i.e. three per CU:
+    // every partial is one more row for k_welch_sum to add, and the short lengths' small tiles would otherwise put eight
+    // workgroups on a CU)
+    const unsigned per_cu3 = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / m3->lds));
+    const unsigned grid3 = std::min({ntiles3, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu3, fft_rows_welch_parts(ctx)});
     TSDR_LAUNCH(ctx, "welch_rows_acc3", m3->last, dim3(grid3), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
     *nparts = grid3;
     *did = true;
@@ -1640,6 +1657,34 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
   const unsigned grid = std::min(ntiles, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu);
   TSDR_LAUNCH(ctx, "welch_rows_acc", k_fft_mix, dim3(grid), dim3(256), lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
   *nparts = grid;
+  *did = true;
+  return TSDR_OK;
+}
+
+// getWaterfall for the segment lengths the three-step kernels serve (1024 has k_seg1024): segments -> Float64 power spectra,
+// fftshifted, in ONE launch -- the segment spectra never reach HBM (the route through a batched FFT + k_waterfall writes and
+// re-reads them: 109-250 us per C2 buffer at 512 .. 4096 against 40-60 us here)
+int fft_rows_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, double *wf, bool *did) {
+  *did = false;
+  if (N < 2 || N > 4096 || nbSeg == 0 || nbSeg >= (size_t(1) << 31) || ctx->opt_fft_no_mix2) return TSDR_OK;
+  const Mix3Entry *m3 = welch3_lookup((unsigned)N);
+  if (!m3) return TSDR_OK;
+  MixDesc d{};
+  d.dir = -1; d.N = N; d.src_mode = SRC_C2C; d.keep = N; d.mode = FFT_LAST; d.scale = 1.0f;
+  d.R = (unsigned)N;
+  const unsigned __int128 inv = ((unsigned __int128)1 << 64) / d.R;
+  d.r_hi = (unsigned)(inv >> 32);
+  d.r_lo = (unsigned)inv;
+  d.logT = m3->logT;
+  d.rows = (unsigned)nbSeg;
+  d.wf = wf;
+  d.rows_real = is_complex ? 0 : 1;
+  int rc = mix3_prepare(ctx, m3);
+  if (rc) return rc;
+  const unsigned ntiles = (unsigned)ceil_div(nbSeg, (size_t)1 << d.logT);
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / m3->lds);
+  const unsigned grid = std::min(ntiles, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu);
+  TSDR_LAUNCH(ctx, "waterfall_rows3", m3->last, dim3(grid), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
   *did = true;
   return TSDR_OK;
 }

@@ -569,6 +569,11 @@ int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len
     }
     return TSDR_OK;
   }
+  if (sizeFFT && sMatrix && len / sizeFFT > 0 && (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {
+    bool did = false;
+    int rcw = fft_rows_waterfall(ctx, sig, is_complex, sizeFFT, len / sizeFFT, sMatrix, &did);
+    if (rcw || did) return rcw;
+  }
   float2 *X;
   size_t nbSeg;
   int rc = segments_fft(ctx, sig, is_complex, len, sizeFFT, &X, &nbSeg);
