@@ -69,7 +69,7 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
  *               integers and the pixel in the convex form ((D - r) a + r b) / D in f32, both weights exact (the image's 2-D
  *               blend one f64 FMA per step); in the raster-free kernel 32.32 fixed-point coordinates and f32 blends with
  *               each weight converted from its own integer: pixels within a few ulp of TSDR_EXACT
- *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing and white noise reach 4.9e-7); ~2.5x fewer
+ *               (1e-6 relative; the tests assert 6e-7 on their cases, random fuzzing and white noise reach 5.4e-7 over ~1000 cases); ~2.5x fewer
  *               VALU cycles.  Default.  The images' projection
  *               sums are then formed inside the raster kernel (per-tile partial sums, added in tile order)
  *               instead of by a second pass over the images in the reference's row order, so beta differs from
