@@ -510,6 +510,11 @@ static int get_bluestein(tsdr_ctx *ctx, size_t n, BluesteinPlan **out) {
 int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n, size_t batch, int dir) {
   if (n == 0 || batch == 0) return TSDR_OK;
   const int d = dir < 0 ? -1 : 1;
+  if (is_complex && batch > 1 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0) {  // rows of 257 .. 4096 points: one launch, on chip
+    bool did = false;
+    int rcr = fft_rows_store(ctx, reinterpret_cast<const float2 *>(x), out, n, batch, d, d > 0 ? (float)(1.0 / (double)n) : 1.0f, &did);
+    if (rcr || did) return rcr;
+  }
   if (is_pow2(n)) {
     const float scale = d > 0 ? (float)(1.0 / (double)n) : 1.0f;
     const float2 *src = reinterpret_cast<const float2 *>(x);

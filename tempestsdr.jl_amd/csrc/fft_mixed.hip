@@ -58,6 +58,9 @@ struct MixDesc {
   // ... or getWaterfall's writer (GetSpectrum.jl:54-66; three-step kernels only): Float64(abs2) of every spectrum straight from
   // the registers to wf[segment * R + fftshift position], acc unused (non-null only to select the branch)
   double *wf;
+  // ... or plain batched row transforms (tsdr_fft_c2c with batch > 1, three-step kernels only): rows_out[row * R + k] = scale * X[k],
+  // either direction; may alias the input (a tile's rows are all loaded before any of them is stored)
+  float2 *rows_out;
 };
 
 // a = k_1*(R_2..R_m) + ... + k_m  ->  k_1*W_1 + ... + k_m*W_m  (uniform per workgroup: scalar code)
@@ -869,6 +872,10 @@ struct Mix3Geom {
   static __device__ __forceinline__ int swz(int n3) { return (n3 >> 1) & (T - 1); }
 };
 
+// MODE: FFT_STRIDED / FFT_LAST = passes of a multi-pass transform; the three whole-row modes below = rows of R points, T per
+// tile, walked by persistent workgroups (separate instantiations: as run-time branches of one kernel the row store's conjugations
+// and the writers' extra live values cost the accumulator 15-60 %)
+enum { M3_ACC = 10, M3_WF = 11, M3_ROWS = 12 };   // getWelch's accumulator | getWaterfall's writer | batched row transforms
 template <int RA, int RB, int RC, int LOGT, int MODE>
 __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(const float2 *__restrict__ in, float2 *__restrict__ out, MixDesc d) {
   using G = Mix3Geom<RA, RB, RC, LOGT>;
@@ -881,7 +888,7 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
   for (int e = tid; e < R; e += NT) twR[e] = tw_q32(phase_q32((unsigned)e, d.r_hi, d.r_lo));
   const unsigned bid = blockIdx.x;
   float2 v[G::VMAX];
-  if (MODE == FFT_LAST && (d.acc || d.wf)) {
+  if (MODE >= M3_ACC) {
     // ---- getWelch's accumulator (see MixDesc::acc): rows = segments, T of them per tile, nothing stored per transform.
     // A thread's step-3 slot (kk, t3) is the same for every tile, so abs2 of its RC outputs accumulates in registers.
     float acc[RC];
@@ -900,7 +907,7 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
       } else {
         const float2 *src = in + (size_t)row1 * R + r23;
 #pragma unroll
-        for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok1 ? src[n1 * R23] : make_float2(0.f, 0.f);
+        for (int n1 = 0; n1 < RA; ++n1) v[n1] = ok1 ? (MODE == M3_ROWS ? conj_if(src[n1 * R23], smask) : src[n1 * R23]) : make_float2(0.f, 0.f);
       }
       __syncthreads();  // twR (first trip); the previous tile's step-3 reads (later trips)
       if (tid < G::S1) {
@@ -934,7 +941,12 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
 #pragma unroll
         for (int n3 = 0; n3 < RC; ++n3) v[n3] = p[n3 * T + (t3 ^ G::swz(n3))];
         dft_nat<RC>(v);
-        if (d.wf) {
+        if (MODE == M3_ROWS) {
+          float2 *row = d.rows_out + (size_t)((tile << LOGT) + (unsigned)t3) * R;
+#pragma unroll
+          for (int k3 = 0; k3 < RC; ++k3)
+            row[kk + RA * RB * k3] = conj_if(make_float2(v[k3].x * d.scale, v[k3].y * d.scale), smask);
+        } else if (MODE == M3_WF) {
           double *row = d.wf + (size_t)((tile << LOGT) + (unsigned)t3) * R;
 #pragma unroll
           for (int k3 = 0; k3 < RC; ++k3) {
@@ -948,7 +960,7 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
         }
       }
     }
-    if (d.wf) return;
+    if (MODE != M3_ACC) return;
     // the T segments of a tile sit in T adjacent lanes: added by a fixed xor tree, lane t3 = 0 stores
 #pragma unroll
     for (int k3 = 0; k3 < RC; ++k3) {
@@ -1067,10 +1079,11 @@ __global__ __launch_bounds__((Mix3Geom<RA, RB, RC, LOGT>::NT)) void k_fft_mix3(c
 }
 
 typedef void (*mix3_fn)(const float2 *, float2 *, MixDesc);
-struct Mix3Entry { unsigned R; int logT, nt; size_t lds; mix3_fn strided, last; };
-#define MIX3(RA_, RB_, RC_, LT_)                                                                                              \
-  { RA_ * RB_ * RC_, LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, Mix3Geom<RA_, RB_, RC_, LT_>::LDS,                                 \
-    k_fft_mix3<RA_, RB_, RC_, LT_, FFT_STRIDED>, k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST> }
+struct Mix3Entry { unsigned R; int logT, nt; size_t lds; mix3_fn strided, last, acc, wf, rows; };
+#define MIX3(RA_, RB_, RC_, LT_)                                                                                            \
+  { RA_ * RB_ * RC_, LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, Mix3Geom<RA_, RB_, RC_, LT_>::LDS,                               \
+    k_fft_mix3<RA_, RB_, RC_, LT_, FFT_STRIDED>, k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST>, k_fft_mix3<RA_, RB_, RC_, LT_, M3_ACC>, \
+    k_fft_mix3<RA_, RB_, RC_, LT_, M3_WF>, k_fft_mix3<RA_, RB_, RC_, LT_, M3_ROWS> }
 // 8000-point tiles (64 KiB of LDS + the twiddle table): 1000 x 8 columns, 2000 x 4; 500 x 8 (4000 points)
 // (tiles half as wide -- 32-byte runs -- measured 25.8 / 22.9 us per pass against 18.5 / 19.9 at 2e6 points)
 static const Mix3Entry kMix3[] = {MIX3(10, 10, 10, 3), MIX3(20, 10, 10, 2), MIX3(5, 10, 10, 3)};
@@ -1086,27 +1099,31 @@ static const Mix3Entry *mix3_lookup(unsigned R) {
 // three of the register DFT sizes (4000, 3200, 2500, 1600, 1280, 1200, 768; 960 = 20 x 16 x 3 measured slower than the
 // generic kernel: 108 against 88 us); everything else: the generic LDS-stage kernel
 #define WELCH3(RA_, RB_, RC_, LT_)                                                                                          \
-  { RA_ * RB_ * RC_, LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, Mix3Geom<RA_, RB_, RC_, LT_>::LDS,                               \
-    k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST>, k_fft_mix3<RA_, RB_, RC_, LT_, FFT_LAST> }
+  { RA_ * RB_ * RC_, LT_, Mix3Geom<RA_, RB_, RC_, LT_>::NT, Mix3Geom<RA_, RB_, RC_, LT_>::LDS, nullptr, nullptr,             \
+    k_fft_mix3<RA_, RB_, RC_, LT_, M3_ACC>, k_fft_mix3<RA_, RB_, RC_, LT_, M3_WF>, k_fft_mix3<RA_, RB_, RC_, LT_, M3_ROWS> }
 static const Mix3Entry kWelch3[] = {
     WELCH3(16, 16, 8, 1), WELCH3(16, 16, 16, 0), WELCH3(8, 8, 8, 3), WELCH3(8, 8, 4, 3), WELCH3(8, 4, 4, 4),   // 2048 4096 512 256 128
+    WELCH3(16, 8, 8, 2),                                                                                       // 1024 (batched rows only: getWelch / getWaterfall have k_seg1024)
+    WELCH3(10, 10, 10, 2), WELCH3(5, 10, 10, 2),                                                               // 1000 500 on half the pass kernels' tiles: row / waterfall modes
+    // (1000: rows 50.5 -> 40.8 us, waterfall 57 -> 47 us, but the accumulator 44 -> 50 us; 2000 on 4000-point tiles lost everywhere)
     WELCH3(20, 20, 10, 0), WELCH3(25, 10, 10, 0), WELCH3(20, 16, 10, 0), WELCH3(20, 10, 8, 1),                  // 4000 2500 3200 1600
     WELCH3(16, 16, 5, 1), WELCH3(20, 20, 3, 1), WELCH3(16, 16, 3, 2),                                           // 1280 1200 768
 };
 #undef WELCH3
-static const Mix3Entry *welch3_lookup(unsigned R) {
-  if (const Mix3Entry *e = mix3_lookup(R)) return e;
+static const Mix3Entry *welch3_lookup(unsigned R, bool accumulator) {
+  if (accumulator)
+    if (const Mix3Entry *e = mix3_lookup(R)) return e;   // getWelch: the pass kernels' 8000-point tiles measured better
   for (const Mix3Entry &e : kWelch3)
     if (e.R == R) return &e;
-  return nullptr;
+  return mix3_lookup(R);
 }
 // kernels above 64 KiB of dynamic LDS have to be opted in once
 static int mix3_prepare(tsdr_ctx *ctx, const Mix3Entry *e) {
   static std::mutex mu;
   static std::unordered_map<const void *, bool> done;
   std::lock_guard<std::mutex> g(mu);
-  for (mix3_fn f : {e->strided, e->last}) {
-    if (done.count((const void *)f)) continue;
+  for (mix3_fn f : {e->strided, e->last, e->acc, e->wf, e->rows}) {
+    if (!f || done.count((const void *)f)) continue;
     TSDR_HIP(ctx, hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
     done[(const void *)f] = true;
   }
@@ -1625,7 +1642,7 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
   d.rows = (unsigned)nbSeg;
   d.acc = part;
   d.rows_real = is_complex ? 0 : 1;
-  if (const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : welch3_lookup(d.R)) {
+  if (const Mix3Entry *m3 = ctx->opt_fft_no_mix2 ? nullptr : welch3_lookup(d.R, true)) {
     // 500 / 1000 / 2000 (and 256 / 512 / 2048 / 4096 / 4000): the three-register-step kernel, 8 (4, 2, 1) segments per workgroup
     int rc3 = mix3_prepare(ctx, m3);
     if (rc3) return rc3;
@@ -1637,7 +1654,7 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
     // workgroups on a CU)
     const unsigned per_cu3 = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / m3->lds));
     const unsigned grid3 = std::min({ntiles3, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu3, fft_rows_welch_parts(ctx)});
-    TSDR_LAUNCH(ctx, "welch_rows_acc3", m3->last, dim3(grid3), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
+    TSDR_LAUNCH(ctx, "welch_rows_acc3", m3->acc, dim3(grid3), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
     *nparts = grid3;
     *did = true;
     return TSDR_OK;
@@ -1661,13 +1678,40 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
   return TSDR_OK;
 }
 
+// Batched row transforms (tsdr_fft_c2c with batch > 1) of the lengths the three-step kernels serve, in ONE launch: a row never
+// leaves the chip between its steps.  (The pass engines split a 512 .. 4096-point row into two passes whose strided one has only
+// 16-64 columns to work on: 67-197 us for 1e7 points against 35-50 us here; rows up to 256 points are one pass there already.)
+int fft_rows_store(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, bool *did) {
+  *did = false;
+  if (N <= 256 || N > 4096 || batch < 2 || batch >= (size_t(1) << 31) || ctx->opt_fft_no_mix2) return TSDR_OK;
+  const Mix3Entry *m3 = welch3_lookup((unsigned)N, false);
+  if (!m3) return TSDR_OK;
+  MixDesc d{};
+  d.dir = dir < 0 ? -1 : 1; d.N = N; d.src_mode = SRC_C2C; d.keep = N; d.mode = FFT_LAST; d.scale = scale;
+  d.R = (unsigned)N;
+  const unsigned __int128 inv = ((unsigned __int128)1 << 64) / d.R;
+  d.r_hi = (unsigned)(inv >> 32);
+  d.r_lo = (unsigned)inv;
+  d.logT = m3->logT;
+  d.rows = (unsigned)batch;
+  d.rows_out = out;
+  int rc = mix3_prepare(ctx, m3);
+  if (rc) return rc;
+  const unsigned ntiles = (unsigned)ceil_div(batch, (size_t)1 << d.logT);
+  const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / m3->lds));
+  const unsigned grid = std::min(ntiles, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu);
+  TSDR_LAUNCH(ctx, "fft_rows3", m3->rows, dim3(grid), dim3(m3->nt), m3->lds, in, (float2 *)nullptr, d);
+  *did = true;
+  return TSDR_OK;
+}
+
 // getWaterfall for the segment lengths the three-step kernels serve (1024 has k_seg1024): segments -> Float64 power spectra,
 // fftshifted, in ONE launch -- the segment spectra never reach HBM (the route through a batched FFT + k_waterfall writes and
 // re-reads them: 109-250 us per C2 buffer at 512 .. 4096 against 40-60 us here)
 int fft_rows_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, double *wf, bool *did) {
   *did = false;
   if (N < 2 || N > 4096 || nbSeg == 0 || nbSeg >= (size_t(1) << 31) || ctx->opt_fft_no_mix2) return TSDR_OK;
-  const Mix3Entry *m3 = welch3_lookup((unsigned)N);
+  const Mix3Entry *m3 = welch3_lookup((unsigned)N, false);
   if (!m3) return TSDR_OK;
   MixDesc d{};
   d.dir = -1; d.N = N; d.src_mode = SRC_C2C; d.keep = N; d.mode = FFT_LAST; d.scale = 1.0f;
@@ -1684,7 +1728,7 @@ int fft_rows_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N
   const unsigned ntiles = (unsigned)ceil_div(nbSeg, (size_t)1 << d.logT);
   const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / m3->lds);
   const unsigned grid = std::min(ntiles, (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256) * per_cu);
-  TSDR_LAUNCH(ctx, "waterfall_rows3", m3->last, dim3(grid), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
+  TSDR_LAUNCH(ctx, "waterfall_rows3", m3->wf, dim3(grid), dim3(m3->nt), m3->lds, reinterpret_cast<const float2 *>(sig), (float2 *)nullptr, d);
   *did = true;
   return TSDR_OK;
 }

@@ -59,6 +59,16 @@ def test_fft_any_length(ctx, n):
     assert relmax(O.fft(x), ref) < 1e-12
 
 
+@pytest.mark.parametrize("n,batch", [(512, 41), (1024, 37), (2048, 11), (4096, 5), (500, 33), (1000, 19), (2000, 6), (4000, 3), (768, 9),
+                                     (1280, 7), (2500, 2), (3200, 3), (128, 300), (512, 2)])
+def test_fft_rows_one_launch(ctx, n, batch):
+    """Batched row transforms of 257 .. 4096 points at the lengths the three-step kernels serve (fft_mixed.hip:fft_rows_store;
+    a ragged last tile: the batch is not a multiple of the rows per tile), both directions, against numpy."""
+    x = crandn(n * batch).reshape(batch, n)
+    assert relmax(ctx.fft(x), np.fft.fft(x.astype(np.complex128), axis=1)) < FFT_TOL
+    assert relmax(ctx.fft(x, inverse=True), np.fft.ifft(x.astype(np.complex128), axis=1)) < FFT_TOL
+
+
 # lengths 2^a 3^b 5^c go through the native mixed-radix passes: one pass (<= 256), two, three (2e6 = the packed
 # half of the 4e6-sample search window), ragged tiles (odd first radix), radix-3 stages, batches
 @pytest.mark.parametrize("n", [6, 10, 15, 25, 45, 120, 125, 200, 243, 250, 300, 625, 1000, 3000, 15625, 30000, 65610,
