@@ -511,6 +511,7 @@ int fft_any(tsdr_ctx *ctx, const float *x, int is_complex, float2 *out, size_t n
   if (n == 0 || batch == 0) return TSDR_OK;
   const int d = dir < 0 ? -1 : 1;
   if (is_complex && batch > 1 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0) {  // rows of 257 .. 4096 points: one launch, on chip
+    if (n == 1024) return fft_rows1024(ctx, reinterpret_cast<const float2 *>(x), out, batch, d, d > 0 ? (float)(1.0 / 1024.0) : 1.0f);
     bool did = false;
     int rcr = fft_rows_store(ctx, reinterpret_cast<const float2 *>(x), out, n, batch, d, d > 0 ? (float)(1.0 / (double)n) : 1.0f, &did);
     if (rcr || did) return rcr;

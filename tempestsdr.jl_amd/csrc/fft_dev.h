@@ -297,6 +297,7 @@ int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_
                        float scale, size_t keep, const FftEpilogue *epi, bool *done);
 unsigned fft_rows_welch_parts(tsdr_ctx *ctx);
 int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, float *part, unsigned *nparts, bool *did);
+int fft_rows1024(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t batch, int dir, float scale);   // spectrum.hip
 int fft_rows_store(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t N, size_t batch, int dir, float scale, bool *did);
 int fft_rows_waterfall(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, size_t nbSeg, double *wf, bool *did);
 bool fft_mixed_ok(size_t N);

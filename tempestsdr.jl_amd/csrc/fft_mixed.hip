@@ -1103,7 +1103,6 @@ static const Mix3Entry *mix3_lookup(unsigned R) {
     k_fft_mix3<RA_, RB_, RC_, LT_, M3_ACC>, k_fft_mix3<RA_, RB_, RC_, LT_, M3_WF>, k_fft_mix3<RA_, RB_, RC_, LT_, M3_ROWS> }
 static const Mix3Entry kWelch3[] = {
     WELCH3(16, 16, 8, 1), WELCH3(16, 16, 16, 0), WELCH3(8, 8, 8, 3), WELCH3(8, 8, 4, 3), WELCH3(8, 4, 4, 4),   // 2048 4096 512 256 128
-    WELCH3(16, 8, 8, 2),                                                                                       // 1024 (batched rows only: getWelch / getWaterfall have k_seg1024)
     WELCH3(10, 10, 10, 2), WELCH3(5, 10, 10, 2),                                                               // 1000 500 on half the pass kernels' tiles: row / waterfall modes
     // (1000: rows 50.5 -> 40.8 us, waterfall 57 -> 47 us, but the accumulator 44 -> 50 us; 2000 on 4000-point tiles lost everywhere)
     WELCH3(20, 20, 10, 0), WELCH3(25, 10, 10, 0), WELCH3(20, 16, 10, 0), WELCH3(20, 10, 8, 1),                  // 4000 2500 3200 1600

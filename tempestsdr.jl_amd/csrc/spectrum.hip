@@ -121,10 +121,16 @@ constexpr int kSegN = 1024, kSegWaves = 4, kSegPitch = 65;
 constexpr int kSegOcc = 3;
 constexpr bool kSegPrefetch = true;
 
-template <bool WATERFALL, bool CPLX>
+// KIND: what leaves the registers -- 0 getWelch's accumulation, 1 getWaterfall's Float64 power spectra, 2 the spectra themselves
+// (batched 1024-point row transforms, tsdr_fft_c2c: rows[seg * 1024 + k] = scale * X[k]; inverse by conjugating on the way in
+// and out; may alias the input: a wavefront stores segment s after it has loaded s and s + 1, and segments belong to one wavefront)
+enum { SEG_WELCH = 0, SEG_WATERFALL = 1, SEG_ROWS = 2 };
+template <int KIND, bool CPLX>
 __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float *__restrict__ sig, size_t nbSeg,
                                                             unsigned nwaves, float *__restrict__ part,
-                                                            double *__restrict__ wf) {
+                                                            double *__restrict__ wf, float2 *__restrict__ rows = nullptr,
+                                                            unsigned smask = 0u, float scale = 1.0f) {
+  constexpr bool WATERFALL = KIND == SEG_WATERFALL;
   __shared__ float2 lds[kSegWaves][16 * kSegPitch];
   __shared__ float2 tw2t[64];  // W_64^(l0 kb1) at [l0 * 16 + kb1]: four distinct addresses per wave-instruction
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float
     float2 v[16];
     if (!kSegPrefetch) fetch(seg);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = nx[m];
+    for (int m = 0; m < 16; ++m) v[m] = KIND == SEG_ROWS ? conj_if(nx[m], smask) : nx[m];
     if (kSegPrefetch && seg + 1 < seg1) fetch(seg + 1);
     reg_dft<16>(v);
 #pragma unroll
@@ -197,6 +203,10 @@ __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float
 #pragma unroll
       for (int kb0 = 0; kb0 < 4; ++kb0) {
         const float2 X = d[brev<4>(kb0)];
+        if (KIND == SEG_ROWS) {
+          rows[seg * kSegN + (size_t)(lane + 64 * j + 256 * kb0)] = conj_if(make_float2(X.x * scale, X.y * scale), smask);
+          continue;
+        }
         const float p = X.x * X.x + X.y * X.y;  // abs2 in f32, as the reference's abs2.(::ComplexF32)
         if (WATERFALL) {
           const int k = lane + 64 * j + 256 * kb0;
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(64 * kSegWaves, kSegOcc) void k_seg1024(const float
     __builtin_amdgcn_wave_barrier();  // Z2 fully read before the next segment's Z1 lands in the region
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  if (!WATERFALL) {
+  if (KIND == SEG_WELCH) {
     // the workgroup's wavefronts, in wavefront order, through LDS: one partial spectrum per workgroup
     __syncthreads();
     float *sp = reinterpret_cast<float *>(&lds[0][0]);  // [kSegWaves][1024] floats fit the kSegWaves x 8448-byte regions
@@ -493,6 +503,21 @@ static unsigned seg_waves(tsdr_ctx *ctx, size_t nbSeg, unsigned *blocks) {
   return nwaves;
 }
 
+}  // extern "C"
+namespace tsdr {
+// batched 1024-point row transforms on the wavefront-per-segment kernel (fft.hip:fft_any): 1e7 points in 30 us
+int fft_rows1024(tsdr_ctx *ctx, const float2 *in, float2 *out, size_t batch, int dir, float scale) {
+  if (batch == 0) return TSDR_OK;
+  if (batch >= (size_t(1) << 31)) return set_err(ctx, TSDR_EINVAL, "fft: too many rows");
+  unsigned blocks = 0;
+  const unsigned nwaves = seg_waves(ctx, batch, &blocks);
+  TSDR_LAUNCH(ctx, "fft_rows1024", (k_seg1024<SEG_ROWS, true>), dim3(blocks), dim3(64 * kSegWaves), 0, reinterpret_cast<const float *>(in), batch,
+              nwaves, (float *)nullptr, (double *)nullptr, out, dir > 0 ? 0x80000000u : 0u, scale);
+  return TSDR_OK;
+}
+}  // namespace tsdr
+extern "C" {
+
 int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y) {
   if (!ctx || !y || (len && !sig)) return TSDR_EINVAL;
   if (sizeFFT == (size_t)kSegN && len / sizeFFT > 0 && len / sizeFFT < (size_t(1) << 31) &&
@@ -503,10 +528,10 @@ int tsdr_welch_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len, si
     float *part = (float *)ctx->scratch(WS_FFT_A, (size_t)blocks * kSegN * 4);
     if (!part) return TSDR_ENOMEM;
     if (is_complex) {
-      TSDR_LAUNCH(ctx, "welch_seg1024", (k_seg1024<false, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves, part,
+      TSDR_LAUNCH(ctx, "welch_seg1024", (k_seg1024<SEG_WELCH, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves, part,
                   (double *)nullptr);
     } else {
-      TSDR_LAUNCH(ctx, "welch_seg1024", (k_seg1024<false, false>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves, part,
+      TSDR_LAUNCH(ctx, "welch_seg1024", (k_seg1024<SEG_WELCH, false>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves, part,
                   (double *)nullptr);
     }
     TSDR_LAUNCH(ctx, "welch_finish", k_welch_finish, dim3(kSegN / 16), dim3(256), 0, (const float *)part, blocks, lin, y);
@@ -561,10 +586,10 @@ int tsdr_waterfall_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t len
     unsigned blocks = 0;
     const unsigned nwaves = seg_waves(ctx, nbSeg, &blocks);
     if (is_complex) {
-      TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<true, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
+      TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<SEG_WATERFALL, true>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
                   (float *)nullptr, sMatrix);
     } else {
-      TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<true, false>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
+      TSDR_LAUNCH(ctx, "waterfall_seg1024", (k_seg1024<SEG_WATERFALL, false>), dim3(blocks), dim3(64 * kSegWaves), 0, sig, nbSeg, nwaves,
                   (float *)nullptr, sMatrix);
     }
     return TSDR_OK;
