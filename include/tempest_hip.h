@@ -113,13 +113,14 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *   "down_spp_max_pct" the raster-free TSDR_FAST route uses the tap kernel up to this many samples per raster pixel, in percent
  *                 (default 200), the raster walk with out == NULL above; "down_xcd" 1 (default): XCD-aware tile order of that kernel.
  *   "beta_waves"  wavefronts per workgroup of the vsync statistics kernel: 4 (default) or 8; identical results.
- *   "pipe_mode"   how tsdr_frames_submit_d arranges successive buffers on its internal streams: 0 = image launches on one stream,
- *                 every buffer's tail on a second one of the highest priority; 1 = whole buffers alternate between equal
- *                 streams, only the shift + IIR launches chained; -1 (default) = 0 when rasters are written, 1 when not
- *                 (what measured best on C2).  "pipe_lanes": equal streams of arrangement 1 (2; 3 pays only with
- *                 GPU_MAX_HW_QUEUES >= 8).  "pipe_priority": 0 = no stream priority for the tails (before the first use).
+ *   "pipe_mode"   how tsdr_frames_submit_d arranges successive buffers on its internal streams: -1 (default) = the measured
+ *                 choice (below); 0 = image launches on one stream, every buffer's tail on a second one ("pipe_priority" 1,
+ *                 default: of the highest priority); 1 = whole buffers alternate between "pipe_lanes" (2 or 3) equal streams,
+ *                 only the shift + IIR launches chained; 2 = one internal stream (the sequential order).
+ *                 "pipe_tune" 1 (default): with "pipe_mode" -1 the first submissions of a configuration time every candidate
+ *                 arrangement (tsdr_frames_pipeline_info) and the rest use the fastest; 0: arrangement 0 with rasters, 1 without.
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
- * TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT
+ * TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_TUNE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT
  * preset them, read once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
 /* running totals of the sync guard on this context: frames whose margins were checked / frames flagged (re-evaluated in
@@ -291,18 +292,24 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
 /* The same per-buffer body pipelined across buffers, for callers that stream successive buffers (the GUI loop of
  * GUI.jl:150-178 does: one buffer after the other from the SDR).  submit(k) only enqueues, on internal HIP streams, so
  * that the latency-bound tail of a buffer (vsync statistics, sync guard, shift + IIR) runs beside the image launch of the
- * next one.  With rasters: the image launches of all submissions back to back on one stream, every tail on a second one of
- * the highest priority, which waits for its image launch through an event (C2: 182 k vs 171 k frames/s).  Without: whole
- * buffers alternate between two equal streams, and only the shift + IIR launches -- the lagged s_y and the IIR recurrence
- * -- are chained across them by events (390 k vs 347 k; option "pipe_mode").  Up to three image / key
- * / projection slots rotate.
+ * next one.  Arrangements: the image launches of all submissions back to back on one stream and every tail on a second one,
+ * which waits for its image launch through an event; or whole buffers alternating between equal streams with only the
+ * shift + IIR launches -- the lagged s_y and the IIR recurrence -- chained across them by events; or one stream.
+ * WHICH one, on which of the library's streams, is MEASURED: how well two HIP streams of a process overlap depends on the
+ * hardware queues they were mapped to, i.e. on what else the process created before (the same code: +8 % or -40 % against one
+ * call per buffer).  Like the reference's FFTW.PATIENT plans (Resampler.jl:31,39), the first submissions of a configuration
+ * -- 15 buffers through each of 8 candidates, results identical in all of them -- are timed with HIP events and the rest
+ * use the fastest, the sequential order included, so the pipeline is never slower than one call per buffer by more than the
+ * measurement's noise (options "pipe_mode" / "pipe_tune"; tsdr_frames_pipeline_info).  Up to three image / key / projection
+ * slots rotate.
  * Ordering: a submission waits for whatever the context's stream holds at the time of the call (uploads, a producer's
  * kernels); tsdr_frames_flush -- which only enqueues -- orders the context's stream behind every submitted buffer, so
  * outputs are complete in stream order after the flush and on the host after tsdr_synchronize (which flushes).  Any
  * other entry point that uses the same SyncXY state or image slots (tsdr_frames_d, tsdr_frames_scan_d / _combine_d,
  * tsdr_vsync_d, tsdr_sync_reset / _free, tsdr_set_stream, tsdr_dev_free, tsdr_destroy) flushes first, so results never
  * depend on the mix of calls.  Results are identical to calling tsdr_frames_d once per buffer (sync indices; pixels
- * bit for bit -- except which buffers the adaptive guard route runs in TSDR_EXACT, see "sync_guard_auto").
+ * bit for bit).  A submission whose configuration (frames per buffer, S, y_t, x_t, raster or not, precision, SyncXY) differs
+ * from the previous one's waits on the HOST for the buffers in flight (its workspace slots move), as does a trial boundary.
  * Lifetime: until a flush point has been reached AND the context's stream has completed, the caller must not touch or
  * free iq, the SyncXY state, imageOut_state, frames_out / raster_out / sync_idx of submitted work, and each in-flight
  * buffer (up to three) needs its own frames_out / raster_out / sync_idx. */
@@ -310,6 +317,11 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                          int *sync_idx, int *n_frames);
 int tsdr_frames_flush(tsdr_ctx *ctx);
+/* what the pipeline measured on this context (host-side, no synchronisation): *trials_left = candidate arrangements still to
+ * be timed for the current configuration (0: settled, or nothing is measured); *chosen = index of the arrangement in use
+ * (-1 while measuring); ms_per_buffer[c] = mean interval between the tails of successive buffers under candidate c (0: not
+ * yet measured), min(cap, 8) entries; text: the same as one line, with the candidates' names. */
+int tsdr_frames_pipeline_info(tsdr_ctx *ctx, int *trials_left, int *chosen, float *ms_per_buffer, int cap, char *text, size_t text_cap);
 
 /* ---- host -> device staging ring ---------------------------------------
  * The consumer side of AtomicCircularBuffer (AtomicAbstractSDRs.jl:64-190): `depth` slots of nEch samples in
@@ -347,6 +359,47 @@ int tsdr_frames_scan_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t n
                        int do_align, float *img_out, float *raster_out, unsigned long long *keys_out, int *n_frames);
 int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, const unsigned long long *keys, int n_frames,
                           float alpha, int do_align, float *imageOut_state, float *frames_out, int *sync_idx);
+
+/* ---- one process, several GPUs: the multi-GPU split behind the C ABI ------------------
+ * The reference runtime is ONE process (GUI.jl:380-382).  A tsdr_group is what such a process holds to use several
+ * MI355X of a node: one tsdr_ctx per device and one RCCL communicator per device (ncclCommInitAll from librccl, which this
+ * library links: single-process ranks over xGMI), driven by the calling thread.  Host pointers in and out, like the other
+ * entry points the Julia shim binds; every call returns with its outputs complete.  Member 0 is the root: it runs the
+ * non-linear and sequential steps and is the device a renderer would read from.
+ * devices == NULL: devices 0 .. n-1.  A group of ONE device is valid and returns the single-context results bit for bit. */
+typedef struct tsdr_group tsdr_group;
+int tsdr_group_create(const int *devices, int n, tsdr_group **out);
+void tsdr_group_destroy(tsdr_group *g);
+int tsdr_group_size(const tsdr_group *g);
+tsdr_ctx *tsdr_group_ctx(tsdr_group *g, int i); /* member i's context (owned by the group) */
+const char *tsdr_group_last_error(tsdr_group *g);
+int tsdr_group_set_precision(tsdr_group *g, int mode);                  /* tsdr_set_precision on every member */
+int tsdr_group_set_option(tsdr_group *g, const char *name, int value);  /* tsdr_set_option on every member */
+/* extract_configuration's inner step, GUI.jl:73-81 -- arguments as tsdr_autocorr_search_d, x and out on the HOST (out may be
+ * NULL).  The circular autocorrelation (Autocorrelations.jl:27-29) is a sum over m: member g receives its range of m plus a
+ * halo of indexMax samples, forms the partial sums (tsdr_autocorr_partial_d), ONE ncclAllReduce(sum, f32, indexMax) adds the
+ * accumulators over xGMI, then the root applies 10log10(abs2) (:33) and findmax over out[win_lo .. win_lo + win_cnt).
+ * route 0: sharded only when a member's segment + halo transform is smaller than the single-device one -- with the
+ * reference's own window n = 2 indexMax (:27) the halo makes that never the case, and the root runs tsdr_autocorr_search_d
+ * alone; 1: always sharded (also on one device: the all-reduce then has one rank); 2: always the root alone. */
+int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, double Fs, double minDelay, double maxDelay,
+                      int log_scale, float *out, size_t *n_out, size_t win_lo, size_t win_cnt, size_t *idx, float *val,
+                      int route);
+/* coreProcessing's per-buffer body, GUI.jl:163-178 -- arguments as tsdr_frames (host pointers).  Member g scans its
+ * contiguous range of the buffer's frames (tsdr_frames_scan_d: H2D of those frames only); images and argmax keys are
+ * gathered to the root (ncclSend / ncclRecv, 1.92 MB + 16 B per frame), which applies the lagged s_y, circshift and the IIR
+ * over all frames in order (tsdr_frames_combine_d); rasters, when wanted, go from each member straight to raster_out.
+ * The SyncXY states live inside the group (the root's carries the lagged s_y across calls): tsdr_group_sync_reset = a
+ * fresh SyncXY. */
+int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha, int do_align,
+                      float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx, int *n_frames);
+int tsdr_group_sync_reset(tsdr_group *g);
+/* getWelch, GetSpectrum.jl:36-52 -- arguments as tsdr_welch: member g accumulates abs2.(fft(seg)) over its range of
+ * segments, ONE all-reduce of sizeFFT f32, 10log10 after it. */
+int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y);
+/* the last call's route (1 = sharded / gathered, 2 = root alone) and its three stages on the root's stream in ms:
+ * {upload + per-member stage, collective, root's final stage}. */
+int tsdr_group_timing(tsdr_group *g, int *route, double ms[3]);
 
 #ifdef __cplusplus
 }

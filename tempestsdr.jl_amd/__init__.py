@@ -13,6 +13,6 @@ julia/TempestHIP.jl (the `ccall` shim the Julia runtime loads).
 """
 from . import _lib  # noqa: F401
 from ._lib import RENDER_H, RENDER_W, TempestHIPError  # noqa: F401
-from .api import (Context, Resampler, StagingRing, SyncXY, amDemod, calculate_autocorrelation, default_context,  # noqa: F401
+from .api import (Context, Group, Resampler, StagingRing, SyncXY, amDemod, calculate_autocorrelation, default_context,  # noqa: F401
                   downgradeImage, fmDemod, getSpectrum, getWaterfall, getWelch, init_resampler, invert_amDemod,
                   naiveResampler, sig_to_image, vsync, zoom_autocorr)

@@ -117,6 +117,7 @@ _SIGS = {
     "tsdr_frames_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_submit_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_flush": (C.c_int, [vp]),
+    "tsdr_frames_pipeline_info": (C.c_int, [vp, c_i, c_i, c_f, C.c_int, C.c_char_p, c_sz]),
     "tsdr_ring_create": (C.c_int, [vp, c_sz, C.c_int, C.c_int, C.c_float, C.POINTER(vp)]),
     "tsdr_ring_free": (None, [vp]),
     "tsdr_ring_put": (C.c_int, [vp, vp]),
@@ -129,6 +130,20 @@ _SIGS = {
     "tsdr_ring_prefetch_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "tsdr_frames_scan_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, c_i]),
     "tsdr_frames_combine_d": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+    # one process, several GPUs (RCCL inside the library)
+    "tsdr_group_create": (C.c_int, [c_i, C.c_int, C.POINTER(vp)]),
+    "tsdr_group_destroy": (None, [vp]),
+    "tsdr_group_size": (C.c_int, [vp]),
+    "tsdr_group_ctx": (vp, [vp, C.c_int]),
+    "tsdr_group_last_error": (C.c_char_p, [vp]),
+    "tsdr_group_set_precision": (C.c_int, [vp, C.c_int]),
+    "tsdr_group_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "tsdr_group_search": (C.c_int, [vp, vp, C.c_int, c_sz, C.c_double, C.c_double, C.c_double, C.c_int, vp, c_szp, c_sz, c_sz,
+                                    c_szp, c_f, C.c_int]),
+    "tsdr_group_frames": (C.c_int, [vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
+    "tsdr_group_sync_reset": (C.c_int, [vp]),
+    "tsdr_group_welch": (C.c_int, [vp, vp, C.c_int, c_sz, c_sz, C.c_int, vp]),
+    "tsdr_group_timing": (C.c_int, [vp, c_i, c_d]),
 }
 
 

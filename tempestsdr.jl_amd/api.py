@@ -95,6 +95,13 @@ class Context:
         self.call("tsdr_sync_guard_auto", C.byref(e), C.byref(a), C.byref(b))
         return bool(e.value), int(a.value), int(b.value)
 
+    def pipeline_info(self):
+        """what tsdr_frames_submit_d measured on this context: dict(trials_left, chosen, ms_per_buffer[8], text)"""
+        left, chosen, ms, text = C.c_int(0), C.c_int(-1), (C.c_float * 8)(), C.create_string_buffer(1024)
+        self.call("tsdr_frames_pipeline_info", C.byref(left), C.byref(chosen), ms, 8, text, 1024)
+        return {"trials_left": left.value, "chosen": chosen.value, "ms_per_buffer": [round(float(v), 5) for v in ms],
+                "text": text.value.decode()}
+
     def sync_guard_margins(self, max_frames=1 << 16):
         """(frames, 2) relative top-2 margins (x, y) the guard saw in the last FAST frame-loop call"""
         n = C.c_int(0)
@@ -388,6 +395,117 @@ def frames_submit_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, fr
 def frames_flush(ctx):
     """Order the context's stream after every buffer submitted with frames_submit_d."""
     ctx.call("tsdr_frames_flush")
+
+
+class Group:
+    """One process, several GPUs (tsdr_group_*): one context per device and one RCCL communicator per device inside the
+    library; host arrays in and out.  The Python twin of TempestHIP.jl's `HipGroup` -- what a single-process runtime such as
+    the reference's (GUI.jl:380-382) holds to use every MI355X of a node.  A group of one device is valid."""
+
+    ROUTES = {"auto": 0, "sharded": 1, "root": 2}
+
+    def __init__(self, devices=(0,)):
+        self.lib = _lib.load()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p(0)
+        rc = self.lib.tsdr_group_create(devs, len(devices), C.byref(h))
+        if rc or not h.value:
+            raise TempestHIPError(f"tsdr_group_create({list(devices)}) failed: {self.lib.tsdr_strerror(rc).decode()} "
+                                  "(no usable HIP device / RCCL communicator; there is no CPU fallback)")
+        self.h = h.value
+        self.devices = tuple(int(d) for d in devices)
+
+    def _chk(self, rc, what):
+        if rc == _lib.TSDR_OK:
+            return
+        detail = self.lib.tsdr_group_last_error(self.h).decode()
+        msg = f"{what}: {self.lib.tsdr_strerror(rc).decode()}" + (f" [{detail}]" if detail else "")
+        if rc == _lib.TSDR_EINVAL:
+            raise AssertionError(msg)
+        if rc == _lib.TSDR_EBOUNDS:
+            raise IndexError(msg)
+        if rc == _lib.TSDR_ENOMEM:
+            raise MemoryError(msg)
+        raise TempestHIPError(msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tsdr_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.lib.tsdr_group_size(self.h)
+
+    def set_precision(self, mode):
+        self._chk(self.lib.tsdr_group_set_precision(self.h, {"exact": _lib.EXACT, "fast": _lib.FAST}[mode]), "set_precision")
+
+    def set_option(self, name, value):
+        self._chk(self.lib.tsdr_group_set_option(self.h, name.encode(), int(value)), f"set_option({name})")
+
+    def sync_reset(self):
+        self._chk(self.lib.tsdr_group_sync_reset(self.h), "sync_reset")
+
+    def timing(self):
+        """(route, [ms per-member stage incl. upload, ms collective, ms root's final stage]) of the last call"""
+        r, ms = C.c_int(0), (C.c_double * 3)()
+        self._chk(self.lib.tsdr_group_timing(self.h, C.byref(r), ms), "timing")
+        return {1: "sharded", 2: "root"}.get(r.value, "none"), [float(v) for v in ms]
+
+    def autocorr_search(self, sig, Fs, minDelay, maxDelay, rate_min=50, rate_max=90, scale="log", route="auto"):
+        """Context.autocorr_search over the group (tsdr_group_search; GUI.jl:73-81): -> (G, pos, val)."""
+        a = np.ascontiguousarray(sig)
+        is_iq = int(np.iscomplexobj(a))
+        a = a.astype(np.complex64 if is_iq else np.float32, copy=False)
+        index_min = 1 + int(np.round(minDelay * Fs))
+        index_max = int(np.round(maxDelay * Fs))
+        cnt = max(index_max - index_min + 1, 0)
+        pmin, pmax = C.c_size_t(0), C.c_size_t(0)
+        check(None, self.lib.tsdr_zoom_bounds(cnt, float(Fs), float(rate_min), float(rate_max), C.byref(pmin), C.byref(pmax)),
+              "tsdr_zoom_bounds")
+        G = np.empty(max(cnt, 1), np.float32)
+        n_out, idx, val = C.c_size_t(0), C.c_size_t(0), C.c_float(0)
+        self._chk(self.lib.tsdr_group_search(self.h, _ptr(a), is_iq, a.size, float(Fs), float(minDelay), float(maxDelay),
+                                             1 if scale == "log" else 0, _ptr(G), C.byref(n_out), int(pmin.value - 1),
+                                             int(pmax.value - pmin.value + 1), C.byref(idx), C.byref(val), self.ROUTES[route]),
+                  "tsdr_group_search")
+        return G[: n_out.value], int(idx.value), float(val.value)
+
+    def frames(self, iq, S, y_t, x_t, alpha, imageOut, do_align=True, want_frames=True, want_raster=False):
+        """Context.frames over the group (tsdr_group_frames): frames sharded over the members, combined on the root."""
+        z = _c64(iq)
+        nb = z.size // int(S)
+        if not (isinstance(imageOut, np.ndarray) and imageOut.dtype == np.float32 and imageOut.flags.f_contiguous
+                and imageOut.shape == (RENDER_H, RENDER_W)):
+            raise AssertionError("imageOut must be a Fortran-order float32 (600,800) array")
+        frames = np.empty((nb, RENDER_H, RENDER_W), np.float32) if want_frames else None
+        raster = np.empty((nb, int(y_t) * int(x_t)), np.float32) if want_raster else None
+        idx = np.zeros((nb, 2), np.int32)
+        n = C.c_int(0)
+        self._chk(self.lib.tsdr_group_frames(self.h, _ptr(z), z.size, int(S), int(y_t), int(x_t), C.c_float(alpha),
+                                             int(bool(do_align)), _ptr(imageOut), _ptr(frames), _ptr(raster), _ptr(idx), C.byref(n)),
+                  "tsdr_group_frames")
+        out = {"n_frames": n.value, "sync_idx": idx}
+        if frames is not None:
+            out["frames"] = [frames[f].reshape(-1).reshape((RENDER_H, RENDER_W), order="F") for f in range(nb)]
+        if raster is not None:
+            out["raster"] = [raster[f].reshape((int(y_t), int(x_t)), order="F") for f in range(nb)]
+        return out
+
+    def getWelch(self, fe, sig, sizeFFT=1024, lin=False):
+        """Context.getWelch over the group (tsdr_group_welch): segments sharded, one all-reduce of sizeFFT floats."""
+        a = np.ascontiguousarray(sig)
+        cplx = int(np.iscomplexobj(a))
+        a = a.astype(np.complex64 if cplx else np.float32, copy=False)
+        y = np.empty(int(sizeFFT), np.float32)
+        self._chk(self.lib.tsdr_group_welch(self.h, _ptr(a), cplx, a.size, int(sizeFFT), int(bool(lin)), _ptr(y)), "tsdr_group_welch")
+        fAx = (np.arange(int(sizeFFT), dtype=np.float64) / int(sizeFFT) - 0.5) * fe
+        return fAx, y
 
 
 class StagingRing:

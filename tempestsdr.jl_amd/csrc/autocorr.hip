@@ -278,7 +278,7 @@ static int autocorr_core(tsdr_ctx *ctx, const float *x, int is_iq, size_t n, siz
   return TSDR_OK;
 }
 
-static int autocorr_args(tsdr_ctx *ctx, size_t len, double Fs, double minDelay, double maxDelay, size_t *n, size_t *k0,
+int autocorr_args(tsdr_ctx *ctx, size_t len, double Fs, double minDelay, double maxDelay, size_t *n, size_t *k0,
                          size_t *cnt) {
   const double dmin = jl_round(minDelay * Fs), dmax = jl_round(maxDelay * Fs);
   // (round(x) |> Int of a non-finite or huge value is an InexactError in the reference; a negative index a BoundsError)

@@ -106,23 +106,43 @@ struct tsdr_ctx {
   int amax_slot = 0;
   bool amax_dirty = false;   // a fused findmax may have left keys in the slot words (autocorr.hip:amax_begin clears them)
   unsigned long long amax_seq = 0;
-  // frame loop pipelined across buffers (tsdr_frames_submit_d, frames.hip): the image launches of successive buffers run
-  // back to back on one internal stream, every buffer's tail (vsync statistics, sync guard, shift + IIR) on a second one
+  // frame loop pipelined across buffers (tsdr_frames_submit_d, frames.hip): successive buffers on internal HIP streams so that
+  // the latency-bound tail of one (vsync statistics, sync guard, shift + IIR) runs beside the image launch of the next.
+  // WHICH streams, and in which arrangement, is measured, not assumed (frames.hip:pipe_pick): how well two HIP streams of a
+  // process overlap depends on the hardware queues they were mapped to, i.e. on what else the process created before.
   static constexpr int kPipeSlots = 3;   // image / key / projection / guard-record slots in rotation
+  static constexpr int kPoolN = 6, kPoolH = 2;   // candidate streams: normal priority / highest priority
+  static constexpr int kTuneCands = 8, kTrial = 15;
   unsigned long long pipe_n = 0;    // submissions since the last flush point
   unsigned long long pipe_seq = 0;  // submissions since the lanes were last run empty (slot = pipe_seq % kPipeSlots)
-  size_t pipe_nb = 0;               // frames per buffer of the submissions in flight (the image slots are pipe_nb frames apart)
-  hipStream_t lane[4] = {};         // created when first used (frames.hip:lane_get)
+  // what the slot offsets of the submissions in flight were computed from: frames per buffer (the image slots are that many
+  // frames apart), the tile plan of (S, y_t, x_t, raster or not, precision) for the projection sums, the SyncXY object's block
+  // counts for the guard records.  A change of any of them runs the pipeline empty first.
+  struct PipeKey {
+    size_t nb = 0, S = 0; int y_t = 0, x_t = 0, raster = -1, prec = -1, align = -1; const void *sync = nullptr;
+    bool operator==(const PipeKey &o) const {
+      return nb == o.nb && S == o.S && y_t == o.y_t && x_t == o.x_t && raster == o.raster && prec == o.prec && align == o.align && sync == o.sync;
+    }
+  } pipe_key;
+  hipStream_t pool[kPoolN + kPoolH] = {};  // created at the first submission (frames.hip:pipe_init)
+  hipStream_t lane[4] = {};         // the streams of the arrangement in use (members of pool): [0], [1], [3] equal lanes / [0] image lane, [2] tail lane
   hipEvent_t ev_img[kPipeSlots] = {}, ev_tail[kPipeSlots] = {};  // recorded behind a slot's image launch / its shift + IIR
   bool ev_tail_used[kPipeSlots] = {};
   hipEvent_t lane_in = nullptr;     // "inputs ready" point of the context's stream
   int pipe_last_slot = -1;          // slot of the latest submission: its tail is behind everything submitted
-  int opt_pipe_priority = 1;        // 1: the tail streams are created with the highest stream priority
-  int pipe_lane = 0;                // lane of the call being enqueued (per-lane guard queue words)
-  int opt_pipe_mode = -1;           // 0: image lane + tail lane; 1: whole buffers alternate between opt_pipe_lanes equal lanes, only
-                                    // shift + IIR chained; -1: 0 with rasters, 1 without
-  int pipe_sym_now = -1;            // arrangement of the submissions in flight
-  int opt_pipe_lanes = 2;           // equal lanes of the symmetric arrangement: 2, or 3 (pays only with GPU_MAX_HW_QUEUES >= 8: 401 k vs 390 k frames/s)
+  int pipe_cand_now = -1;           // arrangement (index into frames.hip:kCands) of the submissions in flight
+  int pipe_lane = 0;                // lane of the call being enqueued (per-lane guard queue words, workspace raster)
+  int opt_pipe_mode = -1;           // -1: the measured choice; 0: image lane + tail lane; 1: whole buffers alternate between opt_pipe_lanes
+                                    // equal lanes, only shift + IIR chained; 2: one internal stream (the sequential order)
+  int opt_pipe_lanes = 2;           // equal lanes of the forced arrangement 1: 2 or 3
+  int opt_pipe_priority = 1;        // forced arrangement 0: the tail lane is a stream of the highest priority
+  int opt_pipe_tune = 1;            // 0: "pipe_mode" -1 means arrangement 0 with rasters, 1 without (rounds 1-4), nothing is measured
+  struct PipeTune {                 // the measured choice for one PipeKey
+    PipeKey key; int state = 0;     // 0: nothing measured; 1: trials running; 2: settled
+    int cand = 0, pos = 0, chosen = -1;
+    float ms[kTuneCands] = {};      // mean interval between the tails of successive buffers, per arrangement
+  } tune;
+  hipEvent_t tune_ev[kTrial] = {};
   int opt_beta_waves = 4;           // wavefronts per k_beta workgroup (4 or 8): alone the two tie; beside the pipeline's image kernel a 256-thread
                                     // workgroup fits the holes its retiring workgroups leave (raster-free 357 k vs 309 k frames/s)
 
@@ -133,6 +153,9 @@ namespace tsdr {
 
 int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...);
 int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what);
+// A kernel that asks for more than 64 KiB of dynamic LDS has to be opted in -- once per (device, function): the attribute
+// belongs to the device's function object, and one process may hold contexts on several devices (tsdr_group_*).
+int lds_opt_in(tsdr_ctx *ctx, const void *fn, size_t bytes);
 // frames.hip: order the context's stream behind every buffer submitted to the pipeline (tsdr_frames_submit_d)
 int pipe_drain(tsdr_ctx *ctx);
 void pipe_sync_lanes(tsdr_ctx *ctx);   // host-side wait for the pipeline's internal streams

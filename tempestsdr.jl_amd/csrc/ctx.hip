@@ -2,6 +2,8 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
 
 #include "common.h"
 
@@ -24,6 +26,17 @@ int set_err(tsdr_ctx *ctx, int status, const char *fmt, ...) {
 
 int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what) {
   return set_err(ctx, TSDR_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int lds_opt_in(tsdr_ctx *ctx, const void *fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, size_t> opted;   // (device, function) -> bytes opted in to so far
+  std::lock_guard<std::mutex> g(mu);
+  size_t &have = opted[{ctx->device, fn}];
+  if (bytes <= have) return TSDR_OK;
+  TSDR_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return TSDR_OK;
 }
 
 static hipEvent_t take_event(tsdr_ctx *ctx) {
@@ -143,7 +156,8 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_RASTER_REC4")) ctx->opt_raster_rec4 = atoi(e);
   if (const char *e = getenv("TSDR_DOWN_XCD")) ctx->opt_down_xcd = atoi(e) != 0;
   if (const char *e = getenv("TSDR_DOWN_SPP_MAX_PCT")) ctx->opt_down_spp_max_pct = atoi(e);
-  if (const char *e = getenv("TSDR_PIPE_MODE")) ctx->opt_pipe_mode = atoi(e) < 0 ? -1 : atoi(e) != 0;
+  if (const char *e = getenv("TSDR_PIPE_MODE")) ctx->opt_pipe_mode = atoi(e) < 0 ? -1 : atoi(e) > 2 ? 2 : atoi(e);
+  if (const char *e = getenv("TSDR_PIPE_TUNE")) ctx->opt_pipe_tune = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;
   if (const char *e = getenv("TSDR_BETA_WAVES")) ctx->opt_beta_waves = atoi(e) == 8 ? 8 : 4;
   return ctx;
@@ -155,7 +169,8 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   (void)tsdr::pipe_drain(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   tsdr::pipe_sync_lanes(ctx);
-  for (auto &l : ctx->lane) if (l) (void)hipStreamDestroy(l);
+  for (auto &l : ctx->pool) if (l) (void)hipStreamDestroy(l);
+  for (auto &e : ctx->tune_ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : ctx->ev_img) if (e) (void)hipEventDestroy(e);
   for (auto &e : ctx->ev_tail) if (e) (void)hipEventDestroy(e);
   if (ctx->lane_in) (void)hipEventDestroy(ctx->lane_in);
@@ -221,21 +236,13 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "raster_split")) ctx->opt_raster_split = value < 0 || value > 2 ? 0 : value;
   else if (!strcmp(name, "raster_rec4")) ctx->opt_raster_rec4 = value < 0 ? -1 : value != 0;
   else if (!strcmp(name, "beta_waves")) ctx->opt_beta_waves = value == 8 ? 8 : 4;
-  else if (!strcmp(name, "pipe_mode")) {
-    int rc = tsdr::pipe_drain(ctx);
+  else if (!strcmp(name, "pipe_mode") || !strcmp(name, "pipe_lanes") || !strcmp(name, "pipe_priority") || !strcmp(name, "pipe_tune")) {
+    int rc = tsdr::pipe_drain(ctx);   // (the next submission sees another arrangement and runs the lanes empty itself)
     if (rc) return rc;
-    ctx->opt_pipe_mode = value < 0 ? -1 : value != 0;
-  }
-  else if (!strcmp(name, "pipe_lanes")) {
-    int rc = tsdr::pipe_drain(ctx);
-    if (rc) return rc;
-    tsdr::pipe_sync_lanes(ctx);
-    ctx->pipe_sym_now = -1;   // (the slot rotation restarts)
-    ctx->opt_pipe_lanes = value == 3 ? 3 : 2;
-  }
-  else if (!strcmp(name, "pipe_priority")) {   // takes effect when the pipeline's streams are created (first submission)
-    if (ctx->lane[2]) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_priority must be set before the first tsdr_frames_submit_d with rasters");
-    ctx->opt_pipe_priority = value != 0;
+    if (name[5] == 'm') ctx->opt_pipe_mode = value < 0 ? -1 : value > 2 ? 2 : value;
+    else if (name[5] == 'l') ctx->opt_pipe_lanes = value == 3 ? 3 : 2;
+    else if (name[5] == 'p') ctx->opt_pipe_priority = value != 0;
+    else { ctx->opt_pipe_tune = value != 0; ctx->tune = tsdr_ctx::PipeTune{}; }   // (setting it also discards what was measured)
   }
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");

@@ -1118,13 +1118,10 @@ static const Mix3Entry *welch3_lookup(unsigned R, bool accumulator) {
 }
 // kernels above 64 KiB of dynamic LDS have to be opted in once
 static int mix3_prepare(tsdr_ctx *ctx, const Mix3Entry *e) {
-  static std::mutex mu;
-  static std::unordered_map<const void *, bool> done;
-  std::lock_guard<std::mutex> g(mu);
   for (mix3_fn f : {e->strided, e->last, e->acc, e->wf, e->rows}) {
-    if (!f || done.count((const void *)f)) continue;
-    TSDR_HIP(ctx, hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds));
-    done[(const void *)f] = true;
+    if (!f) continue;
+    int rc = lds_opt_in(ctx, (const void *)f, e->lds);
+    if (rc) return rc;
   }
   return TSDR_OK;
 }
@@ -1660,13 +1657,8 @@ int fft_rows_welch(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, si
   }
   const size_t lds = mix_lds(d.R, d.logT);
   if (lds > 64 * 1024) {  // (4096-point tiles + tables: above what a kernel gets without opting in)
-    static std::mutex mu;
-    static size_t opted = 0;
-    std::lock_guard<std::mutex> g(mu);
-    if (lds > opted) {
-      TSDR_HIP(ctx, hipFuncSetAttribute((const void *)k_fft_mix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      opted = lds;
-    }
+    int rco = lds_opt_in(ctx, (const void *)k_fft_mix, lds);
+    if (rco) return rco;
   }
   const unsigned ntiles = (unsigned)ceil_div(nbSeg, (size_t)1 << d.logT);
   const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(3, (size_t)(150 * 1024) / lds));
@@ -1809,15 +1801,8 @@ int fft_mixed_autocorr(tsdr_ctx *ctx, const float2 *x, int src_mode, size_t src_
   if (rc) return rc;
   if (me->RA == 0) {  // three-step kernel
     const size_t lds = me->lds3;
-    static std::mutex mu;
-    static std::unordered_map<const void *, bool> done;
-    {
-      std::lock_guard<std::mutex> g(mu);
-      if (!done.count((const void *)me->fn)) {
-        TSDR_HIP(ctx, hipFuncSetAttribute((const void *)me->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done[(const void *)me->fn] = true;
-      }
-    }
+    rc = lds_opt_in(ctx, (const void *)me->fn, lds);
+    if (rc) return rc;
     const unsigned grid = (unsigned)ceil_div((size_t)m.ndir, (size_t)Th);
     TSDR_LAUNCH(ctx, "fftm_mid", me->fn, dim3(grid), dim3(me->nt), lds, (const float2 *)w, Zbuf, m);
   } else {

@@ -9,6 +9,9 @@
 // The two sequential couplings of the reference loop -- s_y lags one vsync call, and the IIR
 // recurrence -- are resolved inside shift_iir/sync_publish, so everything upstream is parallel
 // over frames.  No host synchronisation happens in the _d entry point.
+#include <algorithm>
+#include <string>
+
 #include "common.h"
 #include "guard.h"
 #include "sync_layout.h"
@@ -229,25 +232,30 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
 // ---- the same body pipelined across successive buffers ----------------------------------------------------------
 // Half of a buffer's sequence is a latency-bound tail (vsync statistics, sync guard, shift + IIR: chains of LDS and L2
 // latencies that leave most of the machine idle) behind one throughput-bound launch (raster / images).  Two independent
-// capture streams on one GPU fill each other's gaps (round 3: +29 % raster-free, +7 % with rasters); the same overlap is
-// available to ONE capture stream, because everything that couples successive buffers -- the lagged s_y, the IIR
-// recurrence -- sits in shift + IIR.  Two arrangements on internal HIP streams ("lanes"), chosen per submission by whether
-// rasters are written (option "pipe_mode"; measurements: DESIGN.md section 4):
+// capture streams on one GPU fill each other's gaps; the same overlap is available to ONE capture stream, because
+// everything that couples successive buffers -- the lagged s_y, the IIR recurrence -- sits in shift + IIR.  Two kinds of
+// arrangement on internal HIP streams ("lanes"):
 //
-//  A (with rasters)   image lane:  R(k)      R(k+1)            R(k+2)  ...          back to back
-//                     tail lane :       [R(k) done] B(k) G(k) C(k)  [R(k+1) done] B(k+1) ...
-//    The tail lane has the highest stream priority: its few, short-lived workgroups take the slots the image kernel's
-//    workgroups free instead of queueing behind thousands of them.  Hand-overs: one event per buffer from the image lane to
-//    the tail lane (its latency delays the tail, which has the slack, never the image lane), and one from the tail of
-//    submission k to the image launch of submission k+3, which reuses its image / key / projection slot -- long satisfied
-//    when it is reached.  The shift + IIR launches are in stream order on the tail lane.
+//  A  image lane:  R(k)      R(k+1)            R(k+2)  ...          back to back
+//     tail lane :       [R(k) done] B(k) G(k) C(k)  [R(k+1) done] B(k+1) ...
+//    Hand-overs: one event per buffer from the image lane to the tail lane (its latency delays the tail, which has the
+//    slack, never the image lane), and one from the tail of submission k to the image launch of submission k+3, which reuses
+//    its image / key / projection slot -- long satisfied when it is reached.  shift + IIR in stream order on the tail lane.
 //
-//  B (raster-free)    lane 0:  R(k)   B(k)   G(k)   [C(k-1) done] C(k)      R(k+2) ...
-//                     lane 1:      R(k+1) B(k+1) G(k+1)       [C(k) done] C(k+1)     ...
-//    Whole buffers alternate between equal lanes; only shift + IIR waits, through an event, for the previous buffer's on the
-//    other lane.  Two raster-free image launches overlap each other well (one's staging under the other's pixel loop); two
-//    raster launches do not (both held by the store stream), which is why A serves them.  The statistics of two buffers may
-//    run side by side here: beta matrices, guard queue words and workspaces exist per lane.
+//  B  lane 0:  R(k)   B(k)   G(k)   [C(k-1) done] C(k)      R(k+2) ...
+//     lane 1:      R(k+1) B(k+1) G(k+1)       [C(k) done] C(k+1)     ...
+//    Whole buffers rotate over nl equal lanes; only shift + IIR waits, through an event, for the previous buffer's on another
+//    lane.  beta matrices, guard queue words and workspaces exist per lane.  nl = 1 is the sequential order.
+//
+// WHICH arrangement on WHICH streams is measured (round 5).  Rounds 3-4 chose by geometry -- A on a high-priority tail stream
+// with rasters (+6-8 % on the builder's boxes), B without (+13 %) -- and the driver's box then measured A 2 % BELOW one call
+// per buffer.  The cause is not the box: how two streams of a process overlap depends on the hardware queues HIP mapped them
+// to, i.e. on how many streams the process had created before (tools/r05_queue_probe.sh: the same code with 5 idle streams
+// created first runs A at 0.269 instead of 0.151 ms per buffer, with 1 runs B at 0.095 instead of 0.076).  So, like the
+// reference's own FFTW.PATIENT plans (Resampler.jl:31,39), the pipeline measures: the first submissions of a configuration
+// run kTrial buffers through each candidate of kCands -- results are identical in every arrangement -- timing the interval
+// between the tails of successive buffers with HIP events, then settle on the fastest (the sequential order among them, so a
+// process in which nothing overlaps falls back to it by itself).  tsdr_frames_pipeline_info reports the measurements.
 //
 // The caller's inputs are ordered through the context's stream: a submission waits for whatever that stream holds at
 // the time of the call (nothing when it is idle, the steady state), and tsdr_frames_flush orders the context's stream
@@ -257,24 +265,34 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
 }  // extern "C"
 
 namespace tsdr {
-// lanes: [0], [1] (and [3] with "pipe_lanes" = 3) normal priority -- the symmetric mode's equal lanes, [0] also the
-// asymmetric mode's image lane; [2] highest priority -- the asymmetric mode's tail lane.  Created when first used.
-static int lane_get(tsdr_ctx *ctx, int i) {
-  if (!ctx->lane_in) {
-    for (int k = 0; k < tsdr_ctx::kPipeSlots; ++k) {
-      TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[k], hipEventDisableTiming));
-      TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[k], hipEventDisableTiming));
-    }
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
+struct PipeCand { const char *name; int sym, nl, s[3]; };
+// sym: whole buffers rotate over nl equal lanes pool[s[0 .. nl)]; !sym: image lane pool[s[0]], tail lane pool[s[1]].
+// pool[0 .. kPoolN) are normal-priority streams, pool[kPoolN ..) streams of the highest priority.
+static const PipeCand kCands[tsdr_ctx::kTuneCands] = {
+    {"one stream (sequential order)", 1, 1, {0, 0, 0}},
+    {"image lane + high-priority tail lane", 0, 2, {0, tsdr_ctx::kPoolN, 0}},
+    {"image lane + tail lane", 0, 2, {2, 3, 0}},
+    {"image lane + high-priority tail lane (other streams)", 0, 2, {4, tsdr_ctx::kPoolN + 1, 0}},
+    {"two equal lanes", 1, 2, {0, 1, 0}},
+    {"two equal lanes (other streams)", 1, 2, {2, 3, 0}},
+    {"two equal lanes (third pair)", 1, 2, {4, 5, 0}},
+    {"three equal lanes", 1, 3, {0, 1, 2}},
+};
+
+static int pipe_init(tsdr_ctx *ctx) {
+  if (ctx->lane_in) return TSDR_OK;
+  for (int k = 0; k < tsdr_ctx::kPipeSlots; ++k) {
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[k], hipEventDisableTiming));
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[k], hipEventDisableTiming));
   }
-  if (ctx->lane[i]) return TSDR_OK;
-  if (i == 2 && ctx->opt_pipe_priority) {
-    int lo = 0, hi = 0;
-    TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically: hi <= lo)
-    TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->lane[i], hipStreamNonBlocking, hi));
-  } else {
-    TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
+  for (auto &e : ctx->tune_ev) TSDR_HIP(ctx, hipEventCreate(&e));
+  int lo = 0, hi = 0;
+  TSDR_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));   // (numerically: hi <= lo)
+  for (int i = 0; i < tsdr_ctx::kPoolN + tsdr_ctx::kPoolH; ++i) {
+    if (i < tsdr_ctx::kPoolN) TSDR_HIP(ctx, hipStreamCreateWithFlags(&ctx->pool[i], hipStreamNonBlocking));
+    else TSDR_HIP(ctx, hipStreamCreateWithPriority(&ctx->pool[i], hipStreamNonBlocking, hi));
   }
+  TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_in, hipEventDisableTiming));
   return TSDR_OK;
 }
 
@@ -283,15 +301,50 @@ static int lane_get(tsdr_ctx *ctx, int i) {
 // calls this first.
 int pipe_drain(tsdr_ctx *ctx) {
   if (!ctx || ctx->pipe_n == 0) return TSDR_OK;
-  // the tails run in submission order on one stream: the latest one is behind everything else
+  // the tails run in submission order (stream order or chained by events): the latest one is behind everything else
   if (ctx->pipe_last_slot >= 0) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->pipe_last_slot], 0));
   ctx->pipe_n = 0;
   return TSDR_OK;
 }
 
-// host-side wait for both lanes (workspace reallocation, destruction)
+// host-side wait for the lanes (workspace reallocation, destruction, a change of arrangement)
 void pipe_sync_lanes(tsdr_ctx *ctx) {
-  for (auto l : ctx->lane) if (l) (void)hipStreamSynchronize(l);
+  for (auto l : ctx->pool) if (l) (void)hipStreamSynchronize(l);
+}
+
+// the arrangement of this submission: forced ("pipe_mode" >= 0), the geometry rule of rounds 3-4 ("pipe_tune" = 0), or the
+// measured one.  May run the pipeline empty (a trial boundary).  Returns an index into kCands, or a negative status.
+static int pipe_pick(tsdr_ctx *ctx, const tsdr_ctx::PipeKey &key) {
+  if (ctx->opt_pipe_mode == 0) return ctx->opt_pipe_priority ? 1 : 2;
+  if (ctx->opt_pipe_mode == 1) return ctx->opt_pipe_lanes == 3 ? 7 : 4;
+  if (ctx->opt_pipe_mode == 2) return 0;
+  if (!ctx->opt_pipe_tune) return key.raster ? 1 : 4;
+  tsdr_ctx::PipeTune &t = ctx->tune;
+  if (t.state == 0 || !(t.key == key)) {   // a new configuration: measure again
+    t = tsdr_ctx::PipeTune{};
+    t.key = key;
+    t.state = 1;
+  }
+  if (t.state == 1 && t.pos == tsdr_ctx::kTrial) {   // this arrangement's trial is complete
+    int rc = pipe_drain(ctx);
+    if (rc) return rc;
+    pipe_sync_lanes(ctx);
+    // mean interval between the tails of successive buffers over a whole number of lane rotations (12 intervals: with two or
+    // three lanes the tails complete in bursts, so a median of single intervals says nothing), after 3 buffers of ramp-up
+    float ms = 0.f;
+    const bool okev = hipEventElapsedTime(&ms, ctx->tune_ev[2], ctx->tune_ev[tsdr_ctx::kTrial - 1]) == hipSuccess;
+    (void)hipGetLastError();
+    t.ms[t.cand] = okev ? ms / (float)(tsdr_ctx::kTrial - 3) : 1e30f;
+    t.pos = 0;
+    if (++t.cand == tsdr_ctx::kTuneCands) {
+      int best = 0;
+      for (int c = 1; c < tsdr_ctx::kTuneCands; ++c) if (t.ms[c] < t.ms[best]) best = c;
+      // the sequential order unless something beats it by more than the measurement's noise
+      t.chosen = t.ms[best] < 0.985f * t.ms[0] ? best : 0;
+      t.state = 2;
+    }
+  }
+  return t.state == 2 ? t.chosen : t.cand;
 }
 
 // A submission that fails half-way has launches on the lanes that no later drain would order (pipe_n is not advanced):
@@ -325,24 +378,33 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   const int F = (int)nb;
   const size_t npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W;
   constexpr int NS = tsdr_ctx::kPipeSlots;
-  // Which arrangement: "pipe_mode" 0 = image lane + tail lane, 1 = equal lanes, -1 (default) = by what was measured on
-  // C2: with rasters the store-bound image launch leaves no room beside itself for a second one, and
-  // the tail lane hides the tail (182 k vs 171 k frames/s); without rasters two whole buffers side by side overlap
-  // better than image launch + tail (390 k vs 359 k)
-  const bool sym = ctx->opt_pipe_mode < 0 ? raster_out == nullptr : ctx->opt_pipe_mode != 0;
-  const int nl = ctx->opt_pipe_lanes == 3 ? 3 : 2;
-  // The image slots sit nb frames apart, so a submission whose frame count differs from the one in flight (S or nEch
-  // changed: GUI.jl's FLAG_CONFIG_UPDATE) would lay its slot over images a tail still has to read: the pipeline runs
-  // empty first (a configuration change, not a steady-state event).
-  if (ctx->pipe_nb != nb || ctx->pipe_sym_now != (sym ? 1 : 0)) {   // (a change of arrangement likewise)
+  rc = pipe_init(ctx);
+  if (rc) return rc;
+  tsdr_ctx::PipeKey key;
+  key.nb = nb; key.S = S; key.y_t = y_t; key.x_t = x_t; key.raster = raster_out ? 1 : 0; key.prec = ctx->precision;
+  key.align = do_align ? 1 : 0; key.sync = (const void *)sync;
+  const int cand = pipe_pick(ctx, key);
+  if (cand < 0) return cand;
+  const PipeCand &pc = kCands[cand];
+  const bool sym = pc.sym != 0;
+  const int nl = pc.nl;
+  // The image slots sit nb frames apart, the projection-sum and guard-record slots are laid out by the tile plan of the
+  // geometry and by the SyncXY object's block counts, and the lanes are the arrangement's: a submission that changes any of
+  // these (GUI.jl's FLAG_CONFIG_UPDATE, its y_t / x_t corrections, a trial boundary of the measurement) would compute slot
+  // offsets that overlap what an in-flight tail on another lane still reads -- the pipeline runs empty first (a
+  // configuration change, not a steady-state event).
+  if (!(ctx->pipe_key == key) || ctx->pipe_cand_now != cand) {
     rc = pipe_drain(ctx);
     if (rc) return rc;
     pipe_sync_lanes(ctx);
     for (bool &u : ctx->ev_tail_used) u = false;
     ctx->pipe_seq = 0;
+    ctx->pipe_last_slot = -1;
+    if (sym) { ctx->lane[0] = ctx->pool[pc.s[0]]; ctx->lane[1] = ctx->pool[pc.s[1]]; ctx->lane[3] = ctx->pool[pc.s[2]]; }
+    else { ctx->lane[0] = ctx->pool[pc.s[0]]; ctx->lane[2] = ctx->pool[pc.s[1]]; }
   }
-  ctx->pipe_nb = nb;
-  ctx->pipe_sym_now = sym ? 1 : 0;
+  ctx->pipe_key = key;
+  ctx->pipe_cand_now = cand;
   // symmetric: whole buffers alternate between nl equal lanes; slot = position in the rotation
   const int slot = (int)(ctx->pipe_seq % (unsigned long long)(sym ? nl : NS));
   // (workspaces first: growing one synchronises and frees what the lanes may be using)
@@ -365,14 +427,14 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     rc = sync_workspace(sync, F, slot, NS, plan.ncp ? &plan : nullptr, &proj, nullptr);
     if (rc) return rc;
   }
+  hipStream_t tail_stream = nullptr;
   if (sym) {
     // R(k) B(k) G(k) [shift + IIR of the previous buffer done] C(k), all on lane `slot`: a lane's next buffer is stream-ordered
     // behind its previous one, and the only cross-lane dependency is the chain of shift + IIR launches (lagged s_y, IIR state)
     const int li = slot == 2 ? 3 : slot;
-    rc = lane_get(ctx, li);
-    if (rc) return rc;
     LaneScope lane_scope(ctx, li);
     hipStream_t st = ctx->lane[li];
+    tail_stream = st;
     if (hipStreamQuery(ctx->stream) != hipSuccess) {
       (void)hipGetLastError();
       TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
@@ -400,9 +462,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     if (rc) return rc;
     TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
   } else {
-    rc = lane_get(ctx, 0);
-    if (!rc) rc = lane_get(ctx, 2);
-    if (rc) return rc;
+    tail_stream = ctx->lane[2];
     {
       LaneScope image_lane(ctx, 0);
       // inputs: whatever the context's stream holds now (uploads, a producer's kernels, an earlier call's launches) comes
@@ -414,6 +474,10 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
       }
       // this slot's previous user: submission k - NS, whose tail read its images / keys / sums
       if (ctx->ev_tail_used[slot]) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->lane[0], ctx->ev_tail[slot], 0));
+      if (do_align) {   // (one beta set serves: the statistics run in stream order on the tail lane)
+        rc = sync_use_lane(sync, 0);
+        if (rc) return rc;
+      }
       rc = raster_and_down_d(ctx, iq, 1, S, S, y_t, x_t, TSDR_RENDER_H, TSDR_RENDER_W, F, raster_out, (size_t)y_t * x_t, img, npx, proj,
                              &got, false, keys);
       if (rc) return rc;
@@ -437,11 +501,34 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
       TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
     }
   }
+  if (ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune && ctx->tune.state == 1 && ctx->tune.pos < tsdr_ctx::kTrial)
+    TSDR_HIP(ctx, hipEventRecord(ctx->tune_ev[ctx->tune.pos++], tail_stream));
   ctx->ev_tail_used[slot] = true;
   ctx->pipe_last_slot = slot;
   ++ctx->pipe_seq;
   ++ctx->pipe_n;
   submitted.ok = true;
+  return TSDR_OK;
+}
+
+int tsdr_frames_pipeline_info(tsdr_ctx *ctx, int *trials_left, int *chosen, float *ms_per_buffer, int cap, char *text, size_t text_cap) {
+  if (!ctx || cap < 0 || (cap && !ms_per_buffer)) return TSDR_EINVAL;
+  const tsdr_ctx::PipeTune &t = ctx->tune;
+  const bool measured = ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune;
+  if (trials_left) *trials_left = !measured ? 0 : t.state == 2 ? 0 : t.state == 1 ? tsdr_ctx::kTuneCands - t.cand : tsdr_ctx::kTuneCands;
+  if (chosen) *chosen = measured ? (t.state == 2 ? t.chosen : -1) : ctx->pipe_cand_now;
+  for (int c = 0; c < cap && c < tsdr_ctx::kTuneCands; ++c) ms_per_buffer[c] = measured && (t.state == 2 || c < t.cand) ? t.ms[c] : 0.f;
+  if (text && text_cap) {
+    std::string s;
+    if (!measured) s = std::string("forced: ") + (ctx->pipe_cand_now >= 0 ? kCands[ctx->pipe_cand_now].name : "nothing submitted yet");
+    else if (t.state != 2) s = "measuring";
+    else {
+      s = std::string("measured: ") + kCands[t.chosen].name + " |";
+      char b[96];
+      for (int c = 0; c < tsdr_ctx::kTuneCands; ++c) { snprintf(b, sizeof b, " [%d] %s %.4f ms;", c, kCands[c].name, (double)t.ms[c]); s += b; }
+    }
+    snprintf(text, text_cap, "%s", s.c_str());
+  }
   return TSDR_OK;
 }
 

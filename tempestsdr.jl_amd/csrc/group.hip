@@ -1,0 +1,439 @@
+// group.hip -- one process, several MI355X: the multi-GPU split of SURVEY.md 8e behind the C ABI.
+//
+// The reference runtime is ONE process (GUI.jl:380-382: a producer task, a consumer task, the GUI task).  A tsdr_group is
+// what such a process holds to use every GPU of the node: one tsdr_ctx per device, one RCCL communicator per device
+// (ncclCommInitAll: single-process ranks over xGMI), and one host thread that drives them -- every per-device stage below
+// only enqueues, so the devices run side by side.
+//
+//   tsdr_group_search   extract_configuration's inner step (GUI.jl:73-81).  The circular autocorrelation
+//                       r[k] = sum_m x[m] x[(m+k) mod n] (Autocorrelations.jl:27-29) is a sum over m: device g receives
+//                       ITS range of m plus a halo of indexMax samples (H2D of that slice only), computes the partial
+//                       sums (tsdr_autocorr_partial_d), ONE ncclAllReduce(sum, f32, indexMax) adds them over xGMI, and only
+//                       then the non-linear step -- 10log10(abs2) (:33) and findmax (GUI.jl:79) -- runs, on the root device.
+//   tsdr_group_frames   the loop body GUI.jl:163-178 for one received buffer: frames are independent through sig_to_image /
+//                       downgradeImage / the vsync statistics, so device g scans its contiguous range of frames
+//                       (tsdr_frames_scan_d); the 600x800 images and two argmax keys per frame are gathered to the rendering
+//                       device (ncclSend / ncclRecv), which resolves the two sequential couplings -- the lagged s_y and the
+//                       IIR recurrence -- over all frames in order (tsdr_frames_combine_d).  Rasters, when wanted, go from
+//                       each device straight to the caller's host array.
+//   tsdr_group_welch    getWelch (GetSpectrum.jl:36-52): the sum of abs2.(fft(seg)) over segments is a sum -- device g
+//                       accumulates its range of segments, ONE all-reduce of sizeFFT f32, 10log10 after it.
+//
+// Per-frame / per-lag arithmetic is the single-context library's, unchanged: a group of one device returns the
+// single-context results bit for bit (tests/test_group_gpu.py); N > 1 differs only by the f32 order of the partial sums.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+struct tsdr_sync;
+
+namespace tsdr {
+int autocorr_args(tsdr_ctx *ctx, size_t len, double Fs, double minDelay, double maxDelay, size_t *n, size_t *k0, size_t *cnt);
+}
+
+struct tsdr_group {
+  int n = 0;
+  std::vector<int> dev;
+  std::vector<tsdr_ctx *> ctx;
+  std::vector<ncclComm_t> comm;
+  std::vector<tsdr_sync *> sync;   // one 600x800 SyncXY per member (scan workspaces); the root's carries the lagged s_y
+  std::vector<hipEvent_t> ev;      // per member: "this stage is enqueued up to here"
+  hipEvent_t t[4] = {};            // root stream: stage boundaries of the last call
+  std::string err;
+  double stage_ms[3] = {0, 0, 0};
+  int last_route = 0;
+};
+
+namespace {
+
+using namespace tsdr;
+
+int gerr(tsdr_group *g, int status, const std::string &what) {
+  if (g) g->err = what;
+  (void)hipGetLastError();
+  return status;
+}
+
+int member_err(tsdr_group *g, int i, int rc, const char *what) {
+  return gerr(g, rc, std::string(what) + " on device " + std::to_string(g->dev[i]) + ": " + tsdr_last_error(g->ctx[i]));
+}
+
+#define G_HIP(g, call)                                                                                          \
+  do {                                                                                                          \
+    hipError_t _e = (call);                                                                                     \
+    if (_e != hipSuccess) return gerr((g), TSDR_EHIP, std::string(#call) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+#define G_NCCL(g, call)                                                                                         \
+  do {                                                                                                          \
+    ncclResult_t _r = (call);                                                                                   \
+    if (_r != ncclSuccess) return gerr((g), TSDR_EHIP, std::string(#call) + ": " + ncclGetErrorString(_r));     \
+  } while (0)
+
+// contiguous, near-equal split of range(n) over `world` members (parallel.py:shard_range)
+void shard_range(size_t n, int world, int rank, size_t *start, size_t *count) {
+  const size_t base = n / (size_t)world, rem = n % (size_t)world;
+  *start = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
+  *count = base + ((size_t)rank < rem ? 1 : 0);
+}
+
+size_t pow2_at_least(size_t v) { size_t p = 1; while (p < v) p <<= 1; return p; }
+bool smooth235(size_t v) {
+  for (size_t f : {2, 3, 5}) while (v > 1 && v % f == 0) v /= f;
+  return v == 1;
+}
+// complex points per transform: the single-context route for n samples / the segment + halo cross-correlation of one member
+size_t single_points(size_t n) { return (n % 2 == 0 && n > 1024 && smooth235(n / 2)) ? n / 2 : pow2_at_least(2 * n) / 2; }
+size_t sharded_points(size_t n, size_t n_lags, int world) { return pow2_at_least((n + world - 1) / world + n_lags - 1); }
+
+__global__ __launch_bounds__(256) void k_db(float *__restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = 10.0f * log10f(y[i]);
+}
+
+int sync_all(tsdr_group *g) {
+  for (int i = 0; i < g->n; ++i) {
+    G_HIP(g, hipSetDevice(g->dev[i]));
+    G_HIP(g, hipStreamSynchronize(g->ctx[i]->stream));
+  }
+  return TSDR_OK;
+}
+
+int ensure_syncs(tsdr_group *g) {
+  for (int i = 0; i < g->n; ++i) {
+    if (g->sync[i]) continue;
+    G_HIP(g, hipSetDevice(g->dev[i]));
+    int rc = tsdr_sync_create(g->ctx[i], TSDR_RENDER_H, TSDR_RENDER_W, &g->sync[i]);
+    if (rc) return member_err(g, i, rc, "SyncXY");
+  }
+  return TSDR_OK;
+}
+
+void stage_times(tsdr_group *g) {
+  for (int k = 0; k < 3; ++k) {
+    float ms = 0.f;
+    g->stage_ms[k] = hipEventElapsedTime(&ms, g->t[k], g->t[k + 1]) == hipSuccess ? (double)ms : 0.0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsdr_group_create(const int *devices, int n, tsdr_group **out) {
+  if (!out) return TSDR_EINVAL;
+  *out = nullptr;
+  if (n <= 0 || n > 64) return TSDR_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TSDR_ENODEV;
+  tsdr_group *g = new tsdr_group();
+  g->n = n;
+  for (int i = 0; i < n; ++i) {
+    const int d = devices ? devices[i] : i;
+    if (d < 0 || d >= ndev || std::find(g->dev.begin(), g->dev.end(), d) != g->dev.end()) { delete g; return TSDR_EINVAL; }
+    g->dev.push_back(d);
+  }
+  g->ctx.assign(n, nullptr); g->sync.assign(n, nullptr); g->ev.assign(n, nullptr);
+  g->comm.assign(n, nullptr);
+  bool ok = true;
+  for (int i = 0; i < n && ok; ++i) {
+    g->ctx[i] = tsdr_create(g->dev[i]);   // (makes its device current)
+    ok = g->ctx[i] != nullptr && hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) == hipSuccess;
+  }
+  // single-process ranks: rank i = member i on devices[i]; the collectives below run inside ncclGroupStart / End
+  if (ok) ok = ncclCommInitAll(g->comm.data(), n, g->dev.data()) == ncclSuccess;
+  if (ok) ok = hipSetDevice(g->dev[0]) == hipSuccess;
+  for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreate(&g->t[k]) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    for (auto &c : g->comm) c = c ? (ncclCommDestroy(c), nullptr) : nullptr;
+    for (int i = 0; i < n; ++i) {
+      if (g->ev[i]) { (void)hipSetDevice(g->dev[i]); (void)hipEventDestroy(g->ev[i]); }
+      if (g->ctx[i]) tsdr_destroy(g->ctx[i]);
+    }
+    for (auto e : g->t) if (e) (void)hipEventDestroy(e);
+    delete g;
+    return TSDR_EHIP;
+  }
+  *out = g;
+  return TSDR_OK;
+}
+
+void tsdr_group_destroy(tsdr_group *g) {
+  if (!g) return;
+  for (int i = 0; i < g->n; ++i) {
+    (void)hipSetDevice(g->dev[i]);
+    (void)tsdr_synchronize(g->ctx[i]);
+  }
+  for (auto c : g->comm) if (c) (void)ncclCommDestroy(c);
+  (void)hipSetDevice(g->dev[0]);
+  for (auto e : g->t) if (e) (void)hipEventDestroy(e);
+  for (int i = 0; i < g->n; ++i) {
+    (void)hipSetDevice(g->dev[i]);
+    if (g->sync[i]) tsdr_sync_free(g->sync[i]);
+    if (g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+    tsdr_destroy(g->ctx[i]);
+  }
+  delete g;
+}
+
+int tsdr_group_size(const tsdr_group *g) { return g ? g->n : TSDR_EINVAL; }
+tsdr_ctx *tsdr_group_ctx(tsdr_group *g, int i) { return (g && i >= 0 && i < g->n) ? g->ctx[i] : nullptr; }
+const char *tsdr_group_last_error(tsdr_group *g) { return g ? g->err.c_str() : "null group"; }
+
+int tsdr_group_set_precision(tsdr_group *g, int mode) {
+  if (!g) return TSDR_EINVAL;
+  for (int i = 0; i < g->n; ++i) {
+    int rc = tsdr_set_precision(g->ctx[i], mode);
+    if (rc) return member_err(g, i, rc, "set_precision");
+  }
+  return TSDR_OK;
+}
+
+int tsdr_group_set_option(tsdr_group *g, const char *name, int value) {
+  if (!g) return TSDR_EINVAL;
+  for (int i = 0; i < g->n; ++i) {
+    int rc = tsdr_set_option(g->ctx[i], name, value);
+    if (rc) return member_err(g, i, rc, "set_option");
+  }
+  return TSDR_OK;
+}
+
+int tsdr_group_sync_reset(tsdr_group *g) {
+  if (!g) return TSDR_EINVAL;
+  for (int i = 0; i < g->n; ++i) {
+    if (!g->sync[i]) continue;
+    G_HIP(g, hipSetDevice(g->dev[i]));
+    int rc = tsdr_sync_reset(g->sync[i]);
+    if (rc) return member_err(g, i, rc, "sync_reset");
+  }
+  return TSDR_OK;
+}
+
+int tsdr_group_timing(tsdr_group *g, int *route, double ms[3]) {
+  if (!g) return TSDR_EINVAL;
+  if (route) *route = g->last_route;
+  if (ms) for (int k = 0; k < 3; ++k) ms[k] = g->stage_ms[k];
+  return TSDR_OK;
+}
+
+int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, double Fs, double minDelay, double maxDelay,
+                      int log_scale, float *out, size_t *n_out, size_t win_lo, size_t win_cnt, size_t *idx, float *val,
+                      int route) {
+  if (!g || !x || !idx || route < 0 || route > 2) return TSDR_EINVAL;
+  const int N = g->n;
+  tsdr_ctx *c0 = g->ctx[0];
+  size_t n, k0, cnt;
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  int rc = autocorr_args(c0, len, Fs, minDelay, maxDelay, &n, &k0, &cnt);
+  if (rc) return member_err(g, 0, rc, "group_search");
+  if (n_out) *n_out = cnt;
+  if (win_cnt == 0 || win_lo >= cnt || win_cnt > cnt - win_lo) return gerr(g, TSDR_EBOUNDS, "group_search: window outside the lag vector");
+  const size_t n_lags = k0 + cnt;   // = indexMax
+  const size_t esz = is_iq ? 8 : 4;
+  // "sharded" when asked for, or (auto) when a member's segment + halo transform is smaller than the one a single device
+  // runs: the halo puts a floor of indexMax points under every member's transform, so with the reference's own window
+  // (n = 2 indexMax, Autocorrelations.jl:27) one device is the faster route and the group says so (tsdr_group_timing)
+  bool sharded = route == 1;
+  if (route == 0 && N > 1) {
+    const size_t one = n <= 2 * n_lags ? single_points(n) : pow2_at_least(n + n_lags - 1);
+    sharded = sharded_points(n, n_lags, N) < one;
+  }
+  g->last_route = sharded ? 1 : 2;
+  G_HIP(g, hipEventRecord(g->t[0], c0->stream));
+  if (!sharded && n <= 2 * n_lags) {  // the single-context search on the root device
+    float *dx = (float *)c0->scratch(WS_IN, n * esz);
+    float *dout = (float *)c0->scratch(WS_OUT, cnt * 4);
+    if (!dx || !dout) return member_err(g, 0, TSDR_ENOMEM, "group_search");
+    G_HIP(g, hipMemcpyAsync(dx, x, n * esz, hipMemcpyHostToDevice, c0->stream));
+    G_HIP(g, hipEventRecord(g->t[1], c0->stream));
+    G_HIP(g, hipEventRecord(g->t[2], c0->stream));
+    rc = tsdr_autocorr_search_d(c0, dx, is_iq, n, Fs, minDelay, maxDelay, log_scale, dout, nullptr, win_lo, win_cnt, idx, val);
+    if (rc) return member_err(g, 0, rc, "group_search");
+    G_HIP(g, hipEventRecord(g->t[3], c0->stream));
+    if (out) G_HIP(g, hipMemcpyAsync(out, dout, cnt * 4, hipMemcpyDeviceToHost, c0->stream));
+    G_HIP(g, hipStreamSynchronize(c0->stream));
+    stage_times(g);
+    return TSDR_OK;
+  }
+  // stage 1, per member: H2D of its range of m plus the halo (wrapping at n), partial sums over that range
+  const int world = sharded ? N : 1;
+  std::vector<float *> part(world, nullptr);
+  for (int i = 0; i < world; ++i) {
+    tsdr_ctx *c = g->ctx[i];
+    G_HIP(g, hipSetDevice(g->dev[i]));
+    size_t m0, mc;
+    shard_range(n, world, i, &m0, &mc);
+    part[i] = (float *)c->scratch(WS_OUT, n_lags * 4);
+    if (!part[i]) return member_err(g, i, TSDR_ENOMEM, "group_search");
+    if (mc == 0) { G_HIP(g, hipMemsetAsync(part[i], 0, n_lags * 4, c->stream)); continue; }
+    const size_t vlen = mc + n_lags - 1;
+    char *dx = (char *)c->scratch(WS_IN, vlen * esz);
+    if (!dx) return member_err(g, i, TSDR_ENOMEM, "group_search");
+    for (size_t done = 0; done < vlen;) {   // x[(m0 + j) mod n], j < vlen: at most a few contiguous pieces
+      const size_t src = (m0 + done) % n, run = std::min(vlen - done, n - src);
+      G_HIP(g, hipMemcpyAsync(dx + done * esz, (const char *)x + src * esz, run * esz, hipMemcpyHostToDevice, c->stream));
+      done += run;
+    }
+    // the slice as a sequence of its own: sum_{m < mc} xs[m] xs[m + k], no wrap inside (m + k <= vlen - 1)
+    rc = tsdr_autocorr_partial_d(c, (const float *)dx, is_iq, vlen, 0, mc, n_lags, part[i]);
+    if (rc) return member_err(g, i, rc, "autocorr_partial");
+  }
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[1], c0->stream));
+  // stage 2: ONE all-reduce of the accumulators (linear domain) over xGMI
+  if (sharded) {
+    G_NCCL(g, ncclGroupStart());
+    for (int i = 0; i < N; ++i) {
+      ncclResult_t r = ncclAllReduce(part[i], part[i], n_lags, ncclFloat, ncclSum, g->comm[i], g->ctx[i]->stream);
+      if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+    }
+    G_NCCL(g, ncclGroupEnd());
+  }
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[2], c0->stream));
+  // stage 3, root: the non-linear step comes after the reduce -- 10log10(abs2) (:33) and findmax over the zoom window
+  float *dout = (float *)c0->scratch(WS_AUX, cnt * 4);
+  if (!dout) return member_err(g, 0, TSDR_ENOMEM, "group_search");
+  rc = tsdr_autocorr_finish_d(c0, part[0], k0, cnt, log_scale, dout);
+  if (!rc) rc = tsdr_argmax_d(c0, dout + win_lo, win_cnt, idx, val);
+  if (rc) return member_err(g, 0, rc, "group_search");
+  G_HIP(g, hipEventRecord(g->t[3], c0->stream));
+  if (out) G_HIP(g, hipMemcpyAsync(out, dout, cnt * 4, hipMemcpyDeviceToHost, c0->stream));
+  rc = sync_all(g);
+  if (rc) return rc;
+  stage_times(g);
+  return TSDR_OK;
+}
+
+int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha, int do_align,
+                      float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx, int *n_frames) {
+  if (!g || !imageOut_state || S == 0 || y_t <= 0 || x_t <= 0 || (nEch && !iq)) return TSDR_EINVAL;
+  const int N = g->n;
+  const size_t nb = nEch / S, npx = (size_t)TSDR_RENDER_H * TSDR_RENDER_W, P = (size_t)y_t * x_t;
+  if (nb > (size_t)1 << 20) return gerr(g, TSDR_EINVAL, "too many frames in one buffer");
+  if (n_frames) *n_frames = (int)nb;
+  if (nb == 0) return TSDR_OK;
+  int rc = ensure_syncs(g);
+  if (rc) return rc;
+  tsdr_ctx *c0 = g->ctx[0];
+  std::vector<float *> img(N, nullptr);
+  std::vector<unsigned long long *> keys(N, nullptr);
+  std::vector<size_t> f0(N), fc(N);
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[0], c0->stream));
+  // stage 1, per member: H2D of its frames' samples, IQ -> 600x800 image + two argmax keys per frame (+ raster -> host)
+  for (int i = 0; i < N; ++i) {
+    tsdr_ctx *c = g->ctx[i];
+    shard_range(nb, N, i, &f0[i], &fc[i]);
+    G_HIP(g, hipSetDevice(g->dev[i]));
+    // (the root's buffers hold every frame of the buffer: its own range lies where the gather puts the others')
+    const size_t hold = i == 0 ? nb : fc[i];
+    img[i] = (float *)c->scratch(WS_IMG, (hold ? hold : 1) * npx * 4);
+    keys[i] = (unsigned long long *)c->scratch(WS_KEYS, (hold ? hold : 1) * 2 * 8);
+    if (!img[i] || !keys[i]) return member_err(g, i, TSDR_ENOMEM, "group_frames");
+    if (fc[i] == 0) continue;
+    float *d_iq = (float *)c->scratch(WS_IN, fc[i] * S * 8);
+    float *d_ra = raster_out ? (float *)c->scratch(WS_FFT_A, fc[i] * P * 4) : nullptr;
+    if (!d_iq || (raster_out && !d_ra)) return member_err(g, i, TSDR_ENOMEM, "group_frames");
+    G_HIP(g, hipMemcpyAsync(d_iq, iq + 2 * f0[i] * S, fc[i] * S * 8, hipMemcpyHostToDevice, c->stream));
+    int nf = 0;
+    float *my_img = img[i] + (i == 0 ? f0[0] * npx : 0);
+    unsigned long long *my_keys = keys[i] + (i == 0 ? f0[0] * 2 : 0);
+    rc = tsdr_frames_scan_d(c, g->sync[i], d_iq, fc[i] * S, S, y_t, x_t, do_align, my_img, d_ra, do_align ? my_keys : nullptr, &nf);
+    if (rc) return member_err(g, i, rc, "frames_scan");
+    if (d_ra) G_HIP(g, hipMemcpyAsync(raster_out + f0[i] * P, d_ra, fc[i] * P * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[1], c0->stream));
+  // stage 2: gather to the rendering device (GUI.jl:177 hands the frames to ONE renderer): every other member sends its
+  // share once -- 1.92 MB + 16 B per frame
+  if (N > 1) {
+    G_NCCL(g, ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int i = 1; i < N && r == ncclSuccess; ++i) {
+      if (fc[i] == 0) continue;
+      r = ncclSend(img[i], fc[i] * npx, ncclFloat, 0, g->comm[i], g->ctx[i]->stream);
+      if (r == ncclSuccess) r = ncclRecv(img[0] + f0[i] * npx, fc[i] * npx, ncclFloat, i, g->comm[0], c0->stream);
+      if (do_align && r == ncclSuccess) r = ncclSend(keys[i], fc[i] * 2, ncclUint64, 0, g->comm[i], g->ctx[i]->stream);
+      if (do_align && r == ncclSuccess) r = ncclRecv(keys[0] + f0[i] * 2, fc[i] * 2, ncclUint64, i, g->comm[0], c0->stream);
+    }
+    if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("gather: ") + ncclGetErrorString(r)); }
+    G_NCCL(g, ncclGroupEnd());
+  }
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[2], c0->stream));
+  // stage 3, root: lagged s_y (FrameSynchronisation.jl:66) + circshift + IIR (GUI.jl:172,175) over all frames in order
+  float *d_state = (float *)c0->scratch(WS_AUX, npx * 4);
+  float *d_frames = frames_out ? (float *)c0->scratch(WS_OUT, nb * npx * 4) : nullptr;
+  int *d_idx = (sync_idx && do_align) ? (int *)c0->scratch(WS_MISC, nb * 8 + 16) : nullptr;
+  if (!d_state || (frames_out && !d_frames) || (sync_idx && do_align && !d_idx)) return member_err(g, 0, TSDR_ENOMEM, "group_frames");
+  G_HIP(g, hipMemcpyAsync(d_state, imageOut_state, npx * 4, hipMemcpyHostToDevice, c0->stream));
+  rc = tsdr_frames_combine_d(c0, g->sync[0], img[0], keys[0], (int)nb, alpha, do_align, d_state, d_frames, d_idx);
+  if (rc) return member_err(g, 0, rc, "frames_combine");
+  G_HIP(g, hipEventRecord(g->t[3], c0->stream));
+  G_HIP(g, hipMemcpyAsync(imageOut_state, d_state, npx * 4, hipMemcpyDeviceToHost, c0->stream));
+  if (d_frames) G_HIP(g, hipMemcpyAsync(frames_out, d_frames, nb * npx * 4, hipMemcpyDeviceToHost, c0->stream));
+  if (d_idx) G_HIP(g, hipMemcpyAsync(sync_idx, d_idx, nb * 8, hipMemcpyDeviceToHost, c0->stream));
+  rc = sync_all(g);
+  if (rc) return rc;
+  g->last_route = 1;
+  stage_times(g);
+  return TSDR_OK;
+}
+
+int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y) {
+  if (!g || !y || sizeFFT < 2 || (len && !sig)) return TSDR_EINVAL;
+  const int N = g->n;
+  const size_t nbSeg = len / sizeFFT, esz = is_complex ? 8 : 4;
+  tsdr_ctx *c0 = g->ctx[0];
+  if (nbSeg == 0) {  // (the single-context call defines what an empty sum returns)
+    G_HIP(g, hipSetDevice(g->dev[0]));
+    int rc = tsdr_welch(c0, sig, is_complex, len, sizeFFT, lin, y);
+    return rc ? member_err(g, 0, rc, "group_welch") : TSDR_OK;
+  }
+  std::vector<float *> part(N, nullptr);
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[0], c0->stream));
+  for (int i = 0; i < N; ++i) {
+    tsdr_ctx *c = g->ctx[i];
+    size_t s0, sc;
+    shard_range(nbSeg, N, i, &s0, &sc);
+    G_HIP(g, hipSetDevice(g->dev[i]));
+    part[i] = (float *)c->scratch(WS_OUT, sizeFFT * 4);
+    if (!part[i]) return member_err(g, i, TSDR_ENOMEM, "group_welch");
+    if (sc == 0) { G_HIP(g, hipMemsetAsync(part[i], 0, sizeFFT * 4, c->stream)); continue; }
+    char *dx = (char *)c->scratch(WS_IN, sc * sizeFFT * esz);
+    if (!dx) return member_err(g, i, TSDR_ENOMEM, "group_welch");
+    G_HIP(g, hipMemcpyAsync(dx, (const char *)sig + s0 * sizeFFT * esz, sc * sizeFFT * esz, hipMemcpyHostToDevice, c->stream));
+    int rc = tsdr_welch_d(c, (const float *)dx, is_complex, sc * sizeFFT, sizeFFT, /*lin=*/1, part[i]);   // fftshifted linear sums
+    if (rc) return member_err(g, i, rc, "welch");
+  }
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[1], c0->stream));
+  if (N > 1) {
+    G_NCCL(g, ncclGroupStart());
+    for (int i = 0; i < N; ++i) {
+      ncclResult_t r = ncclAllReduce(part[i], part[i], sizeFFT, ncclFloat, ncclSum, g->comm[i], g->ctx[i]->stream);
+      if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+    }
+    G_NCCL(g, ncclGroupEnd());
+  }
+  G_HIP(g, hipSetDevice(g->dev[0]));
+  G_HIP(g, hipEventRecord(g->t[2], c0->stream));
+  if (!lin) hipLaunchKernelGGL(k_db, dim3((unsigned)ceil_div(sizeFFT, 256)), dim3(256), 0, c0->stream, part[0], sizeFFT);
+  G_HIP(g, hipGetLastError());
+  G_HIP(g, hipEventRecord(g->t[3], c0->stream));
+  G_HIP(g, hipMemcpyAsync(y, part[0], sizeFFT * 4, hipMemcpyDeviceToHost, c0->stream));
+  int rc = sync_all(g);
+  if (rc) return rc;
+  g->last_route = N > 1 ? 1 : 2;
+  stage_times(g);
+  return TSDR_OK;
+}
+
+}  // extern "C"

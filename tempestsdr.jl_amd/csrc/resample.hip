@@ -1154,8 +1154,10 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   }
   if (plan_only) return TSDR_OK;
   // fallback: materialise each raster in workspace, then the generic 2-D resize
-  float *ras = (float *)ctx->scratch(WS_RASTER, P * 4);
+  // (one raster per pipeline lane: two submissions of tsdr_frames_submit_d may be walking this loop side by side)
+  float *ras = (float *)ctx->scratch(WS_RASTER, 4 * P * 4);
   if (!ras) return TSDR_ENOMEM;
+  ras += (size_t)(ctx->pipe_lane & 3) * P;
   for (int f = 0; f < frames; ++f) {
     rc = raster_frames_d(ctx, in + (size_t)f * in_stride * (cplx ? 2 : 1), cplx, in_stride, S, y_t, x_t, 1, ras, P);
     if (rc) return rc;

@@ -883,13 +883,8 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
     // other buffer, 0.11 instead of 0.057 ms per step.)
     const unsigned grid = g.count_only ? 1u : (unsigned)ncu;
     if (lds > 64 * 1024) {   // above what a kernel gets without opting in
-      static std::mutex mu;
-      static bool opted = false;
-      std::lock_guard<std::mutex> lk(mu);
-      if (!opted) {
-        TSDR_HIP(ctx, hipFuncSetAttribute((const void *)k_guard, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGuardLdsMax));
-        opted = true;
-      }
+      int rco = lds_opt_in(ctx, (const void *)k_guard, kGuardLdsMax);
+      if (rco) return rco;
     }
     TSDR_LAUNCH(ctx, "sync_guard", k_guard, dim3(grid), dim3(512), lds, a);
   }
@@ -1061,6 +1056,10 @@ int tsdr_sync_beta(tsdr_sync *s, int which, float *beta_host) {
   if (!s || !beta_host || (which != 0 && which != 1)) return TSDR_EINVAL;
   tsdr_ctx *ctx = s->ctx;
   const size_t n = which == 0 ? (size_t)(1 + s->wmax_x - s->wmin_x) * s->x_t : (size_t)(1 + s->wmax_y - s->wmin_y) * s->y_t;
+  {  // submitted buffers fill the beta sets on the pipeline's internal streams: they come first
+    int rc = pipe_drain(ctx);
+    if (rc) return rc;
+  }
   TSDR_HIP(ctx, hipMemcpyAsync(beta_host, which == 0 ? s->beta_x : s->beta_y, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TSDR_OK;

@@ -116,13 +116,13 @@ def test_frames_many_frames(ctx, tsdr, synth, precision):
 
 
 @pytest.mark.parametrize("want_raster", [True, False])
-@pytest.mark.parametrize("mode", [-1, 0, 1])
+@pytest.mark.parametrize("mode", [-1, 0, 1, 2])
 def test_frames_pipeline_matches_sequential(ctx, tsdr, synth, want_raster, mode):
     """tsdr_frames_submit_d / tsdr_frames_flush (the tail of a buffer in flight beside the image launch of the next, on the
     library's internal streams) must return, bit for bit, what one tsdr_frames_d call per buffer returns: same kernels,
     and the SyncXY / imageOut state threaded through the buffers.  Both arrangements ("pipe_mode" 0: image lane + tail
-    lane; 1: whole buffers on alternating equal lanes; -1: the default choice by whether rasters are written), with and
-    without rasters, five buffers so that the three slots wrap."""
+    lane; 1: whole buffers on alternating equal lanes; 2: one internal stream; -1: the measured choice, here still in its
+    first trial), with and without rasters, five buffers so that the three slots wrap."""
     from tempestsdr_jl_amd import api
     Fs, x_t, y_t, fv, nfr, nbuf = 2.0e6, 1056, 628, 60.0, 4, 5
     S = synth.samples_per_frame(Fs, fv)
@@ -161,6 +161,55 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth, want_raster, mode)
             assert np.array_equal(a[3], b[3])
     finally:
         ctx.set_option("pipe_mode", -1)
+
+
+@pytest.mark.parametrize("want_raster", [False, True])
+def test_pipeline_measured_choice_walks_every_arrangement(tsdr, synth, want_raster):
+    """"pipe_mode" -1 (the default): the first 120 submissions of a configuration go through the eight candidate arrangements,
+    fifteen buffers each, with the pipeline run empty at every trial boundary, and the rest use the one measured fastest.  Results
+    must be those of one tsdr_frames_d per buffer throughout -- bit for bit, the SyncXY / imageOut state threaded through all
+    135 buffers -- and tsdr_frames_pipeline_info must report a settled choice with every candidate timed."""
+    from tempestsdr_jl_amd import api
+    ctx = tsdr.Context(0)   # (a context of its own: the measurement is per context and configuration)
+    Fs, x_t, y_t, fv, nfr, nbuf, ndist = 2.0e6, 1056, 628, 60.0, 2, 135, 5
+    S = synth.samples_per_frame(Fs, fv)
+    P, npx = x_t * y_t, 600 * 800
+    bufs = [synth.synth_leak(Fs, x_t, y_t, fv, S * nfr, n0=b * S * nfr) for b in range(ndist)]
+
+    def run(pipelined):
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
+        d_fr = [ctx.dev_alloc(nfr * npx * 4) for _ in range(nbuf)]
+        d_ra = [ctx.dev_alloc(nfr * P * 4) if want_raster else None for _ in range(nbuf)]
+        d_ix = [ctx.dev_alloc(nfr * 8) for _ in range(nbuf)]
+        try:
+            for b in range(nbuf):
+                f = api.frames_submit_d if pipelined else api.frames_d
+                assert f(ctx, sync, d_iq[b % ndist], bufs[0].size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr[b], d_ra[b], d_ix[b]) == nfr
+            ctx.synchronize()
+            import zlib
+            return ([zlib.crc32(ctx.download(p, (nfr * npx,), np.uint32).tobytes()) for p in d_fr],
+                    [zlib.crc32(ctx.download(p, (nfr * P,), np.uint32).tobytes()) for p in d_ra] if want_raster else [],
+                    [ctx.download(p, (nfr * 2,), np.int32).tolist() for p in d_ix], ctx.download(d_state, (npx,), np.uint32))
+        finally:
+            sync.close()
+            for p in [d_state] + d_iq + d_fr + [r for r in d_ra if r is not None] + d_ix:
+                ctx.dev_free(p)
+
+    try:
+        a = run(False)
+        assert ctx.pipeline_info()["trials_left"] == 8
+        b = run(True)
+        info = ctx.pipeline_info()
+        print("\n", info["text"])
+        assert info["trials_left"] == 0 and 0 <= info["chosen"] < 8 and all(v > 0 for v in info["ms_per_buffer"])
+        # never an arrangement measured slower than the sequential order
+        assert info["ms_per_buffer"][info["chosen"]] <= info["ms_per_buffer"][0]
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        assert np.array_equal(a[3], b[3])
+    finally:
+        ctx.close()
 
 
 def test_pipeline_pending_stage_is_drained_by_other_entry_points(ctx, tsdr, synth):

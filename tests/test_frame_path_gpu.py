@@ -438,6 +438,75 @@ def test_submit_with_changing_frame_count(ctx, tsdr, synth):
     assert np.array_equal(a[2], b[2])
 
 
+def _pipeline_vs_sequential(ctx, tsdr, bufs, geoms, S, want_raster=False):
+    """one tsdr_frames_d per buffer against tsdr_frames_submit_d of the same buffers; geoms[b] = (y_t, x_t) of buffer b"""
+    from tempestsdr_jl_amd import api
+    npx = 600 * 800
+
+    def run(pipelined):
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
+        cnt = [b.size // S for b in bufs]
+        d_fr = [ctx.dev_alloc(c * npx * 4) for c in cnt]
+        d_ra = [ctx.dev_alloc(c * y * x * 4) if want_raster else None for c, (y, x) in zip(cnt, geoms)]
+        d_ix = [ctx.dev_alloc(c * 8) for c in cnt]
+        try:
+            for b, c in enumerate(cnt):
+                f = api.frames_submit_d if pipelined else api.frames_d
+                y_t, x_t = geoms[b]
+                assert f(ctx, sync, d_iq[b], bufs[b].size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr[b], d_ra[b], d_ix[b]) == c
+            if pipelined:
+                api.frames_flush(ctx)
+            ctx.synchronize()
+            return ([ctx.download(p, (c * npx,), np.uint32) for p, c in zip(d_fr, cnt)],
+                    [ctx.download(p, (c * 2,), np.int32) for p, c in zip(d_ix, cnt)], ctx.download(d_state, (npx,), np.uint32))
+        finally:
+            for p in [d_state] + d_iq + d_fr + d_ix + [r for r in d_ra if r is not None]:
+                ctx.dev_free(p)
+
+    a, b = run(False), run(True)
+    for k, (x, y) in enumerate(zip(a[0] + a[1], b[0] + b[1])):
+        assert np.array_equal(x, y), k
+    assert np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("want_raster", [False, True])
+@pytest.mark.parametrize("precision", ["fast", "exact"])
+def test_submit_with_changing_raster_geometry(ctx, tsdr, synth, want_raster, precision):
+    """tsdr_frames_submit_d when y_t / x_t change between un-flushed submissions while S and nEch stay (GUI.jl's y_t / x_t
+    corrections, :238-252): the projection-sum and guard-record slots are laid out by the tile plan of the geometry, so the
+    pipeline must run empty before the new layout is used -- results equal one tsdr_frames_d per buffer."""
+    Fs, fv, nfr = 2.0e6, 60.0, 3
+    S = synth.samples_per_frame(Fs, fv)
+    geoms = [(628, 1056), (628, 1056), (700, 948), (700, 948), (1125, 2576), (628, 1056), (640, 1040)]
+    bufs = [synth.synth_leak(Fs, 1056, 628, fv, S * nfr, n0=b * S * nfr) for b in range(len(geoms))]
+    ctx.set_precision(precision)   # (FAST: in-walk projection sums and guard records, the slots the tile plan lays out)
+    ctx.set_option("sync_guard_auto", 0)
+    try:
+        _pipeline_vs_sequential(ctx, tsdr, bufs, geoms, S, want_raster)
+    finally:
+        ctx.set_option("sync_guard_auto", 1)
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_pipeline_on_a_geometry_without_fused_kernels(ctx, tsdr, mode):
+    """A raster no image kernel tiles (30000 lines of 200 pixels in TSDR_EXACT: 3000 source lines per 64 output rows do not
+    fit the staging budget, and the narrow raster rules out the in-walk downgrade) goes through the raster-in-workspace +
+    2-D resize fallback, frame by frame.  Two pipelined submissions may run that loop side by side on two lanes: each lane
+    has its own workspace raster, so the result is the sequential one."""
+    S, nfr, y_t, x_t = 50_000, 2, 30_000, 200
+    r = np.random.default_rng(41)
+    bufs = [((r.standard_normal(S * nfr) + 1j * r.standard_normal(S * nfr)) * 1e-2).astype(np.complex64) for _ in range(4)]
+    ctx.set_precision("exact")
+    ctx.set_option("pipe_mode", mode)
+    try:
+        _pipeline_vs_sequential(ctx, tsdr, bufs, [(y_t, x_t)] * 4, S)
+    finally:
+        ctx.set_option("pipe_mode", -1)
+        ctx.set_precision("fast")
+
+
 def test_sync_margins_on_the_synthetic_leak(ctx, tsdr, synth):
     """How far the synthetic C2 frames are from a tied frame-sync decision (printed; asserted to be orders of
     magnitude above the 1e-7 level at which implementations may differ -- it is NOT: neighbouring blank-band centres

@@ -16,7 +16,8 @@ NAMES = {  # kernel-name substring -> bench.py's launch name
     "k_down_fused<true, 2, 0": "down_fused_iq", "k_guard": "sync_guard",
     "k_down_fused<true, 3, 2": "down_fused_iq_sums", "k_down_fused<true, 3, 0": "down_fused_iq",
     "k_raster_shear<true>": "raster_sheared_iq", "k_raster_shear<false>": "raster_unsheared_iq",
-    "k_seg1024<false": "welch_seg1024", "k_seg1024<true": "waterfall_seg1024",
+    # k_seg1024<KIND, CPLX>: KIND 0 = getWelch accumulator, 1 = getWaterfall writer, 2 = row store (tsdr_fft_c2c, 1024-point rows)
+    "k_seg1024<0": "welch_seg1024", "k_seg1024<1": "waterfall_seg1024", "k_seg1024<2": "fft_rows1024",
 }
 
 

@@ -16,6 +16,16 @@ w = synth.WORKLOADS[wl]
 Fs, x_t, y_t, fv = w["Fs"], w["x_t"], w["y_t"], w["fv"]
 S = synth.samples_per_frame(Fs, fv); nfr = int(round(w["acquisition"] * Fs)) // S; NPX = 600 * 800; P = x_t * y_t
 iqs = [torch.from_numpy(np.ascontiguousarray(synth.synth_leak(Fs, x_t, y_t, fv, S * nfr, n0=b * S * nfr)).view(np.float32)).cuda() for b in range(3)]
+# DUMMY_STREAMS=K: K HIP streams created (and kept) before the context and its lanes exist -- does the pipeline's overlap
+# depend on which hardware queues its lanes are mapped to?
+_dummy = []
+if int(os.environ.get("DUMMY_STREAMS", "0")):
+    import ctypes
+    _hip = ctypes.CDLL("libamdhip64.so.7")
+    for _ in range(int(os.environ["DUMMY_STREAMS"])):
+        st = ctypes.c_void_p()
+        assert _hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0
+        _dummy.append(st)
 ctx = T.Context()
 for raster in (True, False):
     for pipe in (False, True):
@@ -37,6 +47,10 @@ for raster in (True, False):
             ctx.synchronize()
             return t
         run(20)
+        if pipe:   # the library times its candidate arrangements on the first submissions of a configuration
+            while ctx.pipeline_info()["trials_left"] > 0:
+                run(10)
+            print("   ", ctx.pipeline_info()["text"], flush=True)
         res = []
         for _ in range(3):
             t0 = time.perf_counter()
