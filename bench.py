@@ -126,10 +126,10 @@ class FramesLeg:
                 self.step()
             if self.pipelined:
                 # tsdr_frames_submit_d times its candidate arrangements on the first submissions of a configuration (15 buffers
-                # through each of 8; results are identical in all of them) and then keeps the fastest: that measurement is
+                # through each of 8, twice; results are identical in all of them) and then keeps the fastest: that measurement is
                 # warm-up, like the reference's FFTW.PATIENT planning (Resampler.jl:31,39) -- not part of the timed region
                 extra = 0
-                while ctx.pipeline_info()["trials_left"] > 0 and extra < 200:
+                while ctx.pipeline_info()["trials_left"] > 0 and extra < 400:
                     self.step()
                     extra += 1
                 self.pipeline_info = ctx.pipeline_info()

@@ -81,7 +81,8 @@ int tsdr_device_info(tsdr_ctx *ctx, char *name, size_t cap, int *cu_count, size_
  *               than 15 % of the recent frames were flagged (an input whose blanking interval is flat, so that
  *               neighbouring columns tie), re-evaluating them one by one costs more than computing everything
  *               exactly: the loop then runs WHOLE buffers in the TSDR_EXACT sequence (frames keep being counted)
- *               until the share falls below 5 % (option "sync_guard_auto", default 1; tsdr_sync_guard_auto).
+ *               until the share falls below 5 % (option "sync_guard_auto", default 1; tsdr_sync_guard_auto); the decision is
+ *               made from the counts of the calls up to the third before this one, so it is reproducible run to run.
  * The mode applies ONLY to tsdr_frames / _d / _submit_d / _scan_d.  The per-function entry points
  * (tsdr_sig_to_image, tsdr_resize1d/2d, tsdr_downgrade, tsdr_vsync, ... and their _d forms) always run
  * the TSDR_EXACT operation sequence.  Shift + IIR are evaluated identically in both modes. */
@@ -130,12 +131,14 @@ int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, uns
  * on this context, BEFORE any re-evaluation: margins[2f] = beta_x of frame f (decides s_x of frame f), margins[2f+1] =
  * beta_y of frame f (decides s_y of frame f+1).  Fills min(*n_frames, max_frames) frames.  Synchronises. */
 int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *n_frames);
-/* state of the adaptive route (host-side, no synchronisation): *exact_now = 1 while whole buffers run in the TSDR_EXACT
- * sequence; *buffers_exact = frame-loop calls that did so far; *switches = changes of route so far.  The decision uses
- * counters of completed buffers only, read from a pinned mirror without synchronising, so it lags by the buffers in
- * flight: WHICH buffers carry TSDR_EXACT pixels and which TSDR_FAST pixels (both inside the tolerance; sync indices are
- * the reference's either way) depends on host / GPU timing, i.e. the FAST loop is reproducible run to run at the
- * 1e-7 pixel level only with "sync_guard_auto" = 0 (or in TSDR_EXACT). */
+/* state of the adaptive route (host-side): *exact_now = 1 while whole buffers run in the TSDR_EXACT sequence;
+ * *buffers_exact = frame-loop calls that did so far; *switches = changes of route so far.  REPRODUCIBLE: every guarded
+ * call's guard launch leaves its own {frames, flagged} counts in a pinned ring entry tagged with the call's sequence number,
+ * and the decision for call k folds the entries of the calls <= k - 3 in submission order -- waiting for them if the host is
+ * that far ahead (call k - 3 is complete in any steady state; the wait is a poll of pinned memory, bounded at 50 ms).  So
+ * WHICH buffers carry TSDR_EXACT pixels and which TSDR_FAST pixels is a function of the sequence of buffers alone, not of
+ * host / GPU timing (tests/test_fast_mode_gpu.py:test_adaptive_route_is_reproducible_run_to_run); the price is that a
+ * frame-loop call may return only when the call three before it has reached its guard launch. */
 int tsdr_sync_guard_auto(tsdr_ctx *ctx, int *exact_now, unsigned long long *buffers_exact, unsigned long long *switches);
 
 /* resident buffers for callers without their own device allocator */
@@ -298,7 +301,7 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
  * WHICH one, on which of the library's streams, is MEASURED: how well two HIP streams of a process overlap depends on the
  * hardware queues they were mapped to, i.e. on what else the process created before (the same code: +8 % or -40 % against one
  * call per buffer).  Like the reference's FFTW.PATIENT plans (Resampler.jl:31,39), the first submissions of a configuration
- * -- 15 buffers through each of 8 candidates, results identical in all of them -- are timed with HIP events and the rest
+ * -- 15 buffers through each of 8 candidates, twice, results identical in all of them -- are timed with HIP events and the rest
  * use the fastest, the sequential order included, so the pipeline is never slower than one call per buffer by more than the
  * measurement's noise (options "pipe_mode" / "pipe_tune"; tsdr_frames_pipeline_info).  Up to three image / key / projection
  * slots rotate.
@@ -308,7 +311,7 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
  * other entry point that uses the same SyncXY state or image slots (tsdr_frames_d, tsdr_frames_scan_d / _combine_d,
  * tsdr_vsync_d, tsdr_sync_reset / _free, tsdr_set_stream, tsdr_dev_free, tsdr_destroy) flushes first, so results never
  * depend on the mix of calls.  Results are identical to calling tsdr_frames_d once per buffer (sync indices; pixels
- * bit for bit).  A submission whose configuration (frames per buffer, S, y_t, x_t, raster or not, precision, SyncXY) differs
+ * bit for bit, the adaptive guard route included).  A submission whose configuration (frames per buffer, S, y_t, x_t, raster or not, precision, SyncXY) differs
  * from the previous one's waits on the HOST for the buffers in flight (its workspace slots move), as does a trial boundary.
  * Lifetime: until a flush point has been reached AND the context's stream has completed, the caller must not touch or
  * free iq, the SyncXY state, imageOut_state, frames_out / raster_out / sync_idx of submitted work, and each in-flight
@@ -399,7 +402,7 @@ int tsdr_group_sync_reset(tsdr_group *g);
 int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y);
 /* the last call's route (1 = sharded / gathered, 2 = root alone) and its three stages on the root's stream in ms:
  * {upload + per-member stage, collective, root's final stage}. */
-int tsdr_group_timing(tsdr_group *g, int *route, double ms[3]);
+int tsdr_group_timing(tsdr_group *g, int *route, double *ms /* 3 values */);
 
 #ifdef __cplusplus
 }

@@ -78,12 +78,19 @@ struct tsdr_ctx {
   unsigned long long *guard_stats = nullptr;
   // adaptive route (option "sync_guard_auto"): when more than guard_auto_hi of the recent frames were flagged, re-evaluating
   // them one by one costs more than running whole buffers in the exact sequence, so the FAST frame loop does that until the
-  // share (still counted, on the exact statistics) falls below guard_auto_lo.  Decided on the host from a pinned mirror of
-  // the device counters: no synchronisation, the decision lags by the buffers in flight.
+  // share (still counted, on the exact statistics) falls below guard_auto_lo.  Decided on the host, DETERMINISTICALLY (round 5):
+  // every guarded call's guard launch writes ITS OWN {frames, flagged} into a pinned ring entry tagged with the call's
+  // sequence number; the decision for call k folds the entries of calls <= k - kGuardLag, in submission order, waiting for
+  // them if need be (call k - 3 is long complete in any steady state: it is the pipeline's own slot-reuse distance).  The same
+  // sequence of buffers therefore takes the same route on every run, whatever the host / GPU timing.
   int opt_guard_auto = 1;
   float guard_auto_hi = 0.15f, guard_auto_lo = 0.05f;
-  unsigned long long *guard_host = nullptr;  // pinned: checked << 32 | flagged
-  unsigned guard_seen_c = 0, guard_seen_f = 0;
+  int opt_guard_nowait = 0;                  // measurement switch (TSDR_GUARD_NOWAIT): the decision never waits for an entry
+  static constexpr int kGuardRing = 16, kGuardLag = 3;
+  unsigned long long *guard_ring = nullptr;  // pinned: tag (seq + 1, 16 bits) << 48 | frames << 24 | flagged
+  unsigned long long guard_seq = 0;          // guarded calls issued so far (the next one's sequence number)
+  unsigned long long guard_consumed = 0;     // entries folded into the window so far
+  unsigned guard_win_c = 0, guard_win_f = 0; // frames checked / flagged since the last decision
   bool guard_exact_now = false;
   unsigned long long guard_auto_buffers = 0, guard_auto_switches = 0;
   size_t guard_last_off = (size_t)-1;       // byte offset inside WS_GUARD of the most recent guarded call's top-2 records (tsdr_sync_guard_margins)
@@ -136,10 +143,14 @@ struct tsdr_ctx {
                                     // equal lanes, only shift + IIR chained; 2: one internal stream (the sequential order)
   int opt_pipe_lanes = 2;           // equal lanes of the forced arrangement 1: 2 or 3
   int opt_pipe_priority = 1;        // forced arrangement 0: the tail lane is a stream of the highest priority
+  int opt_pipe_ext_event = 1;       // 1: a buffer's tail event rides on its shift + IIR dispatch (hipExtLaunchKernelGGL's stop event) instead of
+                                    // a marker packet of its own behind it
+  hipEvent_t launch_stop_ev = nullptr;  // set by the pipeline for the next shift + IIR launch, cleared by it
+  int opt_pipe_debug = 0;           // measurement switches (TSDR_PIPE_DEBUG; results are WRONG with bit 2 unless one lane is forced)
   int opt_pipe_tune = 1;            // 0: "pipe_mode" -1 means arrangement 0 with rasters, 1 without (rounds 1-4), nothing is measured
   struct PipeTune {                 // the measured choice for one PipeKey
     PipeKey key; int state = 0;     // 0: nothing measured; 1: trials running; 2: settled
-    int cand = 0, pos = 0, chosen = -1;
+    int cand = 0, pos = 0, chosen = -1, round = 0;   // round 0: warm-up trial of candidate 0; 1, 2: the two measured passes
     float ms[kTuneCands] = {};      // mean interval between the tails of successive buffers, per arrangement
   } tune;
   hipEvent_t tune_ev[kTrial] = {};

@@ -157,7 +157,10 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_DOWN_XCD")) ctx->opt_down_xcd = atoi(e) != 0;
   if (const char *e = getenv("TSDR_DOWN_SPP_MAX_PCT")) ctx->opt_down_spp_max_pct = atoi(e);
   if (const char *e = getenv("TSDR_PIPE_MODE")) ctx->opt_pipe_mode = atoi(e) < 0 ? -1 : atoi(e) > 2 ? 2 : atoi(e);
+  if (const char *e = getenv("TSDR_GUARD_NOWAIT")) ctx->opt_guard_nowait = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_PIPE_DEBUG")) ctx->opt_pipe_debug = atoi(e);
   if (const char *e = getenv("TSDR_PIPE_TUNE")) ctx->opt_pipe_tune = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_PIPE_EXT_EVENT")) ctx->opt_pipe_ext_event = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;
   if (const char *e = getenv("TSDR_BETA_WAVES")) ctx->opt_beta_waves = atoi(e) == 8 ? 8 : 4;
   return ctx;
@@ -182,7 +185,7 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (ctx->amax_keys) (void)hipFree(ctx->amax_keys);
   if (ctx->guard_stats) (void)hipFree(ctx->guard_stats);
   for (auto &q : ctx->guard_sync) if (q) (void)hipFree(q);
-  if (ctx->guard_host) (void)hipHostFree(ctx->guard_host);
+  if (ctx->guard_ring) (void)hipHostFree(ctx->guard_ring);
   if (ctx->amax_host) (void)hipHostFree(ctx->amax_host);
   if (ctx->tw_small) (void)hipFree(ctx->tw_small);
   for (auto &kv : ctx->tw) { (void)hipFree(kv.second.lo); (void)hipFree(kv.second.hi); }
@@ -244,15 +247,14 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
     else if (name[5] == 'p') ctx->opt_pipe_priority = value != 0;
     else { ctx->opt_pipe_tune = value != 0; ctx->tune = tsdr_ctx::PipeTune{}; }   // (setting it also discards what was measured)
   }
+  else if (!strcmp(name, "pipe_ext_event")) ctx->opt_pipe_ext_event = value != 0;
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");
     ctx->guard_thr = (float)value * 1e-9f;
     // the adaptive route's history belongs to the old threshold: start over on the fast route
     ctx->guard_exact_now = false;
-    if (ctx->guard_host) {
-      const unsigned long long w = __atomic_load_n(ctx->guard_host, __ATOMIC_RELAXED);
-      ctx->guard_seen_c = (unsigned)(w >> 32); ctx->guard_seen_f = (unsigned)w;
-    }
+    ctx->guard_consumed = ctx->guard_seq;   // (the calls in flight were counted against the old threshold: never folded)
+    ctx->guard_win_c = ctx->guard_win_f = 0;
   }
   else if (!strcmp(name, "sync_guard_auto")) {
     ctx->opt_guard_auto = value != 0;

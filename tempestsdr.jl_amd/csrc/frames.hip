@@ -10,6 +10,7 @@
 // recurrence -- are resolved inside shift_iir/sync_publish, so everything upstream is parallel
 // over frames.  No host synchronisation happens in the _d entry point.
 #include <algorithm>
+#include <chrono>
 #include <string>
 
 #include "common.h"
@@ -70,26 +71,52 @@ struct PrecisionScope {  // a call that has to run in TSDR_EXACT restores the ca
   ~PrecisionScope() { ctx->precision = saved; }
 };
 
-// the adaptive route's decision (common.h): evaluated over windows of at least kGuardAutoWindow frames
+// the adaptive route's decision (common.h): evaluated over windows of at least kGuardAutoWindow frames, from the per-call
+// counts of the calls up to `upto` (exclusive), folded in submission order
 constexpr unsigned kGuardAutoWindow = 60;
-static void guard_auto_update(tsdr_ctx *ctx) {
-  if (!ctx->opt_guard_auto) { ctx->guard_exact_now = false; return; }
-  if (!ctx->guard_host) return;
-  const unsigned long long w = __atomic_load_n(ctx->guard_host, __ATOMIC_RELAXED);
-  const unsigned c = (unsigned)(w >> 32), fl = (unsigned)w;
-  const unsigned dc = c - ctx->guard_seen_c, df = fl - ctx->guard_seen_f;
-  if (dc < kGuardAutoWindow) return;
-  const float share = (float)df / (float)dc;
-  if (!ctx->guard_exact_now && share > ctx->guard_auto_hi) { ctx->guard_exact_now = true; ++ctx->guard_auto_switches; }
-  else if (ctx->guard_exact_now && share < ctx->guard_auto_lo) { ctx->guard_exact_now = false; ++ctx->guard_auto_switches; }
-  ctx->guard_seen_c = c; ctx->guard_seen_f = fl;
+static void guard_auto_update(tsdr_ctx *ctx, unsigned long long upto) {
+  if (!ctx->guard_ring) return;
+  for (; ctx->guard_consumed < upto; ++ctx->guard_consumed) {
+    const unsigned long long j = ctx->guard_consumed, want = (j + 1) & 0xFFFFull;
+    volatile unsigned long long *e = ctx->guard_ring + (j % tsdr_ctx::kGuardRing);
+    unsigned long long w = 0;
+    bool seen = false;
+    std::chrono::steady_clock::time_point t0;
+    for (unsigned it = 1; !seen; ++it) {
+      w = __atomic_load_n(e, __ATOMIC_ACQUIRE);
+      seen = (w >> 48) == want;
+      if (!seen && ctx->opt_guard_nowait) return;   // (measurement switch: fold what has arrived, never wait -- not reproducible)
+      if (!seen && (it & 0x3FFu) == 0) {
+        // (no HIP call in the ordinary wait: a stream query may put a marker packet into the queue it asks about)
+        if (it == 0x400u) { t0 = std::chrono::steady_clock::now(); continue; }
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited < std::chrono::milliseconds(2)) continue;
+        // the entry's launch may never have been enqueued (a call that failed half-way): once nothing is in flight any
+        // more, nothing will write it.  And a caller's own stream may be held by something only this thread can release:
+        // the wait is bounded (50 ms), the entry then goes uncounted
+        bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
+        for (auto l : ctx->pool) if (l && idle) idle = hipStreamQuery(l) == hipSuccess;
+        (void)hipGetLastError();
+        if (idle || waited > std::chrono::milliseconds(50)) { w = __atomic_load_n(e, __ATOMIC_ACQUIRE); seen = (w >> 48) == want; break; }
+        t0 += std::chrono::milliseconds(2);   // (next look at the streams in another 2 ms)
+      }
+    }
+    if (!seen || !ctx->opt_guard_auto) continue;
+    ctx->guard_win_c += (unsigned)((w >> 24) & 0xFFFFFFull);
+    ctx->guard_win_f += (unsigned)(w & 0xFFFFFFull);
+    if (ctx->guard_win_c < kGuardAutoWindow) continue;
+    const float share = (float)ctx->guard_win_f / (float)ctx->guard_win_c;
+    if (!ctx->guard_exact_now && share > ctx->guard_auto_hi) { ctx->guard_exact_now = true; ++ctx->guard_auto_switches; }
+    else if (ctx->guard_exact_now && share < ctx->guard_auto_lo) { ctx->guard_exact_now = false; ++ctx->guard_auto_switches; }
+    ctx->guard_win_c = ctx->guard_win_f = 0;
+  }
+  if (!ctx->opt_guard_auto) ctx->guard_exact_now = false;
 }
 
 static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int x_t, int do_align, int F, int slot, int nslots,
                          GuardPlan *gp) {
   *gp = GuardPlan{};
   if (!do_align || ctx->precision != TSDR_FAST || !(ctx->guard_thr > 0.f)) return TSDR_OK;
-  guard_auto_update(ctx);
   int nbx = 0, nby = 0;
   sync_beta_blocks(sync, &nbx, &nby);
   GuardArgs g;
@@ -101,9 +128,11 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
   if (!ctx->guard_stats) {
     TSDR_HIP(ctx, hipMalloc((void **)&ctx->guard_stats, 32));
     TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_stats, 0, 32, ctx->stream));
-    TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->guard_host, 8, hipHostMallocDefault));
-    *ctx->guard_host = 0ull;
+    TSDR_HIP(ctx, hipHostMalloc((void **)&ctx->guard_ring, 8 * tsdr_ctx::kGuardRing, hipHostMallocDefault));
+    for (int i = 0; i < tsdr_ctx::kGuardRing; ++i) ctx->guard_ring[i] = 0ull;
   }
+  // this call is guarded call number guard_seq: its route follows from the calls up to guard_seq - kGuardLag
+  if (ctx->guard_seq >= (unsigned long long)tsdr_ctx::kGuardLag) guard_auto_update(ctx, ctx->guard_seq - tsdr_ctx::kGuardLag + 1);
   if (ctx->opt_guard_auto && ctx->guard_exact_now) {  // this buffer: the exact sequence as a whole; flagged frames are only counted
     ctx->precision = TSDR_EXACT;                      // (the caller holds a PrecisionScope)
     g.count_only = 1;
@@ -117,7 +146,9 @@ static int guard_prepare(tsdr_ctx *ctx, tsdr_sync *sync, size_t S, int y_t, int 
   gp->top2 = (uint2 *)(w + ((size_t)F * 4 + 15) / 16 * 16);
   g.top2 = gp->top2;
   g.stats = ctx->guard_stats;
-  g.host = ctx->guard_host;
+  g.host = ctx->guard_ring + (ctx->guard_seq % tsdr_ctx::kGuardRing);
+  g.host_tag = (ctx->guard_seq + 1) & 0xFFFFull;
+  ++ctx->guard_seq;
   gp->g = g;
   gp->on = true;
   // (an offset, not the pointer: the workspace may be reallocated by a later, larger call)
@@ -334,14 +365,23 @@ static int pipe_pick(tsdr_ctx *ctx, const tsdr_ctx::PipeKey &key) {
     float ms = 0.f;
     const bool okev = hipEventElapsedTime(&ms, ctx->tune_ev[2], ctx->tune_ev[tsdr_ctx::kTrial - 1]) == hipSuccess;
     (void)hipGetLastError();
-    t.ms[t.cand] = okev ? ms / (float)(tsdr_ctx::kTrial - 3) : 1e30f;
     t.pos = 0;
-    if (++t.cand == tsdr_ctx::kTuneCands) {
-      int best = 0;
-      for (int c = 1; c < tsdr_ctx::kTuneCands; ++c) if (t.ms[c] < t.ms[best]) best = c;
-      // the sequential order unless something beats it by more than the measurement's noise
-      t.chosen = t.ms[best] < 0.985f * t.ms[0] ? best : 0;
-      t.state = 2;
+    if (t.round == 0) {
+      // the very first trial (the device's clocks and caches as the caller left them) only warms up: measured again, in turn
+      t.round = 1;
+    } else {
+      const float v = okev ? ms / (float)(tsdr_ctx::kTrial - 3) : 1e30f;
+      t.ms[t.cand] = t.round == 1 ? v : std::min(t.ms[t.cand], v);   // two passes over the candidates, the better of the two
+      if (++t.cand == tsdr_ctx::kTuneCands) {
+        t.cand = 0;
+        if (++t.round == 3) {
+          int best = 0;
+          for (int c = 1; c < tsdr_ctx::kTuneCands; ++c) if (t.ms[c] < t.ms[best]) best = c;
+          // the sequential order unless something beats it by more than the measurement's noise
+          t.chosen = t.ms[best] < 0.985f * t.ms[0] ? best : 0;
+          t.state = 2;
+        }
+      }
     }
   }
   return t.state == 2 ? t.chosen : t.cand;
@@ -435,7 +475,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     LaneScope lane_scope(ctx, li);
     hipStream_t st = ctx->lane[li];
     tail_stream = st;
-    if (hipStreamQuery(ctx->stream) != hipSuccess) {
+    if (!(ctx->opt_pipe_debug & 1) && hipStreamQuery(ctx->stream) != hipSuccess) {
       (void)hipGetLastError();
       TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
       TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_in, 0));
@@ -457,10 +497,12 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     }
     if (ctx->pipe_last_slot >= 0 && ctx->pipe_last_slot != slot && ctx->ev_tail_used[ctx->pipe_last_slot])
       TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_tail[ctx->pipe_last_slot], 0));
+    if (ctx->opt_pipe_ext_event && !(ctx->opt_pipe_debug & 2)) ctx->launch_stop_ev = ctx->ev_tail[slot];
     rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
                      do_align ? sync_idx : nullptr);
+    ctx->launch_stop_ev = nullptr;
     if (rc) return rc;
-    TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
+    if (!ctx->opt_pipe_ext_event && !(ctx->opt_pipe_debug & 2)) TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
   } else {
     tail_stream = ctx->lane[2];
     {
@@ -495,14 +537,20 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
         }
       }
       // (shift + IIR on a third stream of its own: 348 k vs 357 k frames/s raster-free, 175 k vs 181 k with rasters -- dropped)
+      if (ctx->opt_pipe_ext_event) ctx->launch_stop_ev = ctx->ev_tail[slot];
       rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
                        do_align ? sync_idx : nullptr);
+      ctx->launch_stop_ev = nullptr;
       if (rc) return rc;
-      TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
+      if (!ctx->opt_pipe_ext_event) TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
     }
   }
-  if (ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune && ctx->tune.state == 1 && ctx->tune.pos < tsdr_ctx::kTrial)
-    TSDR_HIP(ctx, hipEventRecord(ctx->tune_ev[ctx->tune.pos++], tail_stream));
+  if (ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune && ctx->tune.state == 1 && ctx->tune.pos < tsdr_ctx::kTrial) {
+    // two timing events per trial (a timed event is a marker packet that holds up the launches behind it for a few
+    // microseconds: one per buffer made the one-stream candidate look 10 % slower than it is)
+    if (ctx->tune.pos == 2 || ctx->tune.pos == tsdr_ctx::kTrial - 1) TSDR_HIP(ctx, hipEventRecord(ctx->tune_ev[ctx->tune.pos], tail_stream));
+    ++ctx->tune.pos;
+  }
   ctx->ev_tail_used[slot] = true;
   ctx->pipe_last_slot = slot;
   ++ctx->pipe_seq;
@@ -515,9 +563,10 @@ int tsdr_frames_pipeline_info(tsdr_ctx *ctx, int *trials_left, int *chosen, floa
   if (!ctx || cap < 0 || (cap && !ms_per_buffer)) return TSDR_EINVAL;
   const tsdr_ctx::PipeTune &t = ctx->tune;
   const bool measured = ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune;
-  if (trials_left) *trials_left = !measured ? 0 : t.state == 2 ? 0 : t.state == 1 ? tsdr_ctx::kTuneCands - t.cand : tsdr_ctx::kTuneCands;
+  constexpr int kAll = 2 * tsdr_ctx::kTuneCands + 1;   // the warm-up trial + two passes
+  if (trials_left) *trials_left = !measured ? 0 : t.state == 2 ? 0 : t.state == 1 ? kAll - (t.round == 0 ? 0 : 1 + (t.round - 1) * tsdr_ctx::kTuneCands + t.cand) : kAll;
   if (chosen) *chosen = measured ? (t.state == 2 ? t.chosen : -1) : ctx->pipe_cand_now;
-  for (int c = 0; c < cap && c < tsdr_ctx::kTuneCands; ++c) ms_per_buffer[c] = measured && (t.state == 2 || c < t.cand) ? t.ms[c] : 0.f;
+  for (int c = 0; c < cap && c < tsdr_ctx::kTuneCands; ++c) ms_per_buffer[c] = measured && (t.state == 2 || t.round == 2 || (t.round == 1 && c < t.cand)) ? t.ms[c] : 0.f;
   if (text && text_cap) {
     std::string s;
     if (!measured) s = std::string("forced: ") + (ctx->pipe_cand_now >= 0 ? kCands[ctx->pipe_cand_now].name : "nothing submitted yet");

@@ -214,7 +214,7 @@ int tsdr_group_sync_reset(tsdr_group *g) {
   return TSDR_OK;
 }
 
-int tsdr_group_timing(tsdr_group *g, int *route, double ms[3]) {
+int tsdr_group_timing(tsdr_group *g, int *route, double *ms) {
   if (!g) return TSDR_EINVAL;
   if (route) *route = g->last_route;
   if (ms) for (int k = 0; k < 3; ++k) ms[k] = g->stage_ms[k];

@@ -23,7 +23,8 @@ struct GuardArgs {
   int *flags = nullptr;         // [frames] out: 1 = re-evaluated
   unsigned long long *stats = nullptr;  // [0] frames checked, [1] frames flagged (running totals; resettable), [2] the same
                                         // two as one never-reset word: checked << 32 | flagged (both mod 2^32)
-  unsigned long long *host = nullptr;   // pinned host mirror of stats[2]: what the adaptive mode switch reads without a sync
+  unsigned long long *host = nullptr;   // pinned ring entry of THIS call: host_tag << 48 | frames << 24 | flagged (what the
+  unsigned long long host_tag = 0;      // adaptive route's decision folds in submission order, frames.hip:guard_auto_update)
   int count_only = 0;                   // 1: the buffer was computed in the exact sequence as a whole; only count
 };
 

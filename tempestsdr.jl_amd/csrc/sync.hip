@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <mutex>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "down_fused.h"
 #include "guard.h"
@@ -761,11 +763,11 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
         if (blockIdx.x == 0) {
           atomicAdd(&a.g.stats[0], (unsigned long long)a.frames);
           if (n) atomicAdd(&a.g.stats[1], (unsigned long long)n);
-          // {checked << 32 | flagged} in one word (guard launches of two pipeline lanes may run side by side: atomic; the
-          // mirror below may then be overwritten by the older of two values, which the next launch corrects)
-          const unsigned long long dw = ((unsigned long long)(unsigned)a.frames << 32) | (unsigned long long)(unsigned)n;
-          const unsigned long long nw = atomicAdd(&a.g.stats[2], dw) + dw;
-          if (a.g.host) __hip_atomic_store(a.g.host, nw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          // this call's own counts into its pinned ring entry (guard launches of two pipeline lanes may complete in either
+          // order: the host folds the entries by sequence number, not by arrival)
+          if (a.g.host)
+            __hip_atomic_store(a.g.host, (a.g.host_tag << 48) | ((unsigned long long)(unsigned)a.frames << 24) | (unsigned long long)(unsigned)n,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -921,7 +923,20 @@ int shift_iir_d(tsdr_ctx *ctx, tsdr_sync *s, const float *img, size_t img_stride
   const size_t npx = (size_t)h * w;
   IirArgs I;
   iir_args(s, img, img_stride, h, w, frames, keys, do_align, alpha, state, frames_out, sync_idx, &I);
-  TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, I);
+  if (ctx->launch_stop_ev && !ctx->prof_on) {
+    // the pipeline's "tail of this buffer done" event is this dispatch's own completion signal: no marker packet behind it
+    hipEvent_t ev = ctx->launch_stop_ev;
+    ctx->launch_stop_ev = nullptr;
+    hipExtLaunchKernelGGL(k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, ctx->launch_stream, nullptr, ev, 0, I);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return hip_fail(ctx, le, "shift_iir");
+  } else {
+    const bool rec = ctx->launch_stop_ev != nullptr;
+    hipEvent_t ev = ctx->launch_stop_ev;
+    ctx->launch_stop_ev = nullptr;
+    TSDR_LAUNCH(ctx, "shift_iir", k_shift_iir, dim3((unsigned)ceil_div(npx, 256)), dim3(256), 0, I);
+    if (rec) TSDR_HIP(ctx, hipEventRecord(ev, ctx->launch_stream));
+  }
   if (do_align) s->cur ^= 1;
   return TSDR_OK;
 }

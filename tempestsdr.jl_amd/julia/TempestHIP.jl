@@ -22,6 +22,7 @@ export SyncXY, vsync
 export hip_frames!, hip_frames_submit!, hip_frames_flush, hip_synchronize   # fused GUI.jl:163-178 loop body (optional fast path; pipelined form)
 export hip_extract_configuration, sync_guard_stats, sync_guard_auto   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
 export hip_set_precision, hip_set_option                              # TSDR_EXACT / TSDR_FAST and the library's options, per task context
+export HipGroup, hip_group                                            # one process, several GPUs (RCCL inside the library): `devices = ...`
 
 const LIB = get(ENV, "TEMPEST_HIP_LIB", joinpath(@__DIR__, "..", "libtempest_hip.so"))
 const RENDERING_SIZE = (600, 800)   # GUI.jl:10
@@ -298,6 +299,113 @@ function sync_guard_auto()
     e = Ref{Cint}(0); a = Ref{Culonglong}(0); b = Ref{Culonglong}(0); c = ctx()
     check(c, ccall((:tsdr_sync_guard_auto, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Culonglong}, Ptr{Culonglong}), c.h, e, a, b), "sync_guard_auto")
     return (e[] != 0, Int(a[]), Int(b[]))
+end
+
+# ---- one process, several GPUs (tsdr_group_*: one context + one RCCL communicator per device) ----------------------
+"""
+    HipGroup(devices = 0:0)
+
+What this process holds to use several MI355X of the node (the reference runtime is ONE process, GUI.jl:380-382): one
+library context and one RCCL communicator per device (`ncclCommInitAll` inside `libtempest_hip.so`), member 1 (device
+`first(devices)`) the root.  Pass it as `group = g` -- or just `devices = 0:7`, which keeps one group per task -- to
+`hip_extract_configuration`, `hip_frames!` and `getWelch`:
+
+* the search shards the sum over m of the circular autocorrelation (`Autocorrelations.jl:27-29`), ONE all-reduce of the
+  `indexMax` accumulators over xGMI, `10log10(abs2)` and `findmax` after it on the root;
+* the frame loop shards the buffer's frames, gathers 600x800 images + argmax keys to the root, which applies the lagged
+  `s_y`, `circshift` and the IIR in order.  The group owns its `SyncXY` states (`reset!(g)` = a fresh `SyncXY`).
+"""
+mutable struct HipGroup
+    h::Ptr{Cvoid}
+    devices::Vector{Cint}
+end
+function HipGroup(devices = 0:0)
+    devs = collect(Cint, devices); h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:tsdr_group_create, LIB), Cint, (Ptr{Cint}, Cint, Ptr{Ptr{Cvoid}}), devs, length(devs), h)
+    (rc != 0 || h[] == C_NULL) && error("tempest_hip: tsdr_group_create($(devs)) failed (" *
+                                        unsafe_string(ccall((:tsdr_strerror, LIB), Cstring, (Cint,), rc)) * "); there is no CPU fallback")
+    g = HipGroup(h[], devs)
+    finalizer(g) do x
+        if x.h != C_NULL
+            ccall((:tsdr_group_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h)
+            x.h = C_NULL
+        end
+    end
+    return g
+end
+hip_group(devices) = get!(() -> HipGroup(devices), task_local_storage(), (:tempest_hip_group, Tuple(devices)))::HipGroup
+Base.length(g::HipGroup) = Int(ccall((:tsdr_group_size, LIB), Cint, (Ptr{Cvoid},), g.h))
+function check(g::HipGroup, rc::Cint, what)
+    rc == 0 && return
+    detail = unsafe_string(ccall((:tsdr_group_last_error, LIB), Cstring, (Ptr{Cvoid},), g.h))
+    msg = "$what: " * unsafe_string(ccall((:tsdr_strerror, LIB), Cstring, (Cint,), rc)) * " [$detail]"
+    rc == -1 && throw(AssertionError(msg))
+    rc == -2 && throw(BoundsError(what, detail))
+    rc == -3 && throw(OutOfMemoryError())
+    error(msg)
+end
+reset!(g::HipGroup) = check(g, ccall((:tsdr_group_sync_reset, LIB), Cint, (Ptr{Cvoid},), g.h), "reset!")
+hip_set_precision(g::HipGroup, mode::Symbol) =
+    check(g, ccall((:tsdr_group_set_precision, LIB), Cint, (Ptr{Cvoid}, Cint), g.h, mode === :exact ? 0 : 1), "set_precision")
+hip_set_option(g::HipGroup, name::AbstractString, value::Integer) =
+    check(g, ccall((:tsdr_group_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Cint), g.h, name, value), "set_option($name)")
+"route (:sharded / :root) and the three stage times in ms (per-member stage incl. upload, collective, root's final stage) of the last call"
+function timing(g::HipGroup)
+    r = Ref{Cint}(0); ms = Vector{Cdouble}(undef, 3)
+    check(g, ccall((:tsdr_group_timing, LIB), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cdouble}), g.h, r, ms), "timing")
+    return (r[] == 1 ? :sharded : :root, ms)
+end
+
+"""
+    hip_extract_configuration(sigId, Fs; devices, route = :auto, delay = 0.1, rate_min = 50, rate_max = 90)
+    hip_extract_configuration(sigId, Fs; group = g, ...)
+
+`extract_configuration`'s arithmetic (GUI.jl:67-81) over several GPUs of this process.  `route = :auto` shards only when a
+member's segment + halo transform is smaller than the single-device one (with the reference's own window `n = 2 indexMax`,
+`Autocorrelations.jl:27`, it never is -- the root then runs alone); `:sharded` forces the all-reduce route.
+"""
+function hip_extract_configuration(sigId::Vector{ComplexF32}, Fs, g::HipGroup; route::Symbol = :auto, delay = 0.1, rate_min = 50, rate_max = 90)
+    indexMax = round(delay * Fs) |> Int
+    Γ = Vector{Float32}(undef, max(indexMax, 1)); n = Ref{Csize_t}(0)
+    pmin = Ref{Csize_t}(0); pmax = Ref{Csize_t}(0)
+    rc = ccall((:tsdr_zoom_bounds, LIB), Cint, (Csize_t, Cdouble, Cdouble, Cdouble, Ptr{Csize_t}, Ptr{Csize_t}),
+               indexMax, Fs, rate_min, rate_max, pmin, pmax)
+    rc == 0 || throw(BoundsError(Γ, Int(pmin[]):Int(pmax[])))
+    idx = Ref{Csize_t}(0); val = Ref{Cfloat}(0)
+    check(g, ccall((:tsdr_group_search, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{ComplexF32}, Cint, Csize_t, Cdouble, Cdouble, Cdouble, Cint, Ptr{Float32}, Ptr{Csize_t}, Csize_t, Csize_t, Ptr{Csize_t}, Ptr{Cfloat}, Cint),
+                   g.h, sigId, 1, length(sigId), Fs, 0.0, delay, 1, Γ, n, pmin[] - 1, pmax[] - pmin[] + 1, idx, val,
+                   route === :sharded ? 1 : route === :root ? 2 : 0), "extract_configuration")
+    xAx = (Int(pmin[]):Int(pmax[])) ./ Fs
+    rates_refresh = 1 ./ xAx
+    Γ_refresh = Γ[Int(pmin[]):Int(pmax[])]
+    fv = 1 / (1 / rates_refresh[Int(idx[]) + 1])                            # GUI.jl:80-81
+    return rates_refresh, Γ_refresh, fv
+end
+hip_extract_configuration(sigId::Vector{ComplexF32}, Fs, devices::AbstractVector{<:Integer}; kw...) =
+    hip_extract_configuration(sigId, Fs, hip_group(devices); kw...)
+
+"""
+    hip_frames!(imageOut, sigId, g::HipGroup, S, y_t, x_t, α; do_align = true) -> (frames, sync_idx)
+
+`hip_frames!` (GUI.jl:164-178 for one received buffer) with the buffer's frames sharded over the group's devices.
+"""
+function hip_frames!(imageOut::Matrix{Float32}, sigId::Vector{ComplexF32}, g::HipGroup, S, y_t, x_t, α::Float32; do_align = true)
+    nb = length(sigId) ÷ S
+    frames = Array{Float32}(undef, RENDERING_SIZE..., nb); idx = Matrix{Cint}(undef, 2, nb); n = Ref{Cint}(0)
+    check(g, ccall((:tsdr_group_frames, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{ComplexF32}, Csize_t, Csize_t, Cint, Cint, Cfloat, Cint, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{Cint}, Ptr{Cint}),
+                   g.h, sigId, length(sigId), S, y_t, x_t, α, do_align ? 1 : 0, imageOut, frames, C_NULL, idx, n), "hip_frames!")
+    return frames, idx
+end
+
+"getWelch (GetSpectrum.jl:36-52) with the segments sharded over the group: one all-reduce of `sizeFFT` Float32"
+function getWelch(fe, sig, g::HipGroup; sizeFFT = 1024)
+    a = _dense(sig); cplx = eltype(a) <: Complex ? 1 : 0
+    y = Vector{Float32}(undef, sizeFFT)
+    check(g, ccall((:tsdr_group_welch, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t, Csize_t, Cint, Ptr{Float32}),
+                   g.h, a, cplx, length(a), sizeFFT, 0, y), "getWelch")
+    return ((0:sizeFFT-1) ./ sizeFFT .- 0.5) .* fe, y
 end
 
 # ---- streaming ingest: the staging ring (AtomicAbstractSDRs.jl:64-190 on pinned memory) ----------

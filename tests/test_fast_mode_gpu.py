@@ -165,13 +165,13 @@ def test_frames_pipeline_matches_sequential(ctx, tsdr, synth, want_raster, mode)
 
 @pytest.mark.parametrize("want_raster", [False, True])
 def test_pipeline_measured_choice_walks_every_arrangement(tsdr, synth, want_raster):
-    """"pipe_mode" -1 (the default): the first 120 submissions of a configuration go through the eight candidate arrangements,
-    fifteen buffers each, with the pipeline run empty at every trial boundary, and the rest use the one measured fastest.  Results
+    """"pipe_mode" -1 (the default): the first 255 submissions of a configuration go through the eight candidate arrangements,
+    fifteen buffers each, twice after a warm-up trial, with the pipeline run empty at every trial boundary, and the rest use the one measured fastest.  Results
     must be those of one tsdr_frames_d per buffer throughout -- bit for bit, the SyncXY / imageOut state threaded through all
-    135 buffers -- and tsdr_frames_pipeline_info must report a settled choice with every candidate timed."""
+    270 buffers -- and tsdr_frames_pipeline_info must report a settled choice with every candidate timed."""
     from tempestsdr_jl_amd import api
     ctx = tsdr.Context(0)   # (a context of its own: the measurement is per context and configuration)
-    Fs, x_t, y_t, fv, nfr, nbuf, ndist = 2.0e6, 1056, 628, 60.0, 2, 135, 5
+    Fs, x_t, y_t, fv, nfr, nbuf, ndist = 2.0e6, 1056, 628, 60.0, 1, 270, 5
     S = synth.samples_per_frame(Fs, fv)
     P, npx = x_t * y_t, 600 * 800
     bufs = [synth.synth_leak(Fs, x_t, y_t, fv, S * nfr, n0=b * S * nfr) for b in range(ndist)]
@@ -199,7 +199,7 @@ def test_pipeline_measured_choice_walks_every_arrangement(tsdr, synth, want_rast
 
     try:
         a = run(False)
-        assert ctx.pipeline_info()["trials_left"] == 8
+        assert ctx.pipeline_info()["trials_left"] == 17
         b = run(True)
         info = ctx.pipeline_info()
         print("\n", info["text"])
@@ -349,8 +349,9 @@ def test_sync_guard_adaptive_route(ctx, tsdr, synth):
     """At 1080p60 / 20 MS/s the plateau leak flags ~70 % of its frames: re-evaluating them one by one costs more than the
     exact sequence for everything, so after a window of 60 frames the FAST loop runs whole buffers exactly (bit-identical to
     TSDR_EXACT), keeps counting, and returns to the fast route once a leak with a defined sync answer (the box profile: < 1 %
-    flagged) has filled a window.  Indices equal TSDR_EXACT's on every buffer on either route; "sync_guard_auto" = 0 pins
-    the one-by-one route."""
+    flagged) has filled a window.  The decision for call k folds the counts of calls <= k - 3, in submission order (a fixed
+    lag, so that the route is a function of the buffers and not of host / GPU timing): the routes below are exact
+    predictions.  Indices equal TSDR_EXACT's on every buffer on either route; "sync_guard_auto" = 0 pins the one-by-one route."""
     w = synth.WORKLOADS["C2"]
     Fs, x_t, y_t, fv, nfr = w["Fs"], w["x_t"], w["y_t"], w["fv"], 30
     S = synth.samples_per_frame(Fs, fv)
@@ -373,7 +374,7 @@ def test_sync_guard_adaptive_route(ctx, tsdr, synth):
     assert base[0] is False
     ctx.sync_guard_stats(reset=True)
     routes = []
-    for i in range(4):
+    for i in range(6):
         g, sg = run(tie, "fast")
         routes.append(ctx.sync_guard_auto()[1] - base[1])
         assert np.array_equal(g["sync_idx"], e_tie["sync_idx"]), i
@@ -382,14 +383,17 @@ def test_sync_guard_adaptive_route(ctx, tsdr, synth):
                 assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
             assert np.array_equal(sg.view(np.uint32), se_tie.view(np.uint32))
     checked, flagged = ctx.sync_guard_stats()
-    assert checked == 4 * nfr and flagged > 0.5 * checked, (checked, flagged)
-    assert routes == [0, 0, 1, 2], routes          # two fast buffers fill the window; the third and fourth run exactly
+    assert checked == 6 * nfr and flagged > 0.5 * checked, (checked, flagged)
+    # calls 0 and 1 fill the window; call 4 is the first whose decision sees both (4 - 3 = 1): it and call 5 run exactly
+    assert routes == [0, 0, 0, 0, 1, 2], routes
     assert ctx.sync_guard_auto()[0] is True
-    for i in range(4):
+    for i in range(5):
         g, _ = run(box, "fast")
         assert np.array_equal(g["sync_idx"], e_box["sync_idx"]), i
     now, n_exact, switches = ctx.sync_guard_auto()
-    assert now is False and n_exact - base[1] == 4 and switches - base[2] == 2, (now, n_exact, switches)
+    # calls 6 .. 9 (box) still run exactly -- their decisions fold the tie calls 3 .. 5 and the box calls 6, 7, which complete
+    # a quiet window at call 10: the fifth box buffer is back on the fast route
+    assert now is False and n_exact - base[1] == 6 and switches - base[2] == 2, (now, n_exact, switches)
     # pinned to the one-by-one route
     ctx.set_option("sync_guard_auto", 0)
     try:
@@ -400,6 +404,46 @@ def test_sync_guard_adaptive_route(ctx, tsdr, synth):
     finally:
         ctx.set_option("sync_guard_auto", 1)
         ctx.set_option("sync_guard_ppb", 20000)
+
+
+def test_adaptive_route_is_reproducible_run_to_run(tsdr, synth):
+    """The same plateau buffers three times, each time through a fresh context and the pipelined entry point, "sync_guard_auto"
+    on: WHICH buffers run as whole exact buffers is decided from per-call counts folded in submission order with a fixed lag
+    (common.h: kGuardLag), so frames, indices and the route taken are bit-identical on every run -- not a function of how
+    far the host happened to be ahead of the GPU."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y_t, fv, nfr, nbuf = 2.0e6, 1056, 628, 60.0, 20, 8
+    S = synth.samples_per_frame(Fs, fv)
+    npx = 600 * 800
+    bufs = [synth.synth_leak(Fs, x_t, y_t, fv, S * nfr, n0=b * S * nfr, card="plateau") for b in range(nbuf)]
+    runs = []
+    for rep in range(3):
+        ctx = tsdr.Context(0)
+        try:
+            ctx.set_option("pipe_mode", rep % 3)    # (the arrangement changes the timing, not the route)
+            sync = tsdr.SyncXY(ctx, 600, 800)
+            d_state = ctx.upload(np.zeros(npx, np.float32))
+            d_iq = [ctx.upload(b.view(np.float32)) for b in bufs]
+            d_fr = [ctx.dev_alloc(nfr * npx * 4) for _ in bufs]
+            d_ix = [ctx.dev_alloc(nfr * 8) for _ in bufs]
+            route = []
+            for b in range(nbuf):
+                if rep == 1 and b % 3 == 2:
+                    ctx.synchronize()               # a host that sometimes waits, sometimes runs ahead
+                api.frames_submit_d(ctx, sync, d_iq[b], bufs[b].size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr[b], None, d_ix[b])
+                route.append(ctx.sync_guard_auto()[1])
+            ctx.synchronize()
+            runs.append((route, [ctx.download(p, (nfr * npx,), np.uint32) for p in d_fr],
+                         [ctx.download(p, (nfr * 2,), np.int32) for p in d_ix], ctx.sync_guard_stats()))
+            sync.close()
+        finally:
+            ctx.close()
+    print("whole exact buffers after each submission:", runs[0][0], "guard counters", runs[0][3])
+    assert runs[0][0][-1] > 0, "the plateau leak should have switched the route"
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[3] == runs[0][3]
+        for x, y in zip(r[1] + r[2], runs[0][1] + runs[0][2]):
+            assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13])
