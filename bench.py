@@ -623,7 +623,10 @@ def main():
             ingest = {"note": "every buffer crosses PCIe: zero-copy producer publishes pre-filled pinned slots, H2D DMA of "
                               "buffer k+1 overlaps the kernels of buffer k (raster-free frame path)",
                       "cf32": ing.bench_ingest(ctx, tsdr, iq_host0, S, y_t, x_t, seconds=1.0, fmt="cf32"),
-                      "sc16": ing.bench_ingest(ctx, tsdr, iq_host0, S, y_t, x_t, seconds=1.0, fmt="sc16")}
+                      # int16 slots stay int16 in HBM: the frame kernels' loaders convert (tsdr_frames_sc16_d)
+                      "sc16": ing.bench_ingest(ctx, tsdr, iq_host0, S, y_t, x_t, seconds=1.0, fmt="sc16raw"),
+                      # the same slots expanded to ComplexF32 on the device first (rounds 1-4's route)
+                      "sc16_expanded": ing.bench_ingest(ctx, tsdr, iq_host0, S, y_t, x_t, seconds=0.5, fmt="sc16")}
         except Exception as e:
             ingest = {"error": f"{type(e).__name__}: {e}"}
 

@@ -320,6 +320,17 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
                          float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
                          int *sync_idx, int *n_frames);
 int tsdr_frames_flush(tsdr_ctx *ctx);
+/* tsdr_frames_d / tsdr_frames_submit_d on int16 I/Q -- what SDR hardware delivers and the producer of
+ * AtomicAbstractSDRs.jl:284-306 receives before its conversion: iq = nEch interleaved (int16 re, int16 im) pairs on the
+ * device; every sample is ComplexF32(re, im) * scale, formed in the kernels' loaders, so the int16 buffer is never
+ * expanded in HBM (half the IQ bytes the image kernel reads, half the PCIe bytes: tsdr_ring fmt 2).  Results are those of
+ * the ComplexF32 entry points on the converted samples, bit for bit. */
+int tsdr_frames_sc16_d(tsdr_ctx *ctx, tsdr_sync *sync, const int16_t *iq, float scale, size_t nEch, size_t S, int y_t, int x_t,
+                       float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx,
+                       int *n_frames);
+int tsdr_frames_submit_sc16_d(tsdr_ctx *ctx, tsdr_sync *sync, const int16_t *iq, float scale, size_t nEch, size_t S, int y_t,
+                              int x_t, float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
+                              int *sync_idx, int *n_frames);
 /* what the pipeline measured on this context (host-side, no synchronisation): *trials_left = candidate arrangements still to
  * be timed for the current configuration (0: settled, or nothing is measured); *chosen = index of the arrangement in use
  * (-1 while measuring); ms_per_buffer[c] = mean interval between the tails of successive buffers under candidate c (0: not
@@ -334,7 +345,9 @@ int tsdr_frames_pipeline_info(tsdr_ctx *ctx, int *trials_left, int *chosen, floa
  * except that the buffer lands on the device: the H2D DMA runs on the ring's own stream, and the DMA of the next
  * committed slot is started when a buffer is handed out, so it overlaps the kernels of the current one.
  * fmt 0: ComplexF32 slots (what recv! returns); fmt 1: interleaved int16 I/Q as SDR hardware delivers it (half
- * the PCIe bytes), expanded on the device to ComplexF32 * scale.  Counters as print_summary (:333-341). */
+ * the PCIe bytes), expanded on the device to ComplexF32 * scale; fmt 2: int16 slots that STAY int16 on the device --
+ * tsdr_ring_take_d then hands out nEch int16 pairs (cast the pointer) for tsdr_frames_sc16_d / _submit_sc16_d with the
+ * same scale, and nothing expands them.  Counters as print_summary (:333-341). */
 typedef struct tsdr_ring tsdr_ring;
 int tsdr_ring_create(tsdr_ctx *ctx, size_t nEch, int depth, int fmt, float scale, tsdr_ring **out);
 void tsdr_ring_free(tsdr_ring *r);

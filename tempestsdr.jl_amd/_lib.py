@@ -117,6 +117,8 @@ _SIGS = {
     "tsdr_frames_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_submit_d": (C.c_int, [vp, vp, vp, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_flush": (C.c_int, [vp]),
+    "tsdr_frames_sc16_d": (C.c_int, [vp, vp, vp, C.c_float, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
+    "tsdr_frames_submit_sc16_d": (C.c_int, [vp, vp, vp, C.c_float, c_sz, c_sz, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, c_i]),
     "tsdr_frames_pipeline_info": (C.c_int, [vp, c_i, c_i, c_f, C.c_int, C.c_char_p, c_sz]),
     "tsdr_ring_create": (C.c_int, [vp, c_sz, C.c_int, C.c_int, C.c_float, C.POINTER(vp)]),
     "tsdr_ring_free": (None, [vp]),

@@ -392,6 +392,17 @@ def frames_submit_d(ctx, sync, iq, nEch, S, y_t, x_t, alpha, do_align, state, fr
     return n.value
 
 
+def frames_sc16_d(ctx, sync, iq, scale, nEch, S, y_t, x_t, alpha, do_align, state, frames_out=None, raster_out=None, sync_idx=None,
+                  submit=False):
+    """frames_d / frames_submit_d on a device buffer of nEch interleaved int16 (re, im) pairs: every sample is
+    ComplexF32(re, im) * scale, formed in the kernels' loaders (tsdr_frames_sc16_d / tsdr_frames_submit_sc16_d)."""
+    n = C.c_int(0)
+    ctx.call("tsdr_frames_submit_sc16_d" if submit else "tsdr_frames_sc16_d", C.c_void_p(sync.h if sync is not None else 0), _ptr(iq),
+             C.c_float(scale), int(nEch), int(S), int(y_t), int(x_t), C.c_float(alpha), int(bool(do_align)), _ptr(state),
+             _ptr(frames_out), _ptr(raster_out), _ptr(sync_idx), C.byref(n))
+    return n.value
+
+
 def frames_flush(ctx):
     """Order the context's stream after every buffer submitted with frames_submit_d."""
     ctx.call("tsdr_frames_flush")
@@ -511,12 +522,13 @@ class Group:
 class StagingRing:
     """Pinned-host staging ring: the consumer side of AtomicCircularBuffer / recv!(buffer, csdr)
     (AtomicAbstractSDRs.jl:64-190, 320-322) with the buffer landing on the device.
-    fmt "cf32": ComplexF32 slots; "sc16": interleaved int16 I/Q, expanded on the device to ComplexF32 * scale."""
+    fmt "cf32": ComplexF32 slots; "sc16": interleaved int16 I/Q, expanded on the device to ComplexF32 * scale; "sc16raw": int16
+    slots that stay int16 on the device (take_d hands out int16 pairs for frames_sc16_d with the same scale)."""
 
     def __init__(self, ctx, nEch, depth=16, fmt="cf32", scale=1.0):
         self.ctx, self.nEch, self.depth, self.fmt = ctx, int(nEch), int(depth), fmt
         h = C.c_void_p(0)
-        ctx.call("tsdr_ring_create", self.nEch, self.depth, {"cf32": 0, "sc16": 1}[fmt], C.c_float(scale), C.byref(h))
+        ctx.call("tsdr_ring_create", self.nEch, self.depth, {"cf32": 0, "sc16": 1, "sc16raw": 2}[fmt], C.c_float(scale), C.byref(h))
         self.h = h.value
 
     def _chk(self, rc, what):

@@ -37,6 +37,11 @@ struct ProfRec {
   hipEvent_t e0, e1;
 };
 
+// How the frame kernels' loaders read one IQ sample: interleaved ComplexF32 (the reference's recv! buffers), or interleaved
+// int16 pairs as SDR hardware delivers them, turned into ComplexF32(re, im) * scale in the loader itself (tsdr_frames_sc16*:
+// int16 slots are never expanded in HBM -- half the IQ bytes the image kernel reads)
+struct IqFmt { int sc16 = 0; float scale = 1.0f; };
+
 struct TwTable {   // two-level table of W_N^e = exp(-2*pi*i*e/N), N = 2^logN
   int logN = 0, h = 0;
   float2 *lo = nullptr;  // W_N^j, j < 2^h
@@ -59,6 +64,7 @@ struct tsdr_ctx {
   std::string err;
   int cu_count = 0;
   int precision = TSDR_FAST;  // tsdr_precision
+  tsdr::IqFmt iq_fmt;         // set for the duration of a tsdr_frames_sc16* call
   // development switches (tsdr_set_option; environment variables of the same upper-case names are read ONCE, in tsdr_create)
   int opt_ac_mixed = 1;     // autocorrelation of n = 2*(2^a3^b5^c) samples: native mixed-radix route (0: zero-padded power of two)
   int opt_fft_no_mix2 = 0;  // 1: every mixed-radix factor through the generic LDS-stage kernel
@@ -256,6 +262,30 @@ __device__ inline float abs_c(float re, float im) {
   if (isinf(re) || isinf(im)) r = INFINITY;
   return r;
 }
+// one IQ sample of a frame's buffer (k in samples); sc16: the same product the ring's expansion kernel forms
+__device__ inline float2 ld_iq(const float *__restrict__ src, unsigned k, const IqFmt &f) {
+  if (f.sc16) {
+    const short2 v = reinterpret_cast<const short2 *>(src)[k];
+    return make_float2(__fmul_rn((float)v.x, f.scale), __fmul_rn((float)v.y, f.scale));
+  }
+  return reinterpret_cast<const float2 *>(src)[k];
+}
+// The same with the format fixed at compile time (IQF_CF32 / IQF_SC16: the FAST image kernels, whose register allocation and
+// instruction stream must not pay for the other format) or read from the launch's parameters (IQF_RT: every other reader)
+enum { IQF_CF32 = 0, IQF_SC16 = 1, IQF_RT = 2 };
+template <int IQF>
+__device__ inline float2 ld_iq_as(const float *__restrict__ src, unsigned k, const IqFmt &f) {
+  if (IQF == IQF_CF32) return reinterpret_cast<const float2 *>(src)[k];
+  if (IQF == IQF_SC16) {
+    const short2 v = reinterpret_cast<const short2 *>(src)[k];
+    return make_float2(__fmul_rn((float)v.x, f.scale), __fmul_rn((float)v.y, f.scale));
+  }
+  return ld_iq(src, k, f);
+}
+template <int IQF>
+__host__ __device__ inline size_t iq_floats_as(const IqFmt &f) { return IQF == IQF_CF32 ? 2 : IQF == IQF_SC16 ? 1 : (f.sc16 ? 1 : 2); }
+// floats per IQ sample in a buffer of that format (frame strides are counted in samples)
+__host__ __device__ inline size_t iq_floats(const IqFmt &f) { return f.sc16 ? 1 : 2; }
 __device__ inline float abs2_c(float re, float im) { return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)); }
 #endif
 

@@ -99,6 +99,7 @@ struct DownParams {
   float *proj = nullptr;        // per frame: colpart[row blocks][w_out] | rowpart[tiles_c][h_out]  (sync_layout.h)
   size_t proj_stride = 0;
   unsigned long long *keys = nullptr;
+  IqFmt iqf;                    // CPLX input: ComplexF32 or int16 pairs (common.h)
 };
 
 // DM_FAST_F32: f64 tap coordinates, f64 blends (any sample rate).  DM_FAST_FX (round 4; at most 0.5 samples per raster pixel):
@@ -134,7 +135,9 @@ __device__ inline float raster_tap_fast(double x, const void *row, int kf) {
 enum { DS_NONE = 0, DS_COLSUM = 1, DS_PSUM = 2 };
 // LD: staging loads in flight per lane and trip (4; 16 for wide rows -- a template parameter, not a run-time branch: the
 // kernel's register allocation is the maximum over its paths, and 24 more VGPRs cost the 4-load geometries 18 %)
-template <bool CPLX, int MODE, int NT, int SUMS = DS_NONE, int LD = 4>
+// IQF: how IQ samples are read (common.h): the EXACT body (also the sync guard's) takes the format from the parameters, the FAST
+// bodies have it fixed at compile time
+template <bool CPLX, int MODE, int NT, int SUMS = DS_NONE, int LD = 4, int IQF = (MODE == DM_EXACT ? IQF_RT : IQF_CF32)>
 __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, size_t in_stride, const DownParams &q,
                                        float *__restrict__ out, size_t out_stride, int tile_idx, int f, double *lds_dn,
                                        float *__restrict__ colpart = nullptr, float *colT = nullptr) {
@@ -149,7 +152,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
   int *kfirst = ckx + q.TC;                                                                           // [NL]
   const int tr = tile_idx / q.tiles_c, tc = tile_idx - tr * q.tiles_c;
   const int r0 = tr * 64, c0 = tc * q.TC;
-  const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
+  const float *src = in + (size_t)f * in_stride * (CPLX ? iq_floats_as<IQF>(q.iqf) : 1);
   const unsigned P = (unsigned)q.y_t * (unsigned)q.x_t;
   const RsAxis ax1 = rs_axis(q.S, P);
   const RsAxis ay = rs_axis((size_t)q.y_t, (size_t)q.h_out);
@@ -202,7 +205,7 @@ __device__ __forceinline__ void down_fused_body(const float *__restrict__ in, si
 #pragma unroll
           for (int u = 0; u < LD; ++u) {
             const unsigned k = (unsigned)min(max(kf[n] + min(jb + u * lpl, q.W - 1), 0), (int)q.S - 1);
-            if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[n][u] = z.x; im[n][u] = z.y; }
+            if (CPLX) { const float2 z = ld_iq_as<IQF>(src, k, q.iqf); re[n][u] = z.x; im[n][u] = z.y; }
             else { re[n][u] = src[k]; im[n][u] = 0.f; }
           }
         }

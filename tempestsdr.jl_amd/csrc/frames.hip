@@ -581,6 +581,34 @@ int tsdr_frames_pipeline_info(tsdr_ctx *ctx, int *trials_left, int *chosen, floa
   return TSDR_OK;
 }
 
+// ---- int16 I/Q input (what SDR hardware delivers, AtomicAbstractSDRs.jl:284-306 before its conversion): the same loop with
+// the ComplexF32(re, im) * scale conversion inside the kernels' loaders, so the int16 buffer is never expanded in HBM
+namespace {
+struct IqScope {
+  tsdr_ctx *ctx;
+  IqScope(tsdr_ctx *c, float scale) : ctx(c) { c->iq_fmt.sc16 = 1; c->iq_fmt.scale = scale; }
+  ~IqScope() { ctx->iq_fmt = tsdr::IqFmt{}; }
+};
+}  // namespace
+
+int tsdr_frames_sc16_d(tsdr_ctx *ctx, tsdr_sync *sync, const int16_t *iq, float scale, size_t nEch, size_t S, int y_t, int x_t,
+                       float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out, int *sync_idx,
+                       int *n_frames) {
+  if (!ctx) return TSDR_EINVAL;
+  IqScope fmt(ctx, scale);
+  return tsdr_frames_d(ctx, sync, reinterpret_cast<const float *>(iq), nEch, S, y_t, x_t, alpha, do_align, imageOut_state, frames_out,
+                       raster_out, sync_idx, n_frames);
+}
+
+int tsdr_frames_submit_sc16_d(tsdr_ctx *ctx, tsdr_sync *sync, const int16_t *iq, float scale, size_t nEch, size_t S, int y_t,
+                              int x_t, float alpha, int do_align, float *imageOut_state, float *frames_out, float *raster_out,
+                              int *sync_idx, int *n_frames) {
+  if (!ctx) return TSDR_EINVAL;
+  IqScope fmt(ctx, scale);
+  return tsdr_frames_submit_d(ctx, sync, reinterpret_cast<const float *>(iq), nEch, S, y_t, x_t, alpha, do_align, imageOut_state,
+                              frames_out, raster_out, sync_idx, n_frames);
+}
+
 int tsdr_frames_flush(tsdr_ctx *ctx) {
   if (!ctx) return TSDR_EINVAL;
   return pipe_drain(ctx);

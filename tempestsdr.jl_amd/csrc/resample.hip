@@ -33,9 +33,9 @@
 namespace tsdr {
 
 template <bool CPLX, bool EXACT>
-__device__ inline float load_sample(const float *__restrict__ src, unsigned k) {
+__device__ inline float load_sample(const float *__restrict__ src, unsigned k, const IqFmt &iqf) {
   if (CPLX) {
-    const float2 z = reinterpret_cast<const float2 *>(src)[k];
+    const float2 z = ld_iq(src, k, iqf);
     return abs_iq<EXACT>(z.x, z.y);
   }
   return src[k];
@@ -92,6 +92,7 @@ struct TileParams {
   float *proj;          // k_raster_fast<DOWN>: projection partial sums of the (h_out, w_out) images, or null
   size_t proj_stride;   // floats per frame: colpart[tiles_l][w_out] | rowpart[tiles_p][h_out]
   unsigned long long *keys;  // with proj: two vsync argmax keys per frame, cleared here for k_beta's atomicMax
+  IqFmt iqf;            // CPLX input: ComplexF32 or int16 pairs (common.h)
 };
 
 template <bool CPLX, bool DOWN>
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
   int tp = (int)u - f * q.tiles_p;
   if (tp < 0) { tp += q.tiles_p; --f; } else if (tp >= q.tiles_p) { tp -= q.tiles_p; ++f; }
   const int l0 = tl * q.own_l, p0 = tp * q.own_p;
-  const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
+  const float *src = in + (size_t)f * in_stride * (CPLX ? iq_floats(q.iqf) : 1);
   const unsigned P = (unsigned)q.y_t * (unsigned)q.x_t;
   const RsAxis ax = q.ax;
   const bool same = (q.S == P);
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
         for (int u = 0; u < 4; ++u) {
           const int j = jb + u * lpl;
           const unsigned k = min(kf + (unsigned)min(j, q.W - 1), q.S - 1u);
-          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[k]; re[u] = z.x; im[u] = z.y; }
+          if (CPLX) { const float2 z = ld_iq(src, k, q.iqf); re[u] = z.x; im[u] = z.y; }
           else { re[u] = src[k]; im[u] = 0.f; }
         }
 #pragma unroll
@@ -409,6 +410,13 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
   // (eight per chunk where the f32 walk has 32-pixel segments -- C2: 118.6-121.5 -> 111.7-113.0 us for the launch on one box;
   // C3 (16-pixel segments) and C5 (integer walk) measured 2 % better with four, 16 was no better than 8)
   constexpr int CH = (F32W && PW >= 32) ? 8 : PW >= 4 ? 4 : PW;
+  if (OUT) {
+    // (ob IS wave-uniform; saying so once keeps it, and everything added to it below, in scalar registers whatever the
+    // register allocator does with the values it was computed from -- store_saddr's "s" operand cannot take a VGPR pair)
+    const unsigned long long b = reinterpret_cast<unsigned long long>(ob);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    ob = reinterpret_cast<float *>(((unsigned long long)hi << 32) | (unsigned long long)lo);
+  }
   const float4 *row4 = reinterpret_cast<const float4 *>(rowv);
   const double2 *row2 = reinterpret_cast<const double2 *>(rowv);
   const float rstepf = (float)fa.rstep, Df = (float)fa.D;
@@ -508,7 +516,8 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
 // workgroups the halves reach L2 ~20 us apart, longer than a line survives there under this write stream, and are
 // written back as partial lines twice.  Stacking VW waves makes VW-1 of every VW seams internal to a workgroup.
 // REC4: the staged lines are plain f32 samples (fast_walk_full) instead of {a, slope hi, slope lo} records
-template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT, int VW, bool REC4 = false>
+// IQF: the REC4 instantiations (the hot ones) exist once per input format, the others read it from the parameters
+template <bool CPLX, bool F32W, bool DOWN, int PW, bool OUT, int VW, bool REC4 = false, int IQF = (REC4 ? IQF_CF32 : IQF_RT)>
 __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__restrict__ in, size_t in_stride, TileParams q,
                                                      FastAx fa, FastInc fi, float *__restrict__ out, size_t out_stride,
                                                      float *__restrict__ down, size_t down_stride) {
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
   int tp = (int)u - f * q.tiles_p;
   if (tp < 0) { tp += q.tiles_p; --f; } else if (tp >= q.tiles_p) { tp -= q.tiles_p; ++f; }
   const int l0 = tl * q.own_l, p0 = tp * q.own_p;
-  const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
+  const float *src = in + (size_t)f * in_stride * (CPLX ? iq_floats_as<IQF>(q.iqf) : 1);
   const int tid = threadIdx.x;
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int wave = wave_id & 3, wv = wave_id >> 2;  // horizontal segment, vertical position
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
         re[t] = 0.f; im[t] = 0.f;
         if (REC4 ? t < cs : t <= cs) {
           const unsigned ks = min(kf + (unsigned)min(jb + t, q.W - 1), q.S - 1u);
-          if (CPLX) { const float2 z = reinterpret_cast<const float2 *>(src)[ks]; re[t] = z.x; im[t] = z.y; }
+          if (CPLX) { const float2 z = ld_iq_as<IQF>(src, ks, q.iqf); re[t] = z.x; im[t] = z.y; }
           else re[t] = src[ks];
         }
       }
@@ -706,9 +715,9 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
 // direct variant (no LDS, EXACT arithmetic) for ratios the tiled kernel cannot stage; lanes along lines.
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__ in, size_t in_stride, unsigned S,
-                                                       int y_t, int x_t, float *__restrict__ out, size_t out_stride) {
+                                                       int y_t, int x_t, float *__restrict__ out, size_t out_stride, IqFmt iqf) {
   const int f = blockIdx.y;
-  const float *src = in + (size_t)f * in_stride * (CPLX ? 2 : 1);
+  const float *src = in + (size_t)f * in_stride * (CPLX ? iq_floats(iqf) : 1);
   const unsigned P = (unsigned)y_t * (unsigned)x_t;
   const RsAxis ax = rs_axis(S, P);
   const bool same = (S == P);
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__
     if (l >= y_t) continue;
     double d;
     const unsigned k = rs_pos(ax, (double)((unsigned)l * (unsigned)x_t + (unsigned)p + 1u), d);
-    const float a = load_sample<CPLX, true>(src, k), b = load_sample<CPLX, true>(src, k + 1u);
+    const float a = load_sample<CPLX, true>(src, k, iqf), b = load_sample<CPLX, true>(src, k + 1u, iqf);
     out[(size_t)f * out_stride + (size_t)p * y_t + l] = same ? (d == 1.0 ? b : a) : rs_blend(a, b, d);
   }
 }
@@ -730,7 +739,7 @@ __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__
 // grid = (tiles, frames)
 // (256 threads per 64 x 64-pixel tile: 512 threads measured 55.9 us, 512 threads on 64 x 128 58.5 us, 128 threads 70.4 us, against 54.3 us)
 constexpr int kDownNT = 256;
-template <bool CPLX, int MODE, int SUMS = DS_NONE, int LD = 4>
+template <bool CPLX, int MODE, int SUMS = DS_NONE, int LD = 4, int IQF = (MODE == DM_EXACT ? IQF_RT : IQF_CF32)>
 __global__ __launch_bounds__(kDownNT) void k_down_fused(const float *__restrict__ in, size_t in_stride, DownParams q,
                                                     float *__restrict__ out, size_t out_stride, size_t lds_main) {
   extern __shared__ double lds_dn[];
@@ -744,7 +753,7 @@ __global__ __launch_bounds__(kDownNT) void k_down_fused(const float *__restrict_
     tile = (int)(xcd * (unsigned)q.xcd_tpx + (sidx - (unsigned)f * (unsigned)q.xcd_tpx));
     if (tile >= q.xcd_tiles) return;
   }
-  down_fused_body<CPLX, MODE, kDownNT, SUMS, LD>(in, in_stride, q, out, out_stride, tile, f, lds_dn, nullptr,
+  down_fused_body<CPLX, MODE, kDownNT, SUMS, LD, IQF>(in, in_stride, q, out, out_stride, tile, f, lds_dn, nullptr,
                                          reinterpret_cast<float *>(reinterpret_cast<char *>(lds_dn) + lds_main));
 }
 
@@ -838,6 +847,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
                          (double)y_t / h_out >= 1.0 && (double)x_t / w_out >= 1.0;
   TileParams q{};
   q.S = (unsigned)S; q.y_t = y_t; q.x_t = x_t; q.frames = frames;
+  if (cplx) q.iqf = ctx->iq_fmt;
   // pairs of strips.  Measured on C2 -- round 2 (16-byte sample records, 3 workgroups per CU): G=1 0.138 ms, G=4 0.132 ms, G=41 0.146 ms;
   // round 4 (f32 samples, 4 per CU), the launch alone on two boxes: G=1 115.3, G=2 110.9 / 114.9, G=4 113.7 / 117.4, G=8 118.4, G=16 120.5 us
   // (C3: no difference; C5: G=2 1 % behind G=4).  The EXACT tile kernel (two workgroups per CU fewer) keeps four: 146.5 against 148.3 us
@@ -938,15 +948,19 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
                   dim3(256 * VWK), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);                   \
     }                                                                                                                 \
   } while (0)
-#define FASTK2R(W32, PW, VWK)                                                                                         \
+#define FASTK2RF(W32, PW, VWK, IQFK)                                                                                  \
   do {                                                                                                                \
     if (out) {                                                                                                        \
-      TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast<true, W32, true, PW, true, VWK, true>), grid, dim3(256 * VWK), lds, in,   \
+      TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast<true, W32, true, PW, true, VWK, true, IQFK>), grid, dim3(256 * VWK), lds, in,   \
                   in_stride, q, fa, fi, out, out_stride, down, down_stride);                                          \
     } else {                                                                                                          \
-      TSDR_LAUNCH(ctx, "down_walk_iq", (k_raster_fast<true, W32, true, PW, false, VWK, true>), grid, dim3(256 * VWK), lds, in,    \
+      TSDR_LAUNCH(ctx, "down_walk_iq", (k_raster_fast<true, W32, true, PW, false, VWK, true, IQFK>), grid, dim3(256 * VWK), lds, in,    \
                   in_stride, q, fa, fi, out, out_stride, down, down_stride);                                          \
     }                                                                                                                 \
+  } while (0)
+#define FASTK2R(W32, PW, VWK)                                                                                         \
+  do {                                                                                                                \
+    if (q.iqf.sc16) FASTK2RF(W32, PW, VWK, IQF_SC16); else FASTK2RF(W32, PW, VWK, IQF_CF32);                          \
   } while (0)
 #define FASTK1(C, W32, D, PW, NAME)                                                                                   \
   do {                                                                                                                \
@@ -974,6 +988,7 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
 #undef FASTK1
 #undef FASTK2
 #undef FASTK2R
+#undef FASTK2RF
 #undef FASTK
     return TSDR_OK;
   }
@@ -1018,10 +1033,10 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
   dim3 grid((unsigned)stream_grid(ctx, ceil_div((size_t)y_t, 64) * 64 * (size_t)x_t), (unsigned)frames);
   if (cplx) {
     TSDR_LAUNCH(ctx, "raster_direct_iq", (k_raster_direct<true>), grid, dim3(256), 0, in, in_stride, (unsigned)S, y_t, x_t,
-                out, out_stride);
+                out, out_stride, ctx->iq_fmt);
   } else {
     TSDR_LAUNCH(ctx, "raster_direct_f32", (k_raster_direct<false>), grid, dim3(256), 0, in, in_stride, (unsigned)S, y_t, x_t,
-                out, out_stride);
+                out, out_stride, IqFmt{});
   }
   return TSDR_OK;
 }
@@ -1111,6 +1126,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   const size_t P = (size_t)y_t * x_t;
   const bool exact = ctx->precision == TSDR_EXACT || !cplx;
   DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, exact, true);
+  if (cplx) pl.q.iqf = ctx->iq_fmt;
   if (pl.fused) {
     const bool psum = !exact && got != nullptr && (plan_only || (proj != nullptr && keys != nullptr));
     if (psum) {
@@ -1125,10 +1141,19 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
       grid = dim3((unsigned)(8 * pl.q.xcd_tpx * frames), 1);
     }
     const size_t lds_main = (pl.lds + 15) & ~(size_t)15;
-#define DOWNK(C, M, SUMS, NAME, LDS) \
-  TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS>), grid, dim3(kDownNT), LDS, in, in_stride, pl.q, out, out_stride, lds_main)
-#define DOWNK16(C, M, SUMS, NAME, LDS) \
-  TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS, 16>), grid, dim3(kDownNT), LDS, in, in_stride, pl.q, out, out_stride, lds_main)
+  // (the FAST kernels exist once per input format -- ComplexF32 or int16 pairs -- the EXACT one reads either)
+#define DOWNKL(C, M, SUMS, LDN, NAME, LDS)                                                                                         \
+  do {                                                                                                                             \
+    if (M != DM_EXACT && pl.q.iqf.sc16) {                                                                                          \
+      TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS, LDN, (M == DM_EXACT ? IQF_RT : IQF_SC16)>), grid, dim3(kDownNT), LDS, in,   \
+                  in_stride, pl.q, out, out_stride, lds_main);                                                                     \
+    } else {                                                                                                                       \
+      TSDR_LAUNCH(ctx, NAME, (k_down_fused<C, M, SUMS, LDN>), grid, dim3(kDownNT), LDS, in, in_stride, pl.q, out, out_stride,     \
+                  lds_main);                                                                                                       \
+    }                                                                                                                              \
+  } while (0)
+#define DOWNK(C, M, SUMS, NAME, LDS) DOWNKL(C, M, SUMS, 4, NAME, LDS)
+#define DOWNK16(C, M, SUMS, NAME, LDS) DOWNKL(C, M, SUMS, 16, NAME, LDS)
     const size_t lds_ps = lds_main + (kDownNT + (size_t)pl.q.TC) * 4;
     if (cplx) {
       if (pl.mode == DM_EXACT) { DOWNK(true, DM_EXACT, DS_NONE, "down_fused_iq_exact", pl.lds); }
@@ -1150,6 +1175,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
     }
 #undef DOWNK16
 #undef DOWNK
+#undef DOWNKL
     return TSDR_OK;
   }
   if (plan_only) return TSDR_OK;
@@ -1159,7 +1185,7 @@ int down_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, si
   if (!ras) return TSDR_ENOMEM;
   ras += (size_t)(ctx->pipe_lane & 3) * P;
   for (int f = 0; f < frames; ++f) {
-    rc = raster_frames_d(ctx, in + (size_t)f * in_stride * (cplx ? 2 : 1), cplx, in_stride, S, y_t, x_t, 1, ras, P);
+    rc = raster_frames_d(ctx, in + (size_t)f * in_stride * (cplx ? iq_floats(ctx->iq_fmt) : 1), cplx, in_stride, S, y_t, x_t, 1, ras, P);
     if (rc) return rc;
     rc = resize2d_d(ctx, ras, y_t, x_t, h_out, w_out, out + (size_t)f * out_stride);
     if (rc) return rc;
@@ -1174,6 +1200,7 @@ bool guard_image_plan(tsdr_ctx *ctx, size_t S, int y_t, int x_t, int h_out, int 
   if ((y_t == h_out && x_t == w_out) || y_t < 2 || x_t < 2) return false;
   DownPlan pl = plan_down(S, y_t, x_t, h_out, w_out, /*exact=*/true, false, /*guard_tiles=*/true);
   if (!pl.fused) return false;
+  pl.q.iqf = ctx->iq_fmt;
   *q = pl.q;
   *lds = pl.lds;
   return true;
@@ -1212,7 +1239,7 @@ int raster_and_down_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride
   // FAST with a raster (option "raster_split"; A/B of round 4): the rasters by the store-aligned ("sheared") raster-only
   // kernel of raster_shear.hip, the images + projection sums by the raster-free kernel -- two launches, IQ read twice,
   // instead of the one walk that produces raster, image and sums with misaligned column stores
-  if (raster && ctx->precision == TSDR_FAST && cplx && ctx->opt_raster_split) {
+  if (raster && ctx->precision == TSDR_FAST && cplx && ctx->opt_raster_split && !ctx->iq_fmt.sc16) {   // (the A/B kernel reads ComplexF32 only)
     const DownPlan dp = plan_down(S, y_t, x_t, h_out, w_out, false);
     const double spp = (double)S / ((double)y_t * (double)x_t);
     if (dp.fused && dp.q.TC >= 32 && spp <= 0.5 && !(y_t == h_out && x_t == w_out) && check_geom(ctx, S, y_t, x_t) == TSDR_OK && y_t >= 64 && x_t >= 128) {

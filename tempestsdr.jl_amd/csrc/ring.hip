@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_sc16_to_cf32(const short2 *__restrict__
 static int ring_stage(tsdr_ring *r, int slot, int d) {
   tsdr_ctx *ctx = r->ctx;
   const char *src = r->host + (size_t)slot * r->slot_bytes;
-  if (r->fmt == 0) {
+  if (r->fmt == 0 || r->fmt == 2) {   // (2: the int16 pairs stay int16 on the device -- tsdr_frames_sc16_d reads them as they are)
     TSDR_HIP(ctx, hipMemcpyAsync(r->dev[d], src, r->slot_bytes, hipMemcpyHostToDevice, r->copy));
   } else {
     TSDR_HIP(ctx, hipMemcpyAsync(r->raw[d], src, r->slot_bytes, hipMemcpyHostToDevice, r->copy));
@@ -85,7 +85,7 @@ using namespace tsdr;
 extern "C" {
 
 int tsdr_ring_create(tsdr_ctx *ctx, size_t nEch, int depth, int fmt, float scale, tsdr_ring **out) {
-  if (!ctx || !out || nEch == 0 || depth < 2 || (fmt != 0 && fmt != 1)) return TSDR_EINVAL;
+  if (!ctx || !out || nEch == 0 || depth < 2 || fmt < 0 || fmt > 2) return TSDR_EINVAL;
   *out = nullptr;
   tsdr_ring *r = new tsdr_ring();
   r->ctx = ctx; r->nEch = nEch; r->depth = depth; r->fmt = fmt; r->scale = scale;

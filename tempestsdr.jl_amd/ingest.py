@@ -12,12 +12,17 @@ import numpy as np
 from . import api
 
 
-def stream_frames(ctx, ring, sync, n_buffers, nEch, S, y_t, x_t, alpha, state, frames_out, sync_idx, timeout_ms=10000):
-    """Consumer loop: take a device buffer from the ring, run the frame path on it, repeat.  Returns frames done."""
+def stream_frames(ctx, ring, sync, n_buffers, nEch, S, y_t, x_t, alpha, state, frames_out, sync_idx, timeout_ms=10000,
+                  sc16_scale=None):
+    """Consumer loop: take a device buffer from the ring, run the frame path on it, repeat.  Returns frames done.
+    sc16_scale: the ring hands out int16 pairs (fmt "sc16raw"), which the frame kernels convert in their loaders."""
     done = 0
     for _ in range(n_buffers):
         d_iq = ring.take_d(timeout_ms)
-        done += api.frames_d(ctx, sync, d_iq, nEch, S, y_t, x_t, alpha, True, state, frames_out, None, sync_idx)
+        if sc16_scale is None:
+            done += api.frames_d(ctx, sync, d_iq, nEch, S, y_t, x_t, alpha, True, state, frames_out, None, sync_idx)
+        else:
+            done += api.frames_sc16_d(ctx, sync, d_iq, sc16_scale, nEch, S, y_t, x_t, alpha, True, state, frames_out, None, sync_idx)
     return done
 
 
@@ -28,7 +33,7 @@ def bench_ingest(ctx, tsdr, iq_host, S, y_t, x_t, seconds=1.0, depth=4, fmt="cf3
     npx = tsdr.RENDER_H * tsdr.RENDER_W
     nb = nEch // S
     scale = 1.0
-    if fmt == "sc16":
+    if fmt in ("sc16", "sc16raw"):
         peak = float(np.max(np.abs(iq_host.view(np.float32)))) or 1.0
         scale = peak / 2047.0
         src = np.round(iq_host.view(np.float32) / scale).astype(np.int16)
@@ -63,7 +68,8 @@ def bench_ingest(ctx, tsdr, iq_host, S, y_t, x_t, seconds=1.0, depth=4, fmt="cf3
     n_done = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        n_done += stream_frames(ctx, ring, sync, 4, nEch, S, y_t, x_t, np.float32(0.1), state, frames_out, sync_idx)
+        n_done += stream_frames(ctx, ring, sync, 4, nEch, S, y_t, x_t, np.float32(0.1), state, frames_out, sync_idx,
+                                sc16_scale=scale if fmt == "sc16raw" else None)
     ctx.synchronize()
     dt = time.perf_counter() - t0
     stop.set()

@@ -19,7 +19,7 @@ export sig_to_image, downgradeImage, naiveResampler, init_resampler
 export calculate_autocorrelation, zoom_autocorr
 export getSpectrum, getWelch, getWaterfall
 export SyncXY, vsync
-export hip_frames!, hip_frames_submit!, hip_frames_flush, hip_synchronize   # fused GUI.jl:163-178 loop body (optional fast path; pipelined form)
+export hip_frames!, hip_frames_submit!, hip_frames_submit_sc16!, hip_frames_flush, hip_synchronize   # fused GUI.jl:163-178 loop body (optional fast path; pipelined form)
 export hip_extract_configuration, sync_guard_stats, sync_guard_auto   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
 export hip_set_precision, hip_set_option                              # TSDR_EXACT / TSDR_FAST and the library's options, per task context
 export HipGroup, hip_group                                            # one process, several GPUs (RCCL inside the library): `devices = ...`
@@ -229,6 +229,21 @@ function hip_frames_submit!(d_imageOut::Ptr{Cvoid}, d_sigId::Ptr{Cvoid}, nEch::I
                         sync.c.h, sync.h, d_sigId, nEch, S, y_t, x_t, α, do_align ? 1 : 0, d_imageOut, d_frames, d_raster, d_idx, n), "hip_frames_submit!")
     return Int(n[])
 end
+"""
+    hip_frames_submit_sc16!(d_imageOut, d_sigId16, scale, nEch, sync, S, y_t, x_t, α; d_frames, ...) -> nb
+
+`hip_frames_submit!` on a device buffer of `nEch` interleaved `Int16` (re, im) pairs -- what SDR hardware delivers, e.g. the
+slots of a `HipRing(...; sc16 = true, raw = true)`: every sample is `ComplexF32(re, im) * scale`, formed in the kernels'
+loaders, so the buffer is never expanded in HBM (`tsdr_frames_submit_sc16_d`).
+"""
+function hip_frames_submit_sc16!(d_imageOut::Ptr{Cvoid}, d_sigId16::Ptr{Cvoid}, scale::Float32, nEch::Integer, sync::SyncXY{Float32}, S, y_t, x_t, α::Float32;
+                                 d_frames::Ptr{Cvoid}, d_raster::Ptr{Cvoid} = C_NULL, d_idx::Ptr{Cvoid} = C_NULL, do_align = true)
+    n = Ref{Cint}(0)
+    check(sync.c, ccall((:tsdr_frames_submit_sc16_d, LIB), Cint,
+                        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cfloat, Csize_t, Csize_t, Cint, Cint, Cfloat, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
+                        sync.c.h, sync.h, d_sigId16, scale, nEch, S, y_t, x_t, α, do_align ? 1 : 0, d_imageOut, d_frames, d_raster, d_idx, n), "hip_frames_submit_sc16!")
+    return Int(n[])
+end
 hip_frames_flush() = (c = ctx(); check(c, ccall((:tsdr_frames_flush, LIB), Cint, (Ptr{Cvoid},), c.h), "hip_frames_flush"))
 hip_synchronize() = (c = ctx(); check(c, ccall((:tsdr_synchronize, LIB), Cint, (Ptr{Cvoid},), c.h), "hip_synchronize"))
 
@@ -422,10 +437,10 @@ mutable struct HipRing
     nEch::Int
     sc16::Bool
 end
-function HipRing(c::Ctx, nEch::Integer; depth = 16, sc16 = false, scale = 1f0)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
+function HipRing(c::Ctx, nEch::Integer; depth = 16, sc16 = false, raw = false, scale = 1f0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)   # raw: the Int16 slots stay Int16 on the device (for hip_frames_submit_sc16!)
     check(c, ccall((:tsdr_ring_create, LIB), Cint, (Ptr{Cvoid}, Csize_t, Cint, Cint, Cfloat, Ptr{Ptr{Cvoid}}),
-                   c.h, nEch, depth, sc16 ? 1 : 0, scale, h), "HipRing")
+                   c.h, nEch, depth, sc16 ? (raw ? 2 : 1) : 0, scale, h), "HipRing")
     r = HipRing(c, h[], nEch, sc16)
     finalizer(r) do x
         x.c.h != C_NULL && ccall((:tsdr_ring_free, LIB), Cvoid, (Ptr{Cvoid},), x.h)
