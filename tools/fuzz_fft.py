@@ -8,6 +8,9 @@ from tempest_loader import load_package
 T = load_package()
 import oracle_lib as O
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+PCT = int(sys.argv[2]) if len(sys.argv) > 2 else 100     # percentage of the case counts below (tests/test_fuzz_gpu.py runs a subset)
+PCT = min(PCT, 100)
+def cases(n): return max(1, n * PCT // 100)
 ctx = T.Context()
 def relmax(g, w):
     w = np.asarray(w); return float(np.max(np.abs(np.asarray(g, dtype=w.dtype) - w)) / np.max(np.abs(w)))
@@ -17,7 +20,7 @@ def smooth(maxn):
         n = (2 ** int(a)) * (3 ** int(b)) * (5 ** int(c))
         if 2 <= n <= maxn: return int(n)
 worst = 0.0
-for it in range(60):
+for it in range(cases(60)):
     n = smooth(6_000_000) if it % 3 else int(rng.integers(2, 200_000))
     batch = 1 if n > 100_000 else int(rng.integers(1, 4))
     x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
@@ -25,11 +28,11 @@ for it in range(60):
         ref = (np.fft.ifft if inv else np.fft.fft)(x.astype(np.complex128), axis=1)
         e = relmax(ctx.fft(x if batch > 1 else x[0], inverse=inv), ref if batch > 1 else ref[0]); worst = max(worst, e)
         assert e < 1e-5, (n, batch, inv, e)
-print("fft: 60 lengths ok, worst", worst)
+print(f"fft: {cases(60)} lengths ok, worst", worst)
 worst = 0.0
 for mixed in (0, 1):
     ctx.set_option("ac_mixed", mixed)
-    for it in range(12):
+    for it in range(cases(12)):
         n = 2 * smooth(1_000_000) if it % 2 else int(rng.integers(1500, 500_000))
         x = (rng.random(n) ** 2).astype(np.float32) * 1e-5
         Fs = 1e6; maxd = (n // 2) / Fs
@@ -40,12 +43,12 @@ for mixed in (0, 1):
         o, _ = O.calculate_autocorrelation(x, Fs, mind, maxd, "lin")
         e = relmax(g, o); worst = max(worst, e)
         assert g.shape == o.shape and e < 4e-5, (n, mixed, e)
-print("autocorr: 24 cases ok, worst", worst)
+print(f"autocorr: {2 * cases(12)} cases ok, worst", worst)
 
 # the fused search (lags + zoom window + findmax in one call) on random lengths / windows, real and IQ input
 ctx.set_option("ac_mixed", 1)
 worst = 0.0
-for it in range(16):
+for it in range(cases(16)):
     n = 2 * smooth(2_500_000) if it % 4 else int(rng.integers(20_000, 600_000))
     if n < 20_000: n = 2 * 3 ** 9
     Fs = float(rng.choice([1e6, 2e6, 20e6]))
@@ -71,11 +74,11 @@ for it in range(16):
     if zw.size:
         want = int(np.argmax(zw))                     # first maximum, like findmax
         assert pos == want and val == zw[want], ("search findmax", n, cplx, pos, want, val, float(zw[want]))
-print("search: 16 cases ok, worst |dB| diff", worst)
+print(f"search: {cases(16)} cases ok, worst |dB| diff", worst)
 
 # resampler!: random (bufferSize, upCoeff) incl. odd sizes (full-size route), 4096-point fast path, large primes
 worst = 0.0
-for it in range(14):
+for it in range(cases(14)):
     up = int(rng.choice([1, 2, 3, 4, 5, 8]))
     nb = [int(rng.integers(4, 3000)), 4096 // up if 4096 % up == 0 else 1024, 2 * smooth(300_000), smooth(200_000) | 1,
           int(rng.integers(3000, 120_000))][it % 5]
@@ -87,4 +90,4 @@ for it in range(14):
     e = float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)); worst = max(worst, e)
     assert e < 8e-6, ("resampler", nb, up, e)
     r.close()
-print("resampler: 14 cases ok, worst", worst)
+print(f"resampler: {cases(14)} cases ok, worst", worst)

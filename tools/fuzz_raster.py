@@ -7,11 +7,13 @@ from tempest_loader import load_package
 T = load_package()
 import oracle_lib as O
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+PCT = int(sys.argv[2]) if len(sys.argv) > 2 else 100     # percentage of the case counts below (tests/test_fuzz_gpu.py runs a subset)
+def cases(n): return max(1, n * PCT // 100)
 ctx = T.Context()
 def relerr(g, w):
     w = np.asarray(w, np.float64); return float(np.max(np.abs(np.asarray(g, np.float64) - w) / np.maximum(np.abs(w), 1e-30)))
 worst = 0.0
-for it in range(40):
+for it in range(cases(40)):
     y_t = int(rng.integers(20, 1400)); x_t = int(rng.integers(30, 3000))
     ratio = float(np.exp(rng.uniform(np.log(0.05), np.log(3.0))))
     S = max(2, int(y_t * x_t * ratio))
@@ -19,9 +21,9 @@ for it in range(40):
     e = relerr(ctx.sig_to_image(sig, y_t, x_t), O.sig_to_image(sig, y_t, x_t))
     worst = max(worst, e)
     assert e < 1e-6, (S, y_t, x_t, e)
-print("sig_to_image: 40 geometries ok, worst", worst)
+print(f"sig_to_image: {cases(40)} geometries ok, worst", worst)
 worst = 0.0
-for it in range(16):
+for it in range(cases(16)):
     y_t = int(rng.integers(130, 1300)); x_t = int(rng.integers(260, 2800)); nfr = int(rng.integers(1, 4))
     ratio = float(np.exp(rng.uniform(np.log(0.08), np.log(1.6))))
     S = max(2, int(y_t * x_t * ratio))
@@ -38,12 +40,12 @@ for it in range(16):
             if want_raster:
                 e = relerr(g["raster"][f], o["raster"][f]); worst = max(worst, e)
                 assert e < 1e-6, (S, y_t, x_t, f, e)
-print("frames: 16 geometries x 2 ok, worst", worst)
+print(f"frames: {cases(16)} geometries x 2 ok, worst", worst)
 
 # EXACT mode: bit-identical rasters, frames, state and indices on random geometries
 ctx.set_precision("exact")
 beq = lambda a, b: np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
-for it in range(10):
+for it in range(cases(10)):
     y_t = int(rng.integers(20, 1300)); x_t = int(rng.integers(30, 2800)); nfr = int(rng.integers(1, 3))
     ratio = float(np.exp(rng.uniform(np.log(0.08), np.log(1.6))))
     S = max(2, int(y_t * x_t * ratio))
@@ -57,5 +59,5 @@ for it in range(10):
         for f in range(nfr):
             assert beq(g["frames"][f], o["frames"][f]), (S, y_t, x_t, f, want_raster)
             assert not want_raster or beq(g["raster"][f], o["raster"][f]), (S, y_t, x_t, f)
-print("exact frames: 10 geometries x 2 bit-identical")
+print(f"exact frames: {cases(10)} geometries x 2 bit-identical")
 ctx.set_precision("fast")
