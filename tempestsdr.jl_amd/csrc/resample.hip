@@ -392,14 +392,28 @@ __device__ inline void down_event(DownInfo &di, int j, float R00, float R01) {
 // REC4 (F32W only): the row holds plain samples; a pixel is ((D - r) a + r b) / D with both weights exact integers in f32 --
 // the convex form, so that each term carries a relative error whatever r is (see DM_FAST_FX in down_fused.h) -- four
 // instructions instead of two, for a quarter of the LDS: what lets C3's wide tiles (39 samples x 127 lines) share a CU.
+// (round 5: the division by D is in the staged samples -- a' = a / D once per sample instead of once per pixel, 0.115 samples per
+// pixel at C2 -- so a pixel is three instructions: (D - r) a' + r b')
+#ifndef TSDR_NO_PRESCALE
+__device__ __forceinline__ float rec4_pixel(float ref, float Df, float invD, float2 s) {
+  return __fmaf_rn(ref, s.y, __fmul_rn(__fsub_rn(Df, ref), s.x));
+}
+#else
 __device__ __forceinline__ float rec4_pixel(float ref, float Df, float invD, float2 s) {
   return __fmul_rn(__fmaf_rn(ref, s.y, __fmul_rn(__fsub_rn(Df, ref), s.x)), invD);
 }
+#endif
 // (the integer walk, D >= 2^24: the weights are conversions of the two integers -- relative error 2^-24 each, which is all the
 // convex form needs)
+#ifndef TSDR_NO_PRESCALE
+__device__ __forceinline__ float rec4_pixel_u(unsigned r, unsigned D, float invD, float2 s) {
+  return __fmaf_rn((float)r, s.y, __fmul_rn((float)(D - r), s.x));
+}
+#else
 __device__ __forceinline__ float rec4_pixel_u(unsigned r, unsigned D, float invD, float2 s) {
   return __fmul_rn(__fmaf_rn((float)r, s.y, __fmul_rn((float)(D - r), s.x)), invD);
 }
+#endif
 __device__ __forceinline__ float2 rec4_read(const float *row, int kk) { return make_float2(row[kk], row[kk + 1]); }
 
 template <bool F32W, bool OUT, bool DOWNR, int PW, bool REC4 = false>
@@ -592,7 +606,11 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
       for (int t = 0; t < 4; ++t) {
         const int j = jb + t;
         if (REC4) {
+#ifndef TSDR_NO_PRESCALE
+          if (t < cs && j < q.W) smp1[r * Wp + j] = __fmul_rn(a[t], fi.invD);
+#else
           if (t < cs && j < q.W) smp1[r * Wp + j] = a[t];
+#endif
         } else if (t < cs && j < q.W) {
           const double sl = ((double)a[t + 1] - (double)a[t]) * fa.invDd;
           if (F32W) {

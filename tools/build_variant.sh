@@ -11,6 +11,6 @@ for f in "$TMP"/tempestsdr.jl_amd/csrc/*.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -w -c "$f" -o "$TMP/obj/$(basename "$f" .hip).o" &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o -L/opt/rocm/lib -lrccl
 rm -rf "$TMP"
 ls -la "$ROOT/ab/$NAME.so"

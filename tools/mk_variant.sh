@@ -12,5 +12,5 @@ if cmp -s "$TMP/tempestsdr.jl_amd/csrc/$FILE" "$ROOT/tempestsdr.jl_amd/csrc/$FIL
 # only the edited file is recompiled; the rest comes from the in-tree build
 cp "$ROOT"/tempestsdr.jl_amd/build/*.o "$TMP/obj/"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -w "$@" -c "$TMP/tempestsdr.jl_amd/csrc/$FILE" -o "$TMP/obj/$(basename "$FILE" .hip).o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o -L/opt/rocm/lib -lrccl
 rm -rf "$TMP"; ls -la "$ROOT/ab/$NAME.so"

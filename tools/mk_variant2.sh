@@ -14,5 +14,5 @@ for u in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -w $EXTRA_FLAGS -c "$TMP/tempestsdr.jl_amd/csrc/$u" -o "$TMP/obj/$(basename "$u" .hip).o" &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/$NAME.so" "$TMP"/obj/*.o -L/opt/rocm/lib -lrccl
 rm -rf "$TMP"; ls -la "$ROOT/ab/$NAME.so"
