@@ -8,16 +8,8 @@ O=$R/gpurun_out
 mkdir -p $O
 python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python3 $R/bench.py --quick --pipeline on > $O/${TAG}_bench_c2_pipeline.json 2>/dev/null
-# round 4: kernel traces of the pipelined loop (do the image launch and the previous buffer's tail overlap?), the raster
-# kernel's store-alignment A/B (option raster_split: 0 = one-launch walk, 1 = sheared raster-only + raster-free, 2 = unsheared)
+# kernel traces of the pipelined loop in the arrangement the library measured fastest (do the launches overlap?)
 $R/tools/prof_pipeline.sh $TAG > /dev/null 2>&1
-$R/tools/ab_env2.sh TSDR_RASTER_SPLIT "0 1 2" > $O/${TAG}_raster_split_ab.txt 2>/dev/null
-for v in 1 2; do
-  rm -rf $O/${TAG}_split$v
-  TSDR_RASTER_SPLIT=$v rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_split$v -o run -- python3 $R/bench.py --quick --no-pipeline-leg --steps 20 --repeats 2 > /dev/null 2>&1
-  cp $(find $O/${TAG}_split$v -name '*kernel_stats.csv' | head -1) $O/${TAG}_kernel_stats_raster_split$v.csv
-  rm -rf $O/${TAG}_split$v
-done
 $R/tools/calib_fetch.sh $TAG > /dev/null 2>&1
 rm -rf $O/${TAG}_stats $O/${TAG}_pmc_*
 # (the legs that run launches of two streams side by side -- `pipeline`, `two_streams` -- are left out of the profiled command:
@@ -42,6 +34,19 @@ for leg in welch waterfall welch_1000 spectrum resampler_1024x4 resampler_100000
   python3 $R/tools/make_traffic.py --spectra $leg $CALLS $O/${TAG}_pmcs_${leg}_FETCH_SIZE $O/${TAG}_pmcs_${leg}_WRITE_SIZE $TAG >> $O/${TAG}_traffic_spectra.txt
   rm -rf $O/${TAG}_pmcs_${leg}_FETCH_SIZE $O/${TAG}_pmcs_${leg}_WRITE_SIZE
 done
+# round 5: (a) SQ counters of the configuration search's FFT passes (what bounds each pass: VALU / LDS activity, waits);
+# (b) the spectrum-path timing tools' outputs; (c) the pipeline against one call per buffer with K idle streams created first,
+# hard-wired arrangement (TSDR_PIPE_TUNE=0: rounds 3-4) and measured one -- the hardware-queue dependence and its cure
+$R/tools/pmc_search.sh k_fft > $O/${TAG}_sq_search.txt 2>&1
+for t in time_fft_rows time_welch_sizes time_waterfall_sizes; do
+  timeout 600 python3 $R/tools/$t.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_$t.txt
+done
+{
+for k in 0 1 5 6; do for tune in 0 1; do
+  echo "== $k idle streams created first, TSDR_PIPE_TUNE=$tune"
+  DUMMY_STREAMS=$k TSDR_PIPE_TUNE=$tune timeout 300 python3 $R/tools/time_pipeline.py 200 C2 2>&1 | grep "pipeline=\|measured"
+done; done
+} > $O/${TAG}_queue_probe.txt 2>&1
 cp $R/profiles/traffic.json $O/${TAG}_traffic_full.json   # (the box's copy: C2 frame kernels + search + spectra legs of this tag)
 # the bench line once more, now that this tag's traffic file is in place (its `traffic` fields are read from it)
 python3 $R/bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err

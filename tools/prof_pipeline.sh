@@ -1,12 +1,12 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel trace of the pipelined frame loop (raster-free, then raster) -> gpurun_out/<tag>_pipe_trace_*
-TAG=${1:-r04_x}
+TAG=${1:-r05_x}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 for mode in fused raster; do
   extra=""; [ $mode = fused ] && extra="--no-raster"
   rm -rf $O/${TAG}_pipe_$mode
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pipe_$mode -o run -- python3 $R/bench.py --quick --pipeline on $extra --steps 20 --warmup 5 --repeats 2 > $O/${TAG}_pipe_${mode}_bench.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pipe_$mode -o run -- python3 $R/bench.py --quick --pipeline on $extra --steps 300 --warmup 5 --repeats 2 > $O/${TAG}_pipe_${mode}_bench.json 2>/dev/null
   f=$(find $O/${TAG}_pipe_$mode -name '*kernel_trace.csv' | head -1)
   python3 $R/tools/trace_overlap.py $f shift_iir > $O/${TAG}_pipe_${mode}_overlap.txt
   cat $O/${TAG}_pipe_${mode}_overlap.txt
@@ -22,7 +22,7 @@ for r in rows:
     w.writerow([r["Queue_Id"], int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Kernel_Name"].split("(")[0].replace("void ", "")])
 PY
   rm -rf $O/${TAG}_pipe_$mode
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pipe_$mode -o run -- python3 $R/bench.py --quick --pipeline on $extra --steps 20 --warmup 5 --repeats 2 > $O/${TAG}_pipe_${mode}_bench.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_pipe_$mode -o run -- python3 $R/bench.py --quick --pipeline on $extra --steps 300 --warmup 5 --repeats 2 > $O/${TAG}_pipe_${mode}_bench.json 2>/dev/null
   f=$(find $O/${TAG}_pipe_$mode -name '*kernel_trace.csv' | head -1)
   python3 $R/tools/trace_overlap.py $f shift_iir > $O/${TAG}_pipe_${mode}_overlap.txt
   cat $O/${TAG}_pipe_${mode}_overlap.txt
