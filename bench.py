@@ -607,6 +607,38 @@ def main():
     except Exception as e:  # the frame number above stays valid; say what failed
         search = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- the multi-GPU split behind the C ABI (tsdr_group_*: one process, one context + one RCCL communicator per device).
+    # At N = 1 the group has this process's one device: the search through the root-alone route and through the sharded
+    # route (segment + halo partial sums, a ONE-rank ncclAllReduce of indexMax f32 inside the library, the non-linear step
+    # after it) -- the RCCL path on this box's hardware, from host memory like the Julia shim calls it (PCIe included)
+    group = None
+    if solo and not args.no_extra:
+        try:
+            g = tsdr.Group([local_rank])
+            try:
+                z = main_leg.iq_host[0][:n_ac]
+                G0, p0, _ = ctx.autocorr_search(z, Fs, 0.0, 0.1, 50, 90)
+                out = {}
+                for route in ("root", "sharded"):
+                    g.autocorr_search(z, Fs, 0.0, 0.1, 50, 90, route=route)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        Gg, pg, _ = g.autocorr_search(z, Fs, 0.0, 0.1, 50, 90, route=route)
+                    dt = (time.perf_counter() - t0) / 3
+                    r, ms = g.timing()
+                    out[route] = {"ms_per_search_from_host_memory": round(dt * 1e3, 3), "route_taken": r,
+                                  "ms_stages_on_root_stream": {"upload_and_member_stage": round(ms[0], 4), "collective": round(ms[1], 4),
+                                                               "root_final_stage": round(ms[2], 4)},
+                                  "same_argmax_as_single_context": bool(pg == p0),
+                                  "max_abs_dB_diff_vs_single_context": float(np.max(np.abs(Gg - G0)))}
+                group = {"devices": [local_rank], "all_reduce_bytes": 4 * k_hi, "search": out,
+                         "note": "tsdr_group_search on a one-device group: what a single-process runtime (the reference's) calls; N > 1 "
+                                 "members need a multi-GPU box (tests/test_group_gpu.py, skipped on 1-GPU boxes)"}
+            finally:
+                g.close()
+        except Exception as e:
+            group = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- N > 1: ONE capture buffer sharded through HipFrames (strong scaling of the loop GUI.jl:165-178)
     strong = None
     if world > 1:
@@ -758,7 +790,7 @@ def main():
             "kernels_ms_per_step_note": "per-launch HIP-event brackets from a separate run of the same steps: each bracket adds ~3 us, so "
                                         "their sum exceeds ms_per_step",
             "roofline": roofline, "sync_margin": margins, "index_parity": parity, "fused": fused, "pipeline": pipeline, "two_streams": two, "cpu_baseline": cpu, "search": search,
-            "strong": strong, "host_ingest": ingest, "spectra": spectra,
+            "strong": strong, "group": group, "host_ingest": ingest, "spectra": spectra,
         }
         line.update(extra)
         line["device"] = info["name"]

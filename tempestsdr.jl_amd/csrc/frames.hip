@@ -250,9 +250,10 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
   float *img = (float *)ctx->scratch(WS_IMG, (nb ? nb : 1) * npx * 4);
   unsigned long long *keys = (unsigned long long *)ctx->scratch(WS_KEYS, (nb ? nb : 1) * 2 * 8);
   if (!img || !keys) return TSDR_ENOMEM;
-  // (Tried and dropped, MI355X/C2: cutting the buffer into frame chunks and running each chunk's vsync/IIR
-  // tail on a second stream under the next chunk's raster launch -- 0.245 ms -> 0.271 ms with 2 chunks, 0.297 ms
-  // with 3: the extra launches and cross-stream event waits cost more than the overlap returns.)
+  // (Measured and closed: cutting ONE buffer into frame chunks whose tails run beside the next chunk's image launch -- round 1:
+  // 0.245 -> 0.271 ms with 2 chunks; round 5 on the pipeline's lanes: 0.162 -> 0.247 ms (2), 0.266 (3); raster-free 0.086 ->
+  // 0.130 / 0.164.  Half-size image launches fill the machine worse and the chain of tails is exposed at the call's end.
+  // The overlap lives ACROSS buffers: tsdr_frames_submit_d.)
   int nf = 0;
   int rc = tsdr_frames_scan_d(ctx, sync, iq, nEch, S, y_t, x_t, do_align, img, raster_out, keys, &nf);
   if (n_frames) *n_frames = nf;
