@@ -144,6 +144,7 @@ struct tsdr_ctx {
   hipEvent_t lane_in = nullptr;     // "inputs ready" point of the context's stream
   int pipe_last_slot = -1;          // slot of the latest submission: its tail is behind everything submitted
   int pipe_cand_now = -1;           // arrangement (index into frames.hip:kCands) of the submissions in flight
+  bool pipe_one_lane = false;       // ... is the one-stream arrangement (no event per buffer; pipe_drain records one when asked)
   int pipe_lane = 0;                // lane of the call being enqueued (per-lane guard queue words, workspace raster)
   int opt_pipe_mode = -1;           // -1: the measured choice; 0: image lane + tail lane; 1: whole buffers alternate between opt_pipe_lanes
                                     // equal lanes, only shift + IIR chained; 2: one internal stream (the sequential order)

@@ -334,7 +334,12 @@ static int pipe_init(tsdr_ctx *ctx) {
 int pipe_drain(tsdr_ctx *ctx) {
   if (!ctx || ctx->pipe_n == 0) return TSDR_OK;
   // the tails run in submission order (stream order or chained by events): the latest one is behind everything else
-  if (ctx->pipe_last_slot >= 0) TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->pipe_last_slot], 0));
+  if (ctx->pipe_last_slot >= 0) {
+    // (the one-stream arrangement records no event per buffer -- nothing but this point ever waits for it -- so that it costs
+    // exactly what one tsdr_frames_d per buffer costs: the event is recorded here, behind everything on its lane)
+    if (ctx->pipe_one_lane) TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[ctx->pipe_last_slot], ctx->lane[0]));
+    TSDR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->pipe_last_slot], 0));
+  }
   ctx->pipe_n = 0;
   return TSDR_OK;
 }
@@ -443,6 +448,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     ctx->pipe_last_slot = -1;
     if (sym) { ctx->lane[0] = ctx->pool[pc.s[0]]; ctx->lane[1] = ctx->pool[pc.s[1]]; ctx->lane[3] = ctx->pool[pc.s[2]]; }
     else { ctx->lane[0] = ctx->pool[pc.s[0]]; ctx->lane[2] = ctx->pool[pc.s[1]]; }
+    ctx->pipe_one_lane = sym && nl == 1;
   }
   ctx->pipe_key = key;
   ctx->pipe_cand_now = cand;
@@ -498,12 +504,13 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     }
     if (ctx->pipe_last_slot >= 0 && ctx->pipe_last_slot != slot && ctx->ev_tail_used[ctx->pipe_last_slot])
       TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_tail[ctx->pipe_last_slot], 0));
-    if (ctx->opt_pipe_ext_event && !(ctx->opt_pipe_debug & 2)) ctx->launch_stop_ev = ctx->ev_tail[slot];
+    const bool want_ev = nl > 1 && !(ctx->opt_pipe_debug & 2);
+    if (ctx->opt_pipe_ext_event && want_ev) ctx->launch_stop_ev = ctx->ev_tail[slot];
     rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
                      do_align ? sync_idx : nullptr);
     ctx->launch_stop_ev = nullptr;
     if (rc) return rc;
-    if (!ctx->opt_pipe_ext_event && !(ctx->opt_pipe_debug & 2)) TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
+    if (!ctx->opt_pipe_ext_event && want_ev) TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], st));
   } else {
     tail_stream = ctx->lane[2];
     {
