@@ -251,6 +251,15 @@ __device__ inline unsigned rs_pos(const RsAxis &a, double i1, double &delta) {
   delta = x - xf;
   return (unsigned)xf - 1u;
 }
+// The same for positions known to lie strictly inside (1, n_in): no clamps, no end-of-signal case -- the identical x, floor and
+// delta with four f64 instructions fewer.  Callers establish the precondition per tile (k_raster_tile: every pixel of a tile
+// that does not hold the first or last few pixels of the frame).
+__device__ inline unsigned rs_pos_inner(const RsAxis &a, double i1, double &delta) {
+  const double x = __dadd_rn(__dmul_rn(a.sf, i1), a.off);
+  const double xf = floor(x);
+  delta = x - xf;
+  return (unsigned)xf - 1u;
+}
 // (1-d)*a + d*b in f64 (two products, one sum, no FMA), rounded once to f32
 __device__ inline float rs_blend(float a, float b, double d) {
   double v = __dadd_rn(__dmul_rn(1.0 - d, (double)a), __dmul_rn(d, (double)b));

@@ -43,6 +43,25 @@ def test_no_device_means_loud_failure_not_fallback(tsdr):
         tsdr.Context(0)
 
 
+def test_group_without_devices_fails_loudly_and_links_rccl(tsdr):
+    """tsdr_group_create without a usable HIP device returns a status and no handle (no CPU fallback for the multi-GPU split
+    either); and the library's one collective comes from librccl, linked directly (readelf: a NEEDED entry), not from Python."""
+    import shutil
+    import subprocess
+    import torch
+    lib = tsdr._lib.load()
+    if not torch.cuda.is_available():
+        h = C.c_void_p(0)
+        devs = (C.c_int * 1)(0)
+        assert lib.tsdr_group_create(devs, 1, C.byref(h)) != 0 and not h.value
+        with pytest.raises(tsdr.TempestHIPError):
+            tsdr.Group([0])
+    assert lib.tsdr_group_size(None) == tsdr._lib.TSDR_EINVAL
+    if shutil.which("readelf"):
+        out = subprocess.run(["readelf", "-d", tsdr._lib.LIB_PATH], capture_output=True, text=True).stdout
+        assert "librccl" in out, "libtempest_hip.so must link librccl (tsdr_group_*: ncclAllReduce of the autocorrelation accumulators)"
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "tempestsdr.jl_amd")
     for dirpath, _, files in os.walk(pkg):
