@@ -95,8 +95,6 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *   "fft_no_mix2" 1: every mixed-radix factor goes through the generic LDS-stage kernel.  Default 0.
  *   "ac_fuse_mid" 1 (default): on the mixed-radix route the autocorrelation's last forward pass, power spectrum and
  *                 first inverse pass run as one launch; 0: two separate transforms.
- *   "spectrum_one" 1 (default): getSpectrum of 4096 < N <= 2^19 points whose length has a 2^a 3^b 5^c divisor in [64, 1024] runs as ONE
- *                 launch (direct summation over the other factor + one LDS transform per workgroup); 0: the pass engines.
  *   "sync_guard_ppb"  sync-guard threshold of the TSDR_FAST frame loop in parts per billion (default 20000 = 2e-5;
  *                 0 switches the guard off: indices may then differ from the reference's where beta is tied at 1e-7).
  *   "vsync_current_sy" 0 (default): tsdr_vsync and the frame loop reproduce the reference's ordering -- s_y is read from beta_y

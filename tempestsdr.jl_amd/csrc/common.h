@@ -76,7 +76,6 @@ struct tsdr_ctx {
   int opt_down_xcd = 1;      // raster-free FAST kernel: XCD-aware tile order
   int opt_raster_rec4 = -1;  // FAST raster walk: staged |IQ| as plain f32 samples (4 bytes) instead of {a, slope hi, slope lo} records (16): 0 = never (the A/B), else wherever the f32 walk forms the images
   int opt_raster_split = 0;  // FAST frame loop with rasters: 1 = sheared raster-only kernel + raster-free image kernel, 2 = the same unsheared (A/B)
-  int opt_spectrum_one = 1; // getSpectrum of up to 2^19 points whose length has a 2-3-5-smooth divisor in [64, 1024]: one launch (spectrum_one.hip)
   int opt_ac_fuse_mid = 1;  // autocorrelation: last forward pass + power spectrum + first inverse pass as one launch
   // sync guard of the FAST frame loop (guard.h): relative top-2 margin below which a frame is re-evaluated exactly
   // (0: off); running totals {frames checked, frames re-evaluated} on the device

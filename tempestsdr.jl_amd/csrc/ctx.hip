@@ -148,7 +148,6 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_FFT_NO_MIX2")) ctx->opt_fft_no_mix2 = atoi(e) != 0;
   if (const char *e = getenv("TSDR_AC_FUSE_MID")) ctx->opt_ac_fuse_mid = atoi(e) != 0;
   if (const char *e = getenv("TSDR_FFT_BIG")) ctx->opt_fft_big = atoi(e) != 0;
-  if (const char *e = getenv("TSDR_SPECTRUM_ONE")) ctx->opt_spectrum_one = atoi(e) != 0;
   if (const char *e = getenv("TSDR_FAST_WALK_ONLY")) ctx->opt_fast_walk_only = atoi(e) != 0;
   if (const char *e = getenv("TSDR_SYNC_GUARD_PPB")) ctx->guard_thr = (float)atoi(e) * 1e-9f;
   if (const char *e = getenv("TSDR_SYNC_GUARD_AUTO")) ctx->opt_guard_auto = atoi(e) != 0;
@@ -235,7 +234,6 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
     ctx->opt_vsync_current_sy = value != 0;
   }
   else if (!strcmp(name, "fft_big")) ctx->opt_fft_big = value != 0;
-  else if (!strcmp(name, "spectrum_one")) ctx->opt_spectrum_one = value != 0;
   else if (!strcmp(name, "down_xcd")) ctx->opt_down_xcd = value != 0;
   else if (!strcmp(name, "down_spp_max_pct")) ctx->opt_down_spp_max_pct = value < 0 ? 0 : value;
   else if (!strcmp(name, "raster_split")) ctx->opt_raster_split = value < 0 || value > 2 ? 0 : value;

@@ -444,15 +444,12 @@ __global__ __launch_bounds__(256) void k_resample4096(const float *__restrict__ 
   for (int m = 0; m < 16; ++m) out[tid + 256 * m] = gain * (v[m].x * inv);  // real(conj(.)) = real(.): ifft scale, then 2*up
 }
 
-int spectrum_one_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int lin, float *y, bool *did);   // spectrum_one.hip
-
 static int spectrum_d(tsdr_ctx *ctx, const float *sig, int is_complex, size_t N, int lin, float *y) {
   if (N == 0) return TSDR_OK;
-  if (ctx->opt_spectrum_one) {   // short signals: one launch (direct first factor + one LDS transform per workgroup)
-    bool did = false;
-    int rc1 = spectrum_one_d(ctx, sig, is_complex, N, lin, y, &did);
-    if (rc1 || did) return rc1;
-  }
+  // (Round 5, built and dropped: ONE launch for short signals -- N = R1 * R2, workgroup k1 forms sum_n1 x[R2 n1 + n2] W_R1^(n1 k1)
+  // by direct summation and runs one R2-point LDS transform: no second pass, no grid barrier.  Correct on every size tried, and
+  // 41-56 us at N = 80 000 against the two passes' 14.9: the work per THREAD is N / 1024 terms whatever R1 is (grid = R1), and
+  // 16 wavefronts of ~2600 instructions share one CU -- 20 us of issue before any latency.  NOTEBOOK.md.)
   float2 *X = (float2 *)ctx->scratch(WS_FFT_A, N * sizeof(float2));
   if (!X) return TSDR_ENOMEM;
   if (fft_passes(N) >= 2 && (reinterpret_cast<uintptr_t>(sig) & (is_complex ? 7u : 3u)) == 0) {

@@ -285,32 +285,6 @@ def test_spectrum_vs_oracle(ctx, N, cplx):
     assert np.max(np.abs(ydb[strong] - odb[strong])) < 2e-2
 
 
-@pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("N", [80_000, 74_000, 10_125, 524_288, 4_100, 6_561, 99_999])
-def test_spectrum_one_launch_route(ctx, N, cplx):
-    """getSpectrum of a short signal as ONE launch (spectrum_one.hip: N = R1 * R2, direct summation over R1 + one R2-point LDS
-    transform per workgroup): 80 000 = 40 x 2000; 74 000 = 37 x 2000 (R1 need not be smooth); 10 125 = 5 x 2025 (odd N: the
-    fftshift); 2^19 = 256 x 2048 (the largest it takes); 4100 = 41 x 100; 6561 = 3^8 = 9 x 729; 99 999 has no smooth divisor
-    >= 64 (falls through to the pass engines).  Against the oracle and against the pass engines' route ("spectrum_one" = 0)."""
-    sig = (crandn(N) if cplx else rng.standard_normal(N).astype(np.float32)) + 2.0
-    o = O.getSpectrum(sig, N=N, lin=True)
-    res = {}
-    for one in (1, 0):
-        ctx.set_option("spectrum_one", one)
-        try:
-            f, y = ctx.getSpectrum(2e6, sig, N=N, lin=True)
-            _, ydb = ctx.getSpectrum(2e6, sig, N=N)
-        finally:
-            ctx.set_option("spectrum_one", 1)
-        assert f.size == N and y.shape == o.shape
-        assert relmax(np.sqrt(y), np.sqrt(o)) < 2 * FFT_TOL, (one, relmax(np.sqrt(y), np.sqrt(o)))
-        assert abs(y.astype(np.float64).sum() / (N * np.sum(np.abs(sig.astype(np.complex128)) ** 2)) - 1) < 1e-5
-        strong = o > 1e-4 * o.max()
-        assert np.max(np.abs(ydb[strong] - 10 * np.log10(o[strong]))) < 2e-2
-        res[one] = y
-    assert relmax(np.sqrt(res[1]), np.sqrt(res[0])) < 2 * FFT_TOL
-
-
 def test_spectrum_too_long_raises(ctx):
     with pytest.raises(IndexError):
         ctx.getSpectrum(1.0, np.ones(10, np.float32), N=11)
