@@ -153,7 +153,6 @@ struct tsdr_ctx {
   int opt_pipe_ext_event = 1;       // 1: a buffer's tail event rides on its shift + IIR dispatch (hipExtLaunchKernelGGL's stop event) instead of
                                     // a marker packet of its own behind it
   hipEvent_t launch_stop_ev = nullptr;  // set by the pipeline for the next shift + IIR launch, cleared by it
-  int opt_pipe_debug = 0;           // measurement switches (TSDR_PIPE_DEBUG; results are WRONG with bit 2 unless one lane is forced)
   int opt_pipe_tune = 1;            // 0: "pipe_mode" -1 means arrangement 0 with rasters, 1 without (rounds 1-4), nothing is measured
   struct PipeTune {                 // the measured choice for one PipeKey
     PipeKey key; int state = 0;     // 0: nothing measured; 1: trials running; 2: settled

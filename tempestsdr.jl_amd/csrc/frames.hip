@@ -482,7 +482,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     LaneScope lane_scope(ctx, li);
     hipStream_t st = ctx->lane[li];
     tail_stream = st;
-    if (!(ctx->opt_pipe_debug & 1) && hipStreamQuery(ctx->stream) != hipSuccess) {
+    if (hipStreamQuery(ctx->stream) != hipSuccess) {
       (void)hipGetLastError();
       TSDR_HIP(ctx, hipEventRecord(ctx->lane_in, ctx->stream));
       TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->lane_in, 0));
@@ -504,7 +504,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
     }
     if (ctx->pipe_last_slot >= 0 && ctx->pipe_last_slot != slot && ctx->ev_tail_used[ctx->pipe_last_slot])
       TSDR_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_tail[ctx->pipe_last_slot], 0));
-    const bool want_ev = nl > 1 && !(ctx->opt_pipe_debug & 2);
+    const bool want_ev = nl > 1;
     if (ctx->opt_pipe_ext_event && want_ev) ctx->launch_stop_ev = ctx->ev_tail[slot];
     rc = shift_iir_d(ctx, sync, img, npx, TSDR_RENDER_H, TSDR_RENDER_W, F, keys, do_align, alpha, imageOut_state, frames_out,
                      do_align ? sync_idx : nullptr);

@@ -411,26 +411,14 @@ __device__ inline void down_event(DownInfo &di, int j, float R00, float R01) {
 // instructions instead of two, for a quarter of the LDS: what lets C3's wide tiles (39 samples x 127 lines) share a CU.
 // (round 5: the division by D is in the staged samples -- a' = a / D once per sample instead of once per pixel, 0.115 samples per
 // pixel at C2 -- so a pixel is three instructions: (D - r) a' + r b')
-#ifndef TSDR_NO_PRESCALE
-__device__ __forceinline__ float rec4_pixel(float ref, float Df, float invD, float2 s) {
+__device__ __forceinline__ float rec4_pixel(float ref, float Df, float2 s) {
   return __fmaf_rn(ref, s.y, __fmul_rn(__fsub_rn(Df, ref), s.x));
 }
-#else
-__device__ __forceinline__ float rec4_pixel(float ref, float Df, float invD, float2 s) {
-  return __fmul_rn(__fmaf_rn(ref, s.y, __fmul_rn(__fsub_rn(Df, ref), s.x)), invD);
-}
-#endif
 // (the integer walk, D >= 2^24: the weights are conversions of the two integers -- relative error 2^-24 each, which is all the
 // convex form needs)
-#ifndef TSDR_NO_PRESCALE
-__device__ __forceinline__ float rec4_pixel_u(unsigned r, unsigned D, float invD, float2 s) {
+__device__ __forceinline__ float rec4_pixel_u(unsigned r, unsigned D, float2 s) {
   return __fmaf_rn((float)r, s.y, __fmul_rn((float)(D - r), s.x));
 }
-#else
-__device__ __forceinline__ float rec4_pixel_u(unsigned r, unsigned D, float invD, float2 s) {
-  return __fmul_rn(__fmaf_rn((float)r, s.y, __fmul_rn((float)(D - r), s.x)), invD);
-}
-#endif
 __device__ __forceinline__ float2 rec4_read(const float *row, int kk) { return make_float2(row[kk], row[kk + 1]); }
 
 template <bool F32W, bool OUT, bool DOWNR, int PW, bool REC4 = false>
@@ -478,7 +466,7 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
       }
       float4 n4 = s4; double2 n2 = s2; float2 n1 = s1;
       if (REC4) n1 = rec4_read(row1, kk); else if (F32W) n4 = row4[kk]; else n2 = row2[kk];  // next pixel's record; in range by the W bound
-      v[i] = REC4 ? (F32W ? rec4_pixel(ref, Df, invD, s1) : rec4_pixel_u(reu, fa.D, invD, s1))
+      v[i] = REC4 ? (F32W ? rec4_pixel(ref, Df, s1) : rec4_pixel_u(reu, fa.D, s1))
                   : F32W ? fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)) : (float)fma((double)reu, s2.y, s2.x);
       if (OUT) { store_saddr(ob, (unsigned)loff * 4u, v[i]); ob += ostride; }
       s4 = n4; s2 = n2; s1 = n1;
@@ -494,7 +482,7 @@ __device__ inline void fast_walk_full(const FastAx &fa, const void *__restrict__
     }
   }
   if (DOWNR && extra && ((di.colmask >> (PW - 1)) & 1ull)) {
-    const float ve = REC4 ? (F32W ? rec4_pixel(rf, Df, invD, s1) : rec4_pixel_u(r, fa.D, invD, s1))
+    const float ve = REC4 ? (F32W ? rec4_pixel(rf, Df, s1) : rec4_pixel_u(r, fa.D, s1))
                           : F32W ? fmaf(rf, s4.z, fmaf(rf, s4.y, s4.x)) : (float)fma((double)r, s2.y, s2.x);
     down_event<F32W>(di, PW - 1, last, ve);
   }
@@ -518,7 +506,7 @@ __device__ inline void fast_walk2(const FastAx &fa, const void *__restrict__ row
     float v;
     if (REC4) {
       const float2 s1 = rec4_read(reinterpret_cast<const float *>(rowv), ks);
-      v = F32W ? rec4_pixel(ref, Df, invD, s1) : rec4_pixel_u(reu, fa.D, invD, s1);
+      v = F32W ? rec4_pixel(ref, Df, s1) : rec4_pixel_u(reu, fa.D, s1);
     }
     else if (F32W) { const float4 s4 = row4[ks]; v = fmaf(ref, s4.z, fmaf(ref, s4.y, s4.x)); }
     else { const double2 s2 = row2[ks]; v = (float)fma((double)reu, s2.y, s2.x); }
@@ -623,11 +611,7 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
       for (int t = 0; t < 4; ++t) {
         const int j = jb + t;
         if (REC4) {
-#ifndef TSDR_NO_PRESCALE
-          if (t < cs && j < q.W) smp1[r * Wp + j] = __fmul_rn(a[t], fi.invD);
-#else
-          if (t < cs && j < q.W) smp1[r * Wp + j] = a[t];
-#endif
+          if (t < cs && j < q.W) smp1[r * Wp + j] = __fmul_rn(a[t], fi.invD);   // a' = a / D (rec4_pixel)
         } else if (t < cs && j < q.W) {
           const double sl = ((double)a[t + 1] - (double)a[t]) * fa.invDd;
           if (F32W) {
