@@ -382,7 +382,10 @@ int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, cons
  * library links: single-process ranks over xGMI), driven by the calling thread.  Host pointers in and out, like the other
  * entry points the Julia shim binds; every call returns with its outputs complete.  Member 0 is the root: it runs the
  * non-linear and sequential steps and is the device a renderer would read from.
- * devices == NULL: devices 0 .. n-1.  A group of ONE device is valid and returns the single-context results bit for bit. */
+ * devices == NULL: devices 0 .. n-1.  A group of ONE device is valid and returns the single-context results bit for bit.
+ * A device listed MORE THAN ONCE gives members that share it; RCCL takes one rank per device, so such a group exchanges by
+ * device-to-device copies and adds in member order instead (no communicator): the same split, slices, halos and offsets as
+ * a group of distinct devices -- what the tests use to run the N > 1 logic on a one-GPU box; production lists distinct devices. */
 typedef struct tsdr_group tsdr_group;
 int tsdr_group_create(const int *devices, int n, tsdr_group **out);
 void tsdr_group_destroy(tsdr_group *g);

@@ -48,6 +48,7 @@ struct tsdr_group {
   std::string err;
   double stage_ms[3] = {0, 0, 0};
   int last_route = 0;
+  bool virt = false;               // a device is listed more than once: no RCCL (see tsdr_group_create)
 };
 
 namespace {
@@ -91,6 +92,10 @@ bool smooth235(size_t v) {
 size_t single_points(size_t n) { return (n % 2 == 0 && n > 1024 && smooth235(n / 2)) ? n / 2 : pow2_at_least(2 * n) / 2; }
 size_t sharded_points(size_t n, size_t n_lags, int world) { return pow2_at_least((n + world - 1) / world + n_lags - 1); }
 
+__global__ __launch_bounds__(256) void k_acc(float *__restrict__ acc, const float *__restrict__ x, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc[i] = acc[i] + x[i];
+}
+
 __global__ __launch_bounds__(256) void k_db(float *__restrict__ y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = 10.0f * log10f(y[i]);
 }
@@ -109,6 +114,35 @@ int ensure_syncs(tsdr_group *g) {
     G_HIP(g, hipSetDevice(g->dev[i]));
     int rc = tsdr_sync_create(g->ctx[i], TSDR_RENDER_H, TSDR_RENDER_W, &g->sync[i]);
     if (rc) return member_err(g, i, rc, "SyncXY");
+  }
+  return TSDR_OK;
+}
+
+// the root's stream is ordered behind what every member has enqueued so far (members sharing one device: HIP events)
+int root_after_members(tsdr_group *g) {
+  for (int i = 1; i < g->n; ++i) {
+    G_HIP(g, hipEventRecord(g->ev[i], g->ctx[i]->stream));
+    G_HIP(g, hipStreamWaitEvent(g->ctx[0]->stream, g->ev[i], 0));
+  }
+  return TSDR_OK;
+}
+
+// sum of the members' vectors: ONE ncclAllReduce over xGMI -- or, members sharing a device, adds on the root in member order
+int all_reduce_sum(tsdr_group *g, const std::vector<float *> &buf, size_t count) {
+  if (!g->virt) {
+    G_NCCL(g, ncclGroupStart());
+    for (int i = 0; i < g->n; ++i) {
+      ncclResult_t r = ncclAllReduce(buf[i], buf[i], count, ncclFloat, ncclSum, g->comm[i], g->ctx[i]->stream);
+      if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+    }
+    G_NCCL(g, ncclGroupEnd());
+    return TSDR_OK;
+  }
+  int rc = root_after_members(g);
+  if (rc) return rc;
+  for (int i = 1; i < g->n; ++i) {
+    hipLaunchKernelGGL(k_acc, dim3((unsigned)std::min<size_t>(ceil_div(count, 256), 2048)), dim3(256), 0, g->ctx[0]->stream, buf[0], (const float *)buf[i], count);
+    G_HIP(g, hipGetLastError());
   }
   return TSDR_OK;
 }
@@ -134,7 +168,8 @@ int tsdr_group_create(const int *devices, int n, tsdr_group **out) {
   g->n = n;
   for (int i = 0; i < n; ++i) {
     const int d = devices ? devices[i] : i;
-    if (d < 0 || d >= ndev || std::find(g->dev.begin(), g->dev.end(), d) != g->dev.end()) { delete g; return TSDR_EINVAL; }
+    if (d < 0 || d >= ndev) { delete g; return TSDR_EINVAL; }
+    if (std::find(g->dev.begin(), g->dev.end(), d) != g->dev.end()) g->virt = true;
     g->dev.push_back(d);
   }
   g->ctx.assign(n, nullptr); g->sync.assign(n, nullptr); g->ev.assign(n, nullptr);
@@ -145,7 +180,8 @@ int tsdr_group_create(const int *devices, int n, tsdr_group **out) {
     ok = g->ctx[i] != nullptr && hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) == hipSuccess;
   }
   // single-process ranks: rank i = member i on devices[i]; the collectives below run inside ncclGroupStart / End
-  if (ok) ok = ncclCommInitAll(g->comm.data(), n, g->dev.data()) == ncclSuccess;
+  // (members sharing a device: RCCL takes one rank per device, so such a group exchanges by copies and adds on the device)
+  if (ok && !g->virt) ok = ncclCommInitAll(g->comm.data(), n, g->dev.data()) == ncclSuccess;
   if (ok) ok = hipSetDevice(g->dev[0]) == hipSuccess;
   for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreate(&g->t[k]) == hipSuccess;
   if (!ok) {
@@ -287,12 +323,8 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
   G_HIP(g, hipEventRecord(g->t[1], c0->stream));
   // stage 2: ONE all-reduce of the accumulators (linear domain) over xGMI
   if (sharded) {
-    G_NCCL(g, ncclGroupStart());
-    for (int i = 0; i < N; ++i) {
-      ncclResult_t r = ncclAllReduce(part[i], part[i], n_lags, ncclFloat, ncclSum, g->comm[i], g->ctx[i]->stream);
-      if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
-    }
-    G_NCCL(g, ncclGroupEnd());
+    rc = all_reduce_sum(g, part, n_lags);
+    if (rc) return rc;
   }
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[2], c0->stream));
@@ -352,7 +384,7 @@ int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int
   G_HIP(g, hipEventRecord(g->t[1], c0->stream));
   // stage 2: gather to the rendering device (GUI.jl:177 hands the frames to ONE renderer): every other member sends its
   // share once -- 1.92 MB + 16 B per frame
-  if (N > 1) {
+  if (N > 1 && !g->virt) {
     G_NCCL(g, ncclGroupStart());
     ncclResult_t r = ncclSuccess;
     for (int i = 1; i < N && r == ncclSuccess; ++i) {
@@ -364,6 +396,14 @@ int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int
     }
     if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("gather: ") + ncclGetErrorString(r)); }
     G_NCCL(g, ncclGroupEnd());
+  } else if (N > 1) {   // members sharing a device: device-to-device copies behind the members' scans
+    rc = root_after_members(g);
+    if (rc) return rc;
+    for (int i = 1; i < N; ++i) {
+      if (fc[i] == 0) continue;
+      G_HIP(g, hipMemcpyAsync(img[0] + f0[i] * npx, img[i], fc[i] * npx * 4, hipMemcpyDeviceToDevice, c0->stream));
+      if (do_align) G_HIP(g, hipMemcpyAsync(keys[0] + f0[i] * 2, keys[i], fc[i] * 2 * 8, hipMemcpyDeviceToDevice, c0->stream));
+    }
   }
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[2], c0->stream));
@@ -416,12 +456,8 @@ int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[1], c0->stream));
   if (N > 1) {
-    G_NCCL(g, ncclGroupStart());
-    for (int i = 0; i < N; ++i) {
-      ncclResult_t r = ncclAllReduce(part[i], part[i], sizeFFT, ncclFloat, ncclSum, g->comm[i], g->ctx[i]->stream);
-      if (r != ncclSuccess) { (void)ncclGroupEnd(); return gerr(g, TSDR_EHIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
-    }
-    G_NCCL(g, ncclGroupEnd());
+    int rca = all_reduce_sum(g, part, sizeFFT);
+    if (rca) return rca;
   }
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[2], c0->stream));

@@ -3,9 +3,11 @@ device, include/tempest_hip.h): what the reference's single-process runtime (GUI
 
 A group of ONE device must return the single-context results bit for bit -- per-frame and per-lag arithmetic is unchanged
 and the 1-rank all-reduce is the identity; this runs on every GPU box and executes the RCCL path (communicator creation,
-ncclAllReduce on the library's stream) on real hardware.  Groups of 2 .. all devices are compared with the single-context
-results where the box has more than one GPU (skipped otherwise): frames bit for bit, the search and getWelch within the
-f32 summation-order tolerance of the sharded sums and with the same argmax."""
+ncclAllReduce on the library's stream) on real hardware.  The N > 1 split -- frame ranges, H2D slices, halos with their wrap,
+gather offsets -- runs on every box too, with 2 / 3 / 5 members SHARING the one device (a group may list a device more than
+once; it then exchanges by copies and adds instead of RCCL, which takes one rank per device).  Groups of 2 / 4 / 8 distinct
+devices over RCCL are compared with the single-context results where the box has that many GPUs (skipped otherwise):
+frames bit for bit, the search and getWelch within the f32 summation-order tolerance of the sharded sums, same argmax."""
 import numpy as np
 import pytest
 
@@ -93,8 +95,6 @@ def test_group_of_one_search_and_welch_equal_single_context(ctx, tsdr, capture):
 
 def test_group_misuse(tsdr):
     with pytest.raises(tsdr.TempestHIPError):
-        tsdr.Group([0, 0])          # one communicator per DEVICE
-    with pytest.raises(tsdr.TempestHIPError):
         tsdr.Group([])
     with pytest.raises(tsdr.TempestHIPError):
         tsdr.Group([_ndev() + 3])
@@ -107,6 +107,48 @@ def test_group_misuse(tsdr):
         s = np.zeros((600, 800), np.float32, order="F")
         assert g.frames(np.ones(10, np.complex64), 33333, 628, 1056, np.float32(0.1), s)["n_frames"] == 0
     finally:
+        g.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 5])
+def test_members_sharing_one_device_run_the_split_logic(ctx, tsdr, capture, n):
+    """N > 1 members on ONE device (the device listed n times: exchanges by device-to-device copies and adds, no RCCL -- which
+    wants one rank per device): everything else is the code a group of n distinct devices runs -- frame ranges (7 frames dealt
+    raggedly over 2 / 3 / 5 members), per-member H2D slices, the gather offsets of images, keys and rasters, the search's
+    segment + halo slices with the wrap at n, the Welch segment ranges.  Frames bit for bit the single-context result; the
+    sharded search within 2e-4 dB with the same argmax (its partial sums are added in member order, not n's own order)."""
+    Fs, x_t, y_t, S, iq = capture
+    g = tsdr.Group([0] * n)
+    try:
+        assert len(g) == n
+        for precision in ("fast", "exact"):
+            g.set_precision(precision)
+            g.set_option("sync_guard_auto", 0)
+            g.sync_reset()
+            ctx.set_precision(precision)
+            sync = tsdr.SyncXY(ctx, 600, 800)
+            s1 = np.zeros((600, 800), np.float32, order="F")
+            s2 = np.zeros((600, 800), np.float32, order="F")
+            for part in (iq[: 4 * S + 50], iq[4 * S:], iq[: S + 7]):     # 4, 3 and 1 frames: fewer frames than members too
+                _frames_equal(ctx.frames(sync, part, S, y_t, x_t, np.float32(0.1), s1, want_raster=True),
+                              g.frames(part, S, y_t, x_t, np.float32(0.1), s2, want_raster=True))
+                assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+            sync.close()
+        G1, p1, _ = ctx.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90)
+        G2, p2, _ = g.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90, route="sharded")
+        assert g.timing()[0] == "sharded"
+        assert np.max(np.abs(G1 - G2)) < 2e-4 and p1 == p2
+        # real input, linear scale, another window (n = 2 indexMax = 40 000 of the 160 000 samples: Autocorrelations.jl:27)
+        x = (iq.real.astype(np.float32) ** 2 + iq.imag.astype(np.float32) ** 2).astype(np.float32)[: 8 * 20_000]
+        G3, p3, _ = g.autocorr_search(x, Fs, 0.0, 0.01, 150, 400, scale="lin", route="sharded")
+        G4, p4, _ = ctx.autocorr_search(x, Fs, 0.0, 0.01, 150, 400, scale="lin")
+        assert np.max(np.abs(G3 - G4)) <= 2e-5 * np.max(np.abs(G4)) and p3 == p4
+        for size in (1024, 1000):
+            _, y1 = ctx.getWelch(Fs, iq, sizeFFT=size)
+            _, y2 = g.getWelch(Fs, iq, sizeFFT=size)
+            assert np.max(np.abs(y1 - y2)) < 2e-4, size
+    finally:
+        ctx.set_precision("fast")
         g.close()
 
 
