@@ -153,6 +153,7 @@ struct tsdr_ctx {
   int opt_pipe_ext_event = 1;       // 1: a buffer's tail event rides on its shift + IIR dispatch (hipExtLaunchKernelGGL's stop event) instead of
                                     // a marker packet of its own behind it
   hipEvent_t launch_stop_ev = nullptr;  // set by the pipeline for the next shift + IIR launch, cleared by it
+  int opt_pipe_dev_events = 1;      // the pipeline's hand-over events release to device scope (TSDR_PIPE_DEV_EVENTS=0: the default system scope; A/B)
   int opt_pipe_tune = 1;            // 0: "pipe_mode" -1 means arrangement 0 with rasters, 1 without (rounds 1-4), nothing is measured
   struct PipeTune {                 // the measured choice for one PipeKey
     PipeKey key; int state = 0;     // 0: nothing measured; 1: trials running; 2: settled

@@ -158,6 +158,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_DOWN_SPP_MAX_PCT")) ctx->opt_down_spp_max_pct = atoi(e);
   if (const char *e = getenv("TSDR_PIPE_MODE")) ctx->opt_pipe_mode = atoi(e) < 0 ? -1 : atoi(e) > 2 ? 2 : atoi(e);
   if (const char *e = getenv("TSDR_GUARD_NOWAIT")) ctx->opt_guard_nowait = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_PIPE_DEV_EVENTS")) ctx->opt_pipe_dev_events = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_TUNE")) ctx->opt_pipe_tune = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_EXT_EVENT")) ctx->opt_pipe_ext_event = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;

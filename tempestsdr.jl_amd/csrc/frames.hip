@@ -313,9 +313,13 @@ static const PipeCand kCands[tsdr_ctx::kTuneCands] = {
 
 static int pipe_init(tsdr_ctx *ctx) {
   if (ctx->lane_in) return TSDR_OK;
+  // (hand-overs between streams of ONE device: a device-scope release when the event is recorded, not the default system-scope
+  // one, whose cache write-back holds up the lane behind every buffer; the host sees results through the context's stream, whose
+  // synchronisation fences as always)
+  const unsigned evf = hipEventDisableTiming | (ctx->opt_pipe_dev_events ? hipEventReleaseToDevice : 0u);
   for (int k = 0; k < tsdr_ctx::kPipeSlots; ++k) {
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[k], hipEventDisableTiming));
-    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[k], hipEventDisableTiming));
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_img[k], evf));
+    TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_tail[k], evf));
   }
   for (auto &e : ctx->tune_ev) TSDR_HIP(ctx, hipEventCreate(&e));
   int lo = 0, hi = 0;
