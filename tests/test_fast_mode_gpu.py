@@ -171,6 +171,8 @@ def test_pipeline_measured_choice_walks_every_arrangement(tsdr, synth, want_rast
     270 buffers -- and tsdr_frames_pipeline_info must report a settled choice with every candidate timed."""
     from tempestsdr_jl_amd import api
     ctx = tsdr.Context(0)   # (a context of its own: the measurement is per context and configuration)
+    ctx.set_option("pipe_mode", -1)   # (whatever TSDR_PIPE_* presets the environment carries)
+    ctx.set_option("pipe_tune", 1)
     Fs, x_t, y_t, fv, nfr, nbuf, ndist = 2.0e6, 1056, 628, 60.0, 1, 270, 5
     S = synth.samples_per_frame(Fs, fv)
     P, npx = x_t * y_t, 600 * 800
