@@ -38,6 +38,7 @@ done
 # (b) the spectrum-path timing tools' outputs; (c) the pipeline against one call per buffer with K idle streams created first,
 # hard-wired arrangement (TSDR_PIPE_TUNE=0: rounds 3-4) and measured one -- the hardware-queue dependence and its cure
 $R/tools/pmc_search.sh k_fft > $O/${TAG}_sq_search.txt 2>&1
+$R/tools/pmc_kernel.sh k_raster_fast cur > $O/${TAG}_sq_raster.txt 2>&1
 for t in time_fft_rows time_welch_sizes time_waterfall_sizes; do
   timeout 600 python3 $R/tools/$t.py 2>/dev/null | grep -v amdgpu.ids > $O/${TAG}_$t.txt
 done
