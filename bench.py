@@ -40,6 +40,23 @@ METRIC = "reconstructed frames/sec + MS/s IQ ingest, 1080p60 leak @ 20 MS/s, 1/2
 NPX = 600 * 800
 
 
+def run_group_child(devs, workload, timeout=150):
+    """tools/group_devices.py on the given devices in a child process; its JSON line, or what went wrong"""
+    import subprocess
+    cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "group_devices.py"), devs, workload]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    except subprocess.TimeoutExpired:
+        return {"devices": devs, "error": f"no result within {timeout} s (child process ended)"}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"devices": devs, "error": f"exit code {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"devices": devs, "error": f"unreadable result: {e}"}
+
+
 def measured_traffic(workload, kernel, key="hbm_bytes_per_launch"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/traffic.json: FETCH_SIZE
     doubled per the gfx950 note + WRITE_SIZE, collected on this bench command by tools/collect_profiles.sh).  PMC
@@ -416,6 +433,14 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def emit(obj):
+    """the ONE line of this run, on the process's real standard output"""
+    os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,6 +483,12 @@ def main():
             return self_launch(args.gpus)
         args.gpus = world
 
+    # stdout carries ONE JSON line and nothing else: libraries print there too (RCCL's version banner at communicator creation,
+    # flushed at exit -- i.e. AFTER the line), so descriptor 1 is pointed at stderr for the run and the line goes to the saved one
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from tempest_loader import load_package
@@ -513,7 +544,7 @@ def main():
         r = {}
         for lg in legs:
             r.update(spectrum_legs(env, iqs, L, only=[lg], reps_scale=max(1, args.steps) / base[lg], warm=args.warmup))
-        print(json.dumps({"spectra_only": r, "calls_per_leg": max(1, args.steps), "warmup_calls_per_leg": args.warmup}))
+        emit({"spectra_only": r, "calls_per_leg": max(1, args.steps), "warmup_calls_per_leg": args.warmup})
         return
 
     # ---- headline: the named workload, raster materialised unless --no-raster
@@ -638,6 +669,21 @@ def main():
                 g.close()
         except Exception as e:
             group = {"error": f"{type(e).__name__}: {e}"}
+        # A box that shows this process MORE than one GPU: the N > 1 split over RCCL / xGMI -- frames sharded, gathered and
+        # combined on the root (bit for bit against one context), the sharded search with its ONE ncclAllReduce, getWelch --
+        # run by tools/group_devices.py in a CHILD process (its own HIP / RCCL state, a timeout: whatever happens there, this
+        # line is printed).  TSDR_BENCH_GROUP_DEVICES=0,0 runs the leg on a 1-GPU box (members sharing the device: no RCCL).
+        sets = []
+        if os.environ.get("TSDR_BENCH_GROUP_DEVICES"):
+            sets = [os.environ["TSDR_BENCH_GROUP_DEVICES"]]
+        else:
+            ndev = torch.cuda.device_count()
+            sets = [",".join(str(d) for d in range(n)) for n in (2, 4, 8) if n <= ndev]
+        multi = []
+        for devs in sets:
+            multi.append(run_group_child(devs, args.workload))
+        if multi and isinstance(group, dict):
+            group["several_devices"] = multi
 
     # ---- N > 1: ONE capture buffer sharded through HipFrames (strong scaling of the loop GUI.jl:165-178)
     strong = None
@@ -826,7 +872,7 @@ def main():
             "search_ms": g("search", "ms_per_search"), "cpu_baseline_value": g("cpu_baseline", "value"),
             "c3_value": g("c3", "value"), "c3_fused_value": g("c3", "fused", "value"), "c5_value": g("c5", "value"),
             "c5_fused_value": g("c5", "fused", "value")}
-        print(json.dumps({"notes": notes, **line}))
+        emit({"notes": notes, **line})
     if world > 1:
         dist.destroy_process_group()
 
