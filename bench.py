@@ -678,10 +678,12 @@ def main():
             sets = [os.environ["TSDR_BENCH_GROUP_DEVICES"]]
         else:
             ndev = torch.cuda.device_count()
-            sets = [",".join(str(d) for d in range(n)) for n in (2, 4, 8) if n <= ndev]
+            sets = [",".join(str(d) for d in range(n)) for n in sorted({min(2, ndev), min(8, ndev)}) if n > 1]
         multi = []
         for devs in sets:
-            multi.append(run_group_child(devs, args.workload))
+            multi.append(run_group_child(devs, args.workload, timeout=100))
+            if "error" in multi[-1]:
+                break   # (a run that is already minutes long is not made longer by a second failure)
         if multi and isinstance(group, dict):
             group["several_devices"] = multi
 
