@@ -147,7 +147,26 @@ int all_reduce_sum(tsdr_group *g, const std::vector<float *> &buf, size_t count)
   return TSDR_OK;
 }
 
+// Every entry point: the calling thread's current device is put back on return (the stages below select each member's device
+// in turn), and a call that fails half-way waits for whatever it has enqueued -- copies that read the caller's arrays among it --
+// before it hands control back.
+struct CallScope {
+  tsdr_group *g;
+  int prev = -1;
+  bool ok = false;
+  explicit CallScope(tsdr_group *g_) : g(g_) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+  ~CallScope() {
+    if (!ok && g)
+      for (int i = 0; i < g->n; ++i)
+        if (g->ctx[i] && hipSetDevice(g->dev[i]) == hipSuccess) (void)hipStreamSynchronize(g->ctx[i]->stream);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
+  }
+  int done() { ok = true; return TSDR_OK; }
+};
+
 void stage_times(tsdr_group *g) {
+  (void)hipSetDevice(g->dev[0]);   // (the events are the root's)
   for (int k = 0; k < 3; ++k) {
     float ms = 0.f;
     g->stage_ms[k] = hipEventElapsedTime(&ms, g->t[k], g->t[k + 1]) == hipSuccess ? (double)ms : 0.0;
@@ -164,6 +183,7 @@ int tsdr_group_create(const int *devices, int n, tsdr_group **out) {
   if (n <= 0 || n > 64) return TSDR_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TSDR_ENODEV;
+  CallScope scope(nullptr);   // (the caller's current device comes back)
   tsdr_group *g = new tsdr_group();
   g->n = n;
   for (int i = 0; i < n; ++i) {
@@ -201,6 +221,7 @@ int tsdr_group_create(const int *devices, int n, tsdr_group **out) {
 
 void tsdr_group_destroy(tsdr_group *g) {
   if (!g) return;
+  CallScope scope(nullptr);
   for (int i = 0; i < g->n; ++i) {
     (void)hipSetDevice(g->dev[i]);
     (void)tsdr_synchronize(g->ctx[i]);
@@ -223,7 +244,9 @@ const char *tsdr_group_last_error(tsdr_group *g) { return g ? g->err.c_str() : "
 
 int tsdr_group_set_precision(tsdr_group *g, int mode) {
   if (!g) return TSDR_EINVAL;
+  CallScope scope(nullptr);
   for (int i = 0; i < g->n; ++i) {
+    G_HIP(g, hipSetDevice(g->dev[i]));
     int rc = tsdr_set_precision(g->ctx[i], mode);
     if (rc) return member_err(g, i, rc, "set_precision");
   }
@@ -232,7 +255,9 @@ int tsdr_group_set_precision(tsdr_group *g, int mode) {
 
 int tsdr_group_set_option(tsdr_group *g, const char *name, int value) {
   if (!g) return TSDR_EINVAL;
+  CallScope scope(nullptr);
   for (int i = 0; i < g->n; ++i) {
+    G_HIP(g, hipSetDevice(g->dev[i]));
     int rc = tsdr_set_option(g->ctx[i], name, value);
     if (rc) return member_err(g, i, rc, "set_option");
   }
@@ -241,6 +266,7 @@ int tsdr_group_set_option(tsdr_group *g, const char *name, int value) {
 
 int tsdr_group_sync_reset(tsdr_group *g) {
   if (!g) return TSDR_EINVAL;
+  CallScope scope(nullptr);
   for (int i = 0; i < g->n; ++i) {
     if (!g->sync[i]) continue;
     G_HIP(g, hipSetDevice(g->dev[i]));
@@ -261,6 +287,7 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
                       int log_scale, float *out, size_t *n_out, size_t win_lo, size_t win_cnt, size_t *idx, float *val,
                       int route) {
   if (!g || !x || !idx || route < 0 || route > 2) return TSDR_EINVAL;
+  CallScope scope(g);
   const int N = g->n;
   tsdr_ctx *c0 = g->ctx[0];
   size_t n, k0, cnt;
@@ -294,7 +321,7 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
     if (out) G_HIP(g, hipMemcpyAsync(out, dout, cnt * 4, hipMemcpyDeviceToHost, c0->stream));
     G_HIP(g, hipStreamSynchronize(c0->stream));
     stage_times(g);
-    return TSDR_OK;
+    return scope.done();
   }
   // stage 1, per member: H2D of its range of m plus the halo (wrapping at n), partial sums over that range
   const int world = sharded ? N : 1;
@@ -339,7 +366,7 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
   rc = sync_all(g);
   if (rc) return rc;
   stage_times(g);
-  return TSDR_OK;
+  return scope.done();
 }
 
 int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int y_t, int x_t, float alpha, int do_align,
@@ -350,6 +377,7 @@ int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int
   if (nb > (size_t)1 << 20) return gerr(g, TSDR_EINVAL, "too many frames in one buffer");
   if (n_frames) *n_frames = (int)nb;
   if (nb == 0) return TSDR_OK;
+  CallScope scope(g);
   int rc = ensure_syncs(g);
   if (rc) return rc;
   tsdr_ctx *c0 = g->ctx[0];
@@ -423,7 +451,7 @@ int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int
   if (rc) return rc;
   g->last_route = 1;
   stage_times(g);
-  return TSDR_OK;
+  return scope.done();
 }
 
 int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len, size_t sizeFFT, int lin, float *y) {
@@ -431,10 +459,11 @@ int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len
   const int N = g->n;
   const size_t nbSeg = len / sizeFFT, esz = is_complex ? 8 : 4;
   tsdr_ctx *c0 = g->ctx[0];
+  CallScope scope(g);
   if (nbSeg == 0) {  // (the single-context call defines what an empty sum returns)
     G_HIP(g, hipSetDevice(g->dev[0]));
     int rc = tsdr_welch(c0, sig, is_complex, len, sizeFFT, lin, y);
-    return rc ? member_err(g, 0, rc, "group_welch") : TSDR_OK;
+    return rc ? member_err(g, 0, rc, "group_welch") : scope.done();
   }
   std::vector<float *> part(N, nullptr);
   G_HIP(g, hipSetDevice(g->dev[0]));
@@ -469,7 +498,7 @@ int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len
   if (rc) return rc;
   g->last_route = N > 1 ? 1 : 2;
   stage_times(g);
-  return TSDR_OK;
+  return scope.done();
 }
 
 }  // extern "C"
