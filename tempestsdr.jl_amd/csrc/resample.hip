@@ -235,12 +235,34 @@ __global__ __launch_bounds__(256) void k_raster_tile(const float *__restrict__ i
       const double fmin = (double)l0 * (double)q.x_t + (double)p0;                                            // smallest flat index of the tile
       const double fmax = (double)min(l0 + 63, q.y_t - 1) * (double)q.x_t + (double)min(p0 + q.TP, q.x_t);   // one past its largest
       const bool edge = same || fmin < margin || fmax + margin >= (double)P;
+      const bool has_out = out != nullptr;   // (uniform: `o` is a per-lane pointer, its null test a per-lane branch)
       if (!edge) {
-        for (int p = pbeg; p < pend; ++p) {
+        // UNR pixels per round: their positions first, then their LDS reads, then the blends (one pixel at a time the loop waits
+        // out the LDS latency behind every position).  The 1-based flat index is carried as an f64 integer -- + 1.0 is exact,
+        // and v_cvt_f64_u32 costs two f64 additions (tools/ubench/valu_rates.hip); the kernel is VALU-issue-bound
+        constexpr int UNR = 2;   // (4: the same; 8: slower)
+        int p = pbeg;
+        double i1 = (double)(flat0 + 1u);
+        for (; p + UNR <= pend; p += UNR, i1 += (double)UNR) {
+          double d[UNR]; int j[UNR]; float a[UNR], bb[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) j[u] = (int)rs_pos_inner(ax, u == 0 ? i1 : i1 + (double)u, d[u]) - kf;
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) { a[u] = row[j[u]]; bb[u] = row[j[u] + 1]; }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const float v = rs_blend(a[u], bb[u], d[u]);
+            if (has_out) o[(size_t)u * (size_t)q.y_t] = v;
+            if (DOWN) trow[u * 65] = v;
+          }
+          if (has_out) o += (size_t)UNR * (size_t)q.y_t;
+          if (DOWN) trow += UNR * 65;
+        }
+        for (; p < pend; ++p, i1 += 1.0) {
           double d;
-          const int j = (int)rs_pos_inner(ax, (double)(flat0 + (unsigned)(p - pbeg) + 1u), d) - kf;
+          const int j = (int)rs_pos_inner(ax, i1, d) - kf;
           const float v = rs_blend(row[j], row[j + 1], d);
-          if (o) { *o = v; o += q.y_t; }
+          if (has_out) { *o = v; o += q.y_t; }
           if (DOWN) { *trow = v; trow += 65; }
         }
       } else {

@@ -21,6 +21,11 @@ __global__ __launch_bounds__(256) void k(float *out, int n, float fa, double da)
       if (OP == 8) d[j] = d[j] / da;                                         // f64 division
       if (OP == 9) d[j] = d[j] * da;                                         // mul_f64
       if (OP == 10) d[j] = d[j] + da;                                        // add_f64
+      if (OP == 11) d[j] = floor(d[j]) + da;                                 // floor_f64 + add_f64
+      if (OP == 12) i8[j] += (int)(unsigned)d[j], d[j] += 1.0;                // cvt_u32_f64 + iadd + add_f64
+      if (OP == 13) d[j] = (double)f[j] + d[j], f[j] += 1.0f;                 // cvt_f64_f32 + add_f64 + add_f32
+      if (OP == 14) d[j] = __builtin_amdgcn_fract(d[j]) + da;                // fract_f64 + add_f64
+      if (OP == 15) d[j] = (double)(unsigned)i8[j] + d[j], i8[j] += 1;        // cvt_f64_u32 + add_f64 + iadd
     }
   }
   float s = 0; for (int j = 0; j < 8; ++j) s += f[j] + (float)d[j] + i8[j];
@@ -42,5 +47,7 @@ int main() {
   run<2>("cvt_f64_i32+fma64+iadd", 3); run<3>("cvt_f32_f64+add_f64", 2);
   run<4>("cvt_f32_i32+mul+iadd", 3); run<5>("sqrt_f32+add", 2); run<6>("cmp+cndmask+2iadd", 4); run<7>("mul_lo_u32+add", 2);
   run<8>("div_f64", 1);
+  run<11>("floor_f64+add_f64", 2); run<12>("cvt_u32_f64+iadd+add_f64", 3); run<13>("cvt_f64_f32+add_f64+add_f32", 3); run<14>("fract_f64+add_f64", 2);
+  run<15>("cvt_f64_u32+add_f64+iadd", 3);
   return 0;
 }
