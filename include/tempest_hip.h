@@ -385,7 +385,10 @@ int tsdr_frames_combine_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *img, cons
  * devices == NULL: devices 0 .. n-1.  A group of ONE device is valid and returns the single-context results bit for bit.
  * A device listed MORE THAN ONCE gives members that share it; RCCL takes one rank per device, so such a group exchanges by
  * device-to-device copies and adds in member order instead (no communicator): the same split, slices, halos and offsets as
- * a group of distinct devices -- what the tests use to run the N > 1 logic on a one-GPU box; production lists distinct devices. */
+ * a group of distinct devices -- what the tests use to run the N > 1 logic on a one-GPU box; production lists distinct devices.
+ * The calls select each member's device in turn and put the calling thread's current HIP device back before they return; a
+ * call that fails has waited for everything it enqueued (nothing still reads or writes the caller's arrays).  One thread at a
+ * time per group. */
 typedef struct tsdr_group tsdr_group;
 int tsdr_group_create(const int *devices, int n, tsdr_group **out);
 void tsdr_group_destroy(tsdr_group *g);
