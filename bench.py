@@ -46,8 +46,10 @@ def run_group_child(devs, workload, timeout=150):
     cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "group_devices.py"), devs, workload]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
-    except subprocess.TimeoutExpired:
-        return {"devices": devs, "error": f"no result within {timeout} s (child process ended)"}
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        stage = [l for l in err.splitlines() if l.startswith("[group_devices]")]
+        return {"devices": devs, "error": f"no result within {timeout} s (child process ended); last stage reached: " + (stage[-1] if stage else "none")}
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"devices": devs, "error": f"exit code {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
@@ -681,7 +683,7 @@ def main():
             sets = [",".join(str(d) for d in range(n)) for n in sorted({min(2, ndev), min(8, ndev)}) if n > 1]
         multi = []
         for devs in sets:
-            multi.append(run_group_child(devs, args.workload, timeout=100))
+            multi.append(run_group_child(devs, args.workload, timeout=75))
             if "error" in multi[-1]:
                 break   # (a run that is already minutes long is not made longer by a second failure)
         if multi and isinstance(group, dict):

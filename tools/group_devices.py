@@ -19,9 +19,15 @@ nfr = int(round(w["acquisition"] * Fs)) // S
 iq = synth.synth_leak(Fs, x_t, y_t, fv, S * nfr + 17)
 out = {"devices": devices, "workload": wl, "frames_per_buffer": nfr, "rccl": len(set(devices)) == len(devices)}
 
+def stage(what):   # (bench.py reports the last one reached when it has to end this process)
+    print(f"[group_devices] {what}", file=sys.stderr, flush=True)
+
+
+stage("creating the contexts and communicators")
 ctx = T.Context(devices[0])
 g = T.Group(devices)
 try:
+    stage("frames: parity")
     # ---- frames: bit for bit the single-context result, both precisions, two successive buffers (lagged s_y, IIR state)
     same = True
     for prec in ("fast", "exact"):
@@ -38,6 +44,7 @@ try:
         sync.close()
     out["frames_bit_identical_to_single_context"] = bool(same)
     ctx.set_precision("fast"); g.set_precision("fast"); g.sync_reset()
+    stage("frames: timing")
     sync = T.SyncXY(ctx, 600, 800)
     for name, f in (("single_context", lambda: ctx.frames(sync, iq, S, y_t, x_t, np.float32(0.1), s1)),
                     ("group", lambda: g.frames(iq, S, y_t, x_t, np.float32(0.1), s2))):
@@ -50,6 +57,7 @@ try:
     out["frames_stage_ms_on_root_stream"] = [round(m, 4) for m in ms]
     sync.close()
     # ---- search: the reference's window (n = 2 indexMax) through both routes
+    stage("search")
     G0, p0, _ = ctx.autocorr_search(iq, Fs, 0.0, 0.1, 50, 90)
     srch = {}
     for route in ("root", "sharded"):
@@ -64,10 +72,12 @@ try:
                        "max_abs_dB_diff_vs_single_context": float(np.max(np.abs(Gg - G0)))}
     out["search"] = srch
     out["all_reduce_bytes"] = 4 * int(round(0.1 * Fs))
+    stage("getWelch")
     _, y1 = ctx.getWelch(Fs, iq)
     _, y2 = g.getWelch(Fs, iq)
     out["welch_max_abs_dB_diff_vs_single_context"] = float(np.max(np.abs(y1 - y2)))
 finally:
+    stage("closing")
     g.close()
     ctx.close()
 print(json.dumps(out), flush=True)
