@@ -18,5 +18,6 @@ for m in raster fused; do
   cp $O/${TAG}_pipe_${m}_trace_excerpt.csv $P/${TAG}_pipeline_${m}_kernel_trace.csv
 done
 for f in sq_search sq_raster queue_probe time_fft_rows time_welch_sizes time_waterfall_sizes; do [ -f $O/${TAG}_$f.txt ] && cp $O/${TAG}_$f.txt $P/${TAG}_$f.txt; done
+[ -f $O/${TAG}_fuzz_full.log ] && cp $O/${TAG}_fuzz_full.log $P/${TAG}_fuzz_full.log
 [ -f $O/${TAG}_gputest.log ] && tail -12 $O/${TAG}_gputest.log > $P/${TAG}_gputest_tail.log
 ls $P | grep $TAG
