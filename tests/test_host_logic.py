@@ -343,3 +343,19 @@ def test_search_route_choice():
     assert par.sharded_route_points(240_000, 60_000, 2) == 262_144
     for world in (2, 4, 8):
         assert par.search_route(240_000, 60_000, world) == "sharded"
+
+
+def test_bench_group_child_failure_is_reported_not_raised():
+    """bench.py's several-devices leg runs tools/group_devices.py in a child process: a child that cannot create its contexts
+    (here: no GPU in the container) or that overruns its time must come back as an {"error": ...} entry of the JSON line."""
+    import importlib.util
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the failure path needs a box without a GPU")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.run_group_child("0,1", "C2", timeout=240)
+    assert r["devices"] == "0,1" and "error" in r and "exit code" in r["error"]
+    r = bench.run_group_child("0,1", "C2", timeout=0.2)
+    assert "error" in r and "no result within" in r["error"]
