@@ -303,8 +303,9 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
  * call per buffer).  Like the reference's FFTW.PATIENT plans (Resampler.jl:31,39), the first submissions of a configuration
  * -- 15 buffers through each of 8 candidates, twice, results identical in all of them -- are timed with HIP events and the rest
  * use the fastest, the sequential order included, so the pipeline is never slower than one call per buffer by more than the
- * measurement's noise (options "pipe_mode" / "pipe_tune"; tsdr_frames_pipeline_info).  Up to three image / key / projection
- * slots rotate.
+ * measurement's noise (options "pipe_mode" / "pipe_tune"; tsdr_frames_pipeline_info).  What was settled for a configuration is
+ * kept (the last 16): going back to one -- a y_t / x_t correction undone, a raster asked for now and then -- measures nothing
+ * again.  Up to three image / key / projection slots rotate.
  * Ordering: a submission waits for whatever the context's stream holds at the time of the call (uploads, a producer's
  * kernels); tsdr_frames_flush -- which only enqueues -- orders the context's stream behind every submitted buffer, so
  * outputs are complete in stream order after the flush and on the host after tsdr_synchronize (which flushes).  Any

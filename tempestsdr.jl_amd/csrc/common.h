@@ -160,6 +160,8 @@ struct tsdr_ctx {
     int cand = 0, pos = 0, chosen = -1, round = 0;   // round 0: warm-up trial of candidate 0; 1, 2: the two measured passes
     float ms[kTuneCands] = {};      // mean interval between the tails of successive buffers, per arrangement
   } tune;
+  std::vector<PipeTune> tune_done;  // settled measurements of earlier configurations (a caller that goes back to one -- GUI.jl's
+                                    // y_t / x_t corrections, a raster asked for now and then -- does not measure it again); <= 16
   hipEvent_t tune_ev[kTrial] = {};
   int opt_beta_waves = 4;           // wavefronts per k_beta workgroup (4 or 8): alone the two tie; beside the pipeline's image kernel a 256-thread
                                     // workgroup fits the holes its retiring workgroups leave (raster-free 357 k vs 309 k frames/s)

@@ -245,7 +245,7 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
     if (name[5] == 'm') ctx->opt_pipe_mode = value < 0 ? -1 : value > 2 ? 2 : value;
     else if (name[5] == 'l') ctx->opt_pipe_lanes = value == 3 ? 3 : 2;
     else if (name[5] == 'p') ctx->opt_pipe_priority = value != 0;
-    else { ctx->opt_pipe_tune = value != 0; ctx->tune = tsdr_ctx::PipeTune{}; }   // (setting it also discards what was measured)
+    else { ctx->opt_pipe_tune = value != 0; ctx->tune = tsdr_ctx::PipeTune{}; ctx->tune_done.clear(); }   // (setting it also discards what was measured)
   }
   else if (!strcmp(name, "pipe_ext_event")) ctx->opt_pipe_ext_event = value != 0;
   else if (!strcmp(name, "sync_guard_ppb")) {

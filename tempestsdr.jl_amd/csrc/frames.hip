@@ -361,10 +361,16 @@ static int pipe_pick(tsdr_ctx *ctx, const tsdr_ctx::PipeKey &key) {
   if (ctx->opt_pipe_mode == 2) return 0;
   if (!ctx->opt_pipe_tune) return key.raster ? 1 : 4;
   tsdr_ctx::PipeTune &t = ctx->tune;
-  if (t.state == 0 || !(t.key == key)) {   // a new configuration: measure again
+  if (t.state == 0 || !(t.key == key)) {   // another configuration: one measured before, or measure now
+    if (t.state == 2) {                      // (what was settled for the previous one is kept)
+      if (ctx->tune_done.size() >= 16) ctx->tune_done.erase(ctx->tune_done.begin());
+      ctx->tune_done.push_back(t);
+    }
     t = tsdr_ctx::PipeTune{};
     t.key = key;
     t.state = 1;
+    for (size_t i = 0; i < ctx->tune_done.size(); ++i)
+      if (ctx->tune_done[i].key == key) { t = ctx->tune_done[i]; ctx->tune_done.erase(ctx->tune_done.begin() + (long)i); break; }
   }
   if (t.state == 1 && t.pos == tsdr_ctx::kTrial) {   // this arrangement's trial is complete
     int rc = pipe_drain(ctx);

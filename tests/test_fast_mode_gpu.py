@@ -214,6 +214,46 @@ def test_pipeline_measured_choice_walks_every_arrangement(tsdr, synth, want_rast
         ctx.close()
 
 
+def test_pipeline_measurement_is_kept_per_configuration(tsdr, synth):
+    """A caller that leaves a configuration and comes back to it (GUI.jl's y_t / x_t corrections and their undo, a raster asked
+    for now and then) finds the arrangement measured for it the first time: no second round of trials."""
+    from tempestsdr_jl_amd import api
+    ctx = tsdr.Context(0)
+    ctx.set_option("pipe_mode", -1)
+    ctx.set_option("pipe_tune", 1)
+    Fs, x_t, y_t, fv = 2.0e6, 1056, 628, 60.0
+    S = synth.samples_per_frame(Fs, fv)
+    P, npx = x_t * y_t, 600 * 800
+    buf = synth.synth_leak(Fs, x_t, y_t, fv, S)
+    sync = tsdr.SyncXY(ctx, 600, 800)
+    d_state = ctx.upload(np.zeros(npx, np.float32))
+    d_iq = ctx.upload(buf.view(np.float32))
+    d_fr, d_ra, d_ix = ctx.dev_alloc(npx * 4), ctx.dev_alloc(P * 4), ctx.dev_alloc(8)
+    try:
+        def submit(n, raster):
+            for _ in range(n):
+                assert api.frames_submit_d(ctx, sync, d_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, d_ra if raster else None, d_ix) == 1
+        submit(260, False)
+        first = ctx.pipeline_info()
+        assert first["trials_left"] == 0 and first["chosen"] >= 0
+        submit(3, True)                      # another configuration: its own trials begin
+        assert ctx.pipeline_info()["trials_left"] > 0
+        submit(1, False)                     # back: settled at once, the same table
+        again = ctx.pipeline_info()
+        assert again["trials_left"] == 0 and again["chosen"] == first["chosen"] and again["ms_per_buffer"] == first["ms_per_buffer"]
+        submit(260, True)                    # the other configuration is measured from the start (its 3 buffers were dropped)
+        assert ctx.pipeline_info()["trials_left"] == 0
+        submit(1, False)
+        assert ctx.pipeline_info()["ms_per_buffer"] == first["ms_per_buffer"]
+        api.frames_flush(ctx)
+        ctx.synchronize()
+    finally:
+        sync.close()
+        for p in (d_state, d_iq, d_fr, d_ra, d_ix):
+            ctx.dev_free(p)
+        ctx.close()
+
+
 def test_pipeline_pending_stage_is_drained_by_other_entry_points(ctx, tsdr, synth):
     """Submitted buffers run on the pipeline's internal streams.  Entry points that use the same SyncXY / IIR state
     outside the pipeline (tsdr_vsync_d here, tsdr_frames_d) and tsdr_sync_free must order themselves behind them first: the
