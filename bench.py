@@ -666,7 +666,7 @@ def main():
                                   "max_abs_dB_diff_vs_single_context": float(np.max(np.abs(Gg - G0)))}
                 group = {"devices": [local_rank], "all_reduce_bytes": 4 * k_hi, "search": out,
                          "note": "tsdr_group_search on a one-device group: what a single-process runtime (the reference's) calls; N > 1 "
-                                 "members need a multi-GPU box (tests/test_group_gpu.py, skipped on 1-GPU boxes)"}
+                                 "members need a multi-GPU box (tests/test_zz_group_devices_gpu.py, skipped on 1-GPU boxes)"}
             finally:
                 g.close()
         except Exception as e:

@@ -6,8 +6,7 @@ and the 1-rank all-reduce is the identity; this runs on every GPU box and execut
 ncclAllReduce on the library's stream) on real hardware.  The N > 1 split -- frame ranges, H2D slices, halos with their wrap,
 gather offsets -- runs on every box too, with 2 / 3 / 5 members SHARING the one device (a group may list a device more than
 once; it then exchanges by copies and adds instead of RCCL, which takes one rank per device).  Groups of 2 / 4 / 8 distinct
-devices over RCCL are compared with the single-context results where the box has that many GPUs (skipped otherwise):
-frames bit for bit, the search and getWelch within the f32 summation-order tolerance of the sharded sums, same argmax."""
+devices over RCCL: tests/test_zz_group_devices_gpu.py (a child process per group, last in the suite)."""
 import numpy as np
 import pytest
 
@@ -147,44 +146,6 @@ def test_members_sharing_one_device_run_the_split_logic(ctx, tsdr, capture, n):
             _, y1 = ctx.getWelch(Fs, iq, sizeFFT=size)
             _, y2 = g.getWelch(Fs, iq, sizeFFT=size)
             assert np.max(np.abs(y1 - y2)) < 2e-4, size
-    finally:
-        ctx.set_precision("fast")
-        g.close()
-
-
-@pytest.mark.parametrize("n", [2, 4, 8])
-def test_groups_of_several_devices_equal_single_context(ctx, tsdr, capture, n):
-    """N > 1 members of ONE process over RCCL / xGMI (skipped on boxes with fewer GPUs): frames sharded raggedly (7 frames),
-    gathered to the root, combined there -- bit for bit the single-context result, rasters included; the sharded search
-    (segment + halo partial sums, ONE all-reduce of indexMax f32) within 2e-4 dB with the same argmax; getWelch likewise."""
-    if _ndev() < n:
-        pytest.skip(f"needs {n} GPUs in one process (this box has {_ndev()})")
-    Fs, x_t, y_t, S, iq = capture
-    g = tsdr.Group(list(range(n)))
-    try:
-        for precision in ("fast", "exact"):
-            g.set_precision(precision)
-            g.set_option("sync_guard_auto", 0)
-            g.sync_reset()
-            ctx.set_precision(precision)
-            sync = tsdr.SyncXY(ctx, 600, 800)
-            s1 = np.zeros((600, 800), np.float32, order="F")
-            s2 = np.zeros((600, 800), np.float32, order="F")
-            for part in (iq[: 4 * S + 50], iq[4 * S:]):
-                _frames_equal(ctx.frames(sync, part, S, y_t, x_t, np.float32(0.1), s1, want_raster=True),
-                              g.frames(part, S, y_t, x_t, np.float32(0.1), s2, want_raster=True))
-                assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
-            sync.close()
-        G1, p1, _ = ctx.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90)
-        G2, p2, _ = g.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90, route="sharded")
-        assert g.timing()[0] == "sharded"
-        assert np.max(np.abs(G1 - G2)) < 2e-4 and p1 == p2
-        # the reference's own window (n = 2 indexMax): the halo makes sharding never pay, so "auto" keeps the root alone
-        G3, p3, _ = g.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90)
-        assert g.timing()[0] == "root" and np.array_equal(G1.view(np.uint32), G3.view(np.uint32)) and p3 == p1
-        _, y1 = ctx.getWelch(Fs, iq)
-        _, y2 = g.getWelch(Fs, iq)
-        assert np.max(np.abs(y1 - y2)) < 2e-4
     finally:
         ctx.set_precision("fast")
         g.close()
