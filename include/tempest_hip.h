@@ -120,8 +120,9 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 only the shift + IIR launches chained; 2 = one internal stream (the sequential order).
  *                 "pipe_tune" 1 (default): with "pipe_mode" -1 the first submissions of a configuration time every candidate
  *                 arrangement (tsdr_frames_pipeline_info) and the rest use the fastest; 0: arrangement 0 with rasters, 1 without.
+ *   "wait_ms"     bound of every host-side wait for a stream, in milliseconds (default 30000; 0 = unbounded): tsdr_wait_stats.
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
- * TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_TUNE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT
+ * TSDR_WAIT_MS / TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_TUNE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT
  * preset them, read once in tsdr_create. */
 int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value);
 /* running totals of the sync guard on this context: frames whose margins were checked / frames flagged (re-evaluated in
@@ -135,11 +136,25 @@ int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *
  * *buffers_exact = frame-loop calls that did so far; *switches = changes of route so far.  REPRODUCIBLE: every guarded
  * call's guard launch leaves its own {frames, flagged} counts in a pinned ring entry tagged with the call's sequence number,
  * and the decision for call k folds the entries of the calls <= k - 3 in submission order -- waiting for them if the host is
- * that far ahead (call k - 3 is complete in any steady state; the wait is a poll of pinned memory, bounded at 50 ms).  So
+ * that far ahead (call k - 3 is complete in any steady state; the wait is a poll of pinned memory, bounded at 50 ms per entry:
+ * tsdr_wait_stats).  So
  * WHICH buffers carry TSDR_EXACT pixels and which TSDR_FAST pixels is a function of the sequence of buffers alone, not of
  * host / GPU timing (tests/test_fast_mode_gpu.py:test_adaptive_route_is_reproducible_run_to_run); the price is that a
  * frame-loop call may return only when the call three before it has reached its guard launch. */
 int tsdr_sync_guard_auto(tsdr_ctx *ctx, int *exact_now, unsigned long long *buffers_exact, unsigned long long *switches);
+/* EVERY HOST-SIDE WAIT OF THE LIBRARY IS BOUNDED (round 6; replaces nothing in the reference -- GUI.jl:197-200 swallows a
+ * consumer task's exceptions, it cannot swallow a ccall that never returns).  Waits for a stream (results of the host-pointer
+ * entry points, tsdr_synchronize, workspace growth, a change of pipeline arrangement, destruction) poll a marker event for at
+ * most "wait_ms" milliseconds (tsdr_set_option / TSDR_WAIT_MS; default 30000; 0 = plain hipStreamSynchronize) and then return
+ * TSDR_EHIP with the waiting stage in tsdr_last_error; an object whose stream never completed is abandoned by its
+ * destructor (memory not released) instead of waiting for the device.  The adaptive route's wait for a guard ring entry is
+ * bounded at 50 ms per entry (2 ms once an entry has timed out, until one arrives again); an entry that did not arrive goes
+ * uncounted.  *timeouts = stream waits given up so far on this context, *guard_uncounted = guard entries that went uncounted. */
+int tsdr_wait_stats(tsdr_ctx *ctx, unsigned long long *timeouts, unsigned long long *guard_uncounted);
+/* Diagnostic: enqueue a host-side delay of `ms` milliseconds (0 .. 10000) on the context's stream -- what a stream held by
+ * something that does not complete looks like to the library.  tests/test_bounded_waits_gpu.py uses it to show that the
+ * frame-loop entry points and tsdr_synchronize return within their bounds while it lasts. */
+int tsdr_debug_hold_stream(tsdr_ctx *ctx, int ms);
 
 /* resident buffers for callers without their own device allocator */
 void *tsdr_dev_alloc(tsdr_ctx *ctx, size_t bytes);

@@ -43,6 +43,8 @@ _SIGS = {
     "tsdr_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "tsdr_sync_guard_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_int]),
     "tsdr_sync_guard_auto": (C.c_int, [vp, c_i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "tsdr_wait_stats": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "tsdr_debug_hold_stream": (C.c_int, [vp, C.c_int]),
     "tsdr_sync_guard_margins": (C.c_int, [vp, C.c_int, vp, c_i]),
     "tsdr_device_info": (C.c_int, [vp, C.c_char_p, c_sz, c_i, c_szp]),
     "tsdr_dev_alloc": (vp, [vp, c_sz]),

@@ -95,6 +95,12 @@ class Context:
         self.call("tsdr_sync_guard_auto", C.byref(e), C.byref(a), C.byref(b))
         return bool(e.value), int(a.value), int(b.value)
 
+    def wait_stats(self):
+        """(stream waits given up after "wait_ms", guard ring entries that went uncounted) on this context -- tsdr_wait_stats"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self.call("tsdr_wait_stats", C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def pipeline_info(self):
         """what tsdr_frames_submit_d measured on this context: dict(trials_left, chosen, ms_per_buffer[8], text)"""
         left, chosen, ms, text = C.c_int(0), C.c_int(-1), (C.c_float * 8)(), C.create_string_buffer(1024)

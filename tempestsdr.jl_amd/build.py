@@ -60,8 +60,9 @@ def build_hip(force=False, verbose=True):
                 sys.stderr.write(out)
     objs = [os.path.join(OBJ, s[:-4] + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
-        # librccl: the one collective of the path (tsdr_group_*: all-reduce of the autocorrelation accumulators over xGMI)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        # librccl -- the one collective of the path (tsdr_group_*: all-reduce of the autocorrelation accumulators over xGMI) -- is
+        # loaded with dlopen at the first group of distinct devices (group.hip:rccl_api), not linked
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)

@@ -12,6 +12,7 @@
 // Multi-GPU: tsdr_autocorr_partial_d computes the partial sum over a range of m on one
 // GPU as a zero-padded cross-correlation of the segment with segment+halo; ranks all-reduce the
 // partial vectors (linear domain) and only then apply 10log10(abs2) via tsdr_autocorr_finish_d.
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -400,12 +401,22 @@ static int amax_begin(tsdr_ctx *ctx, AmaxReq *r) {
 // memory and the host polls the sequence word
 static int amax_wait(tsdr_ctx *ctx, unsigned long long seq, size_t *idx, float *val) {
   bool seen = false;
+  std::chrono::steady_clock::time_point t0;
   for (unsigned it = 1; !seen; ++it) {
     seen = __atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) == seq;
-    if (!seen && (it & 0xFFFu) == 0 && hipStreamQuery(ctx->launch_stream) != hipErrorNotReady) break;  // finished or failed
+    if (seen || (it & 0xFFFu) != 0) continue;
+    if (hipStreamQuery(ctx->launch_stream) != hipErrorNotReady) break;  // finished or failed
+    (void)hipGetLastError();
+    // bounded like every host-side wait of the library (ctx.hip:wait_event)
+    const auto now = std::chrono::steady_clock::now();
+    if (it == 0x1000u) { t0 = now; continue; }
+    if (ctx->opt_wait_ms > 0 && now - t0 > std::chrono::milliseconds(ctx->opt_wait_ms)) {
+      ++ctx->wait_timeouts;
+      return set_err(ctx, TSDR_EHIP, "argmax: the stream did not deliver the result within %d ms (bounded host wait; option wait_ms)", ctx->opt_wait_ms);
+    }
   }
   if (!seen) {
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->launch_stream));
+    { int _w = tsdr::wait_stream(ctx, ctx->launch_stream, "argmax"); if (_w) return _w; }
     if (__atomic_load_n(&ctx->amax_host[1], __ATOMIC_ACQUIRE) != seq) return set_err(ctx, TSDR_EHIP, "argmax: result not delivered");
   }
   const unsigned long long h = *ctx->amax_host;

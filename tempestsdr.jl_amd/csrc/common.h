@@ -163,6 +163,14 @@ struct tsdr_ctx {
   std::vector<PipeTune> tune_done;  // settled measurements of earlier configurations (a caller that goes back to one -- GUI.jl's
                                     // y_t / x_t corrections, a raster asked for now and then -- does not measure it again); <= 16
   hipEvent_t tune_ev[kTrial] = {};
+  // Every host-side wait of this library is bounded (round 6): a stream that does not complete within opt_wait_ms returns
+  // TSDR_EHIP with the waiting stage in tsdr_last_error instead of holding the caller's thread (a GUI task inside a ccall) for
+  // good.  0: unbounded (plain hipStreamSynchronize).  Option "wait_ms" / TSDR_WAIT_MS.
+  int opt_wait_ms = 30000;
+  hipEvent_t wait_ev = nullptr;     // the marker a bounded wait polls (created on first use)
+  unsigned long long wait_timeouts = 0;   // bounded waits that gave up (tsdr_wait_stats)
+  unsigned long long guard_uncounted = 0; // guard ring entries that never arrived within their bound / were overwritten unread
+  bool guard_late = false;          // the last awaited guard entry timed out: later ones get a short bound until one arrives
   int opt_beta_waves = 4;           // wavefronts per k_beta workgroup (4 or 8): alone the two tie; beside the pipeline's image kernel a 256-thread
                                     // workgroup fits the holes its retiring workgroups leave (raster-free 357 k vs 309 k frames/s)
 
@@ -178,7 +186,11 @@ int hip_fail(tsdr_ctx *ctx, hipError_t e, const char *what);
 int lds_opt_in(tsdr_ctx *ctx, const void *fn, size_t bytes);
 // frames.hip: order the context's stream behind every buffer submitted to the pipeline (tsdr_frames_submit_d)
 int pipe_drain(tsdr_ctx *ctx);
-void pipe_sync_lanes(tsdr_ctx *ctx);   // host-side wait for the pipeline's internal streams
+int pipe_sync_lanes(tsdr_ctx *ctx);    // bounded host-side wait for the pipeline's internal streams (TSDR_EHIP when one is stuck)
+// bounded host-side waits (ctx.hip): poll a marker event, first spinning, then in short sleeps; TSDR_EHIP + message after
+// ctx->opt_wait_ms.  `what` names the stage for tsdr_last_error.
+int wait_stream(tsdr_ctx *ctx, hipStream_t s, const char *what);
+int wait_event(tsdr_ctx *ctx, hipEvent_t e, const char *what);
 void prof_begin(tsdr_ctx *ctx, const char *name);
 void prof_end(tsdr_ctx *ctx);
 
@@ -223,8 +235,7 @@ static inline int host_map(tsdr_ctx *ctx, const void *in, size_t in_bytes, void 
   int rc = run(din, dout);
   if (rc) return rc;
   if (out_bytes) TSDR_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return TSDR_OK;
+  return wait_stream(ctx, ctx->stream, "host wrapper: results");
 }
 static inline int ilog2(size_t v) { int l = 0; while ((size_t(1) << l) < v) ++l; return l; }
 static inline bool is_pow2(size_t v) { return v && !(v & (v - 1)); }

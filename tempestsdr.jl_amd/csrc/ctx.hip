@@ -1,8 +1,10 @@
 // ctx.hip -- context lifetime, workspace, error reporting, HIP-event measurement.
 #include <cstdarg>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <utility>
 
 #include "common.h"
@@ -39,6 +41,39 @@ int lds_opt_in(tsdr_ctx *ctx, const void *fn, size_t bytes) {
   return TSDR_OK;
 }
 
+// ---- bounded host-side waits -----------------------------------------------------------------------------------------
+// One marker event behind whatever the stream holds, then polls of that event: a tight spin first (results of a 15 us launch
+// must not pay a sleep), then 50 us sleeps.  hipStreamSynchronize has no time limit: a lane held behind something that
+// never completes would hold the caller's thread with it.
+int wait_event(tsdr_ctx *ctx, hipEvent_t e, const char *what) {
+  if (ctx->opt_wait_ms <= 0) { TSDR_HIP(ctx, hipEventSynchronize(e)); return TSDR_OK; }
+  using clk = std::chrono::steady_clock;
+  clk::time_point t0;
+  for (unsigned it = 1;; ++it) {
+    const hipError_t q = hipEventQuery(e);
+    if (q == hipSuccess) return TSDR_OK;
+    if (q != hipErrorNotReady) return hip_fail(ctx, q, what);
+    (void)hipGetLastError();   // (hipErrorNotReady is a status, not a failure for the next launch check to find)
+    if ((it & 0x3Fu) == 0) {
+      const auto now = clk::now();
+      if (it == 0x40u) { t0 = now; continue; }
+      const auto waited = now - t0;
+      if (waited > std::chrono::milliseconds(ctx->opt_wait_ms)) {
+        ++ctx->wait_timeouts;
+        return set_err(ctx, TSDR_EHIP, "%s: the stream did not complete within %d ms (bounded host wait; option wait_ms)", what, ctx->opt_wait_ms);
+      }
+      if (waited > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+}
+
+int wait_stream(tsdr_ctx *ctx, hipStream_t s, const char *what) {
+  if (ctx->opt_wait_ms <= 0) { TSDR_HIP(ctx, hipStreamSynchronize(s)); return TSDR_OK; }
+  if (!ctx->wait_ev) TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
+  TSDR_HIP(ctx, hipEventRecord(ctx->wait_ev, s));
+  return wait_event(ctx, ctx->wait_ev, what);
+}
+
 static hipEvent_t take_event(tsdr_ctx *ctx) {
   if (!ctx->ev_pool.empty()) {
     hipEvent_t e = ctx->ev_pool.back();
@@ -68,7 +103,7 @@ static int prof_collect(tsdr_ctx *ctx) {
     int rc = pipe_drain(ctx);
     if (rc) return rc;
   }
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   for (auto &r : ctx->prof) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -90,8 +125,9 @@ void *tsdr_ctx::scratch(int slot, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.cap >= bytes) return b.p;
   if (b.p) {
-    (void)hipStreamSynchronize(stream);
-    tsdr::pipe_sync_lanes(this);   // (the pipeline's lanes may be using the other half of this workspace)
+    // (the pipeline's lanes may be using the other half of this workspace; a stream that is stuck keeps it -- freeing would wait
+    // for the device without a bound)
+    if (tsdr::wait_stream(this, stream, "workspace growth") || tsdr::pipe_sync_lanes(this)) return nullptr;
     (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
@@ -162,6 +198,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_PIPE_TUNE")) ctx->opt_pipe_tune = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_EXT_EVENT")) ctx->opt_pipe_ext_event = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;
+  if (const char *e = getenv("TSDR_WAIT_MS")) ctx->opt_wait_ms = atoi(e) < 0 ? 0 : atoi(e);
   if (const char *e = getenv("TSDR_BETA_WAVES")) ctx->opt_beta_waves = atoi(e) == 8 ? 8 : 4;
   return ctx;
 }
@@ -170,8 +207,13 @@ void tsdr_destroy(tsdr_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)tsdr::pipe_drain(ctx);
-  (void)hipStreamSynchronize(ctx->stream);
-  tsdr::pipe_sync_lanes(ctx);
+  if (tsdr::wait_stream(ctx, ctx->stream, "tsdr_destroy") || tsdr::pipe_sync_lanes(ctx)) {
+    // a stream of this context never completed: releasing its memory, streams and events would wait for the device without a
+    // bound (hipFree synchronises) or pull them from under a launch.  The context is abandoned: the caller's thread returns.
+    fprintf(stderr, "tempest_hip: tsdr_destroy: %s -- context abandoned, its device memory is not released\n", ctx->err.c_str());
+    return;
+  }
+  if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
   for (auto &l : ctx->pool) if (l) (void)hipStreamDestroy(l);
   for (auto &e : ctx->tune_ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : ctx->ev_img) if (e) (void)hipEventDestroy(e);
@@ -201,7 +243,7 @@ int tsdr_set_stream(tsdr_ctx *ctx, void *hip_stream) {
     int rc = tsdr::pipe_drain(ctx);
     if (rc) return rc;
   }
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   if (hip_stream) {
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
@@ -248,6 +290,7 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
     else { ctx->opt_pipe_tune = value != 0; ctx->tune = tsdr_ctx::PipeTune{}; ctx->tune_done.clear(); }   // (setting it also discards what was measured)
   }
   else if (!strcmp(name, "pipe_ext_event")) ctx->opt_pipe_ext_event = value != 0;
+  else if (!strcmp(name, "wait_ms")) ctx->opt_wait_ms = value < 0 ? 0 : value;
   else if (!strcmp(name, "sync_guard_ppb")) {
     if (value < 0 || value > 100000000) return tsdr::set_err(ctx, TSDR_EINVAL, "sync_guard_ppb must be in [0, 1e8]");
     ctx->guard_thr = (float)value * 1e-9f;
@@ -272,6 +315,21 @@ int tsdr_sync_guard_auto(tsdr_ctx *ctx, int *exact_now, unsigned long long *buff
   return TSDR_OK;
 }
 
+int tsdr_wait_stats(tsdr_ctx *ctx, unsigned long long *timeouts, unsigned long long *guard_uncounted) {
+  if (!ctx) return TSDR_EINVAL;
+  if (timeouts) *timeouts = ctx->wait_timeouts;
+  if (guard_uncounted) *guard_uncounted = ctx->guard_uncounted;
+  return TSDR_OK;
+}
+
+static void hold_cb(void *p) { std::this_thread::sleep_for(std::chrono::milliseconds((long)(intptr_t)p)); }
+
+int tsdr_debug_hold_stream(tsdr_ctx *ctx, int ms) {
+  if (!ctx || ms < 0 || ms > 10000) return TSDR_EINVAL;
+  TSDR_HIP(ctx, hipLaunchHostFunc(ctx->stream, hold_cb, (void *)(intptr_t)ms));
+  return TSDR_OK;
+}
+
 int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, unsigned long long *frames_reevaluated, int reset) {
   if (!ctx) return TSDR_EINVAL;
   unsigned long long h[2] = {0ull, 0ull};
@@ -280,7 +338,7 @@ int tsdr_sync_guard_stats(tsdr_ctx *ctx, unsigned long long *frames_checked, uns
   if (ctx->guard_stats) {
     TSDR_HIP(ctx, hipMemcpyAsync(h, ctx->guard_stats, 16, hipMemcpyDeviceToHost, ctx->stream));
     if (reset) TSDR_HIP(ctx, hipMemsetAsync(ctx->guard_stats, 0, 16, ctx->stream));
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   }
   if (frames_checked) *frames_checked = h[0];
   if (frames_reevaluated) *frames_reevaluated = h[1];
@@ -303,7 +361,7 @@ int tsdr_sync_guard_margins(tsdr_ctx *ctx, int max_frames, float *margins, int *
   std::vector<uint2> h((size_t)nf * nbb);
   TSDR_HIP(ctx, hipMemcpyAsync(h.data(), (const char *)gb_ws.p + ctx->guard_last_off, h.size() * sizeof(uint2), hipMemcpyDeviceToHost,
                                ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   for (int f = 0; f < nf; ++f)
     for (int axis = 0; axis < 2; ++axis) {  // the same top-2 merge as guard_eval (guard.h)
       const uint2 *e = h.data() + (size_t)f * nbb + (axis ? nbx : 0);
@@ -327,7 +385,7 @@ int tsdr_synchronize(tsdr_ctx *ctx) {
     int rc = tsdr::pipe_drain(ctx);
     if (rc) return rc;
   }
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   return TSDR_OK;
 }
 
@@ -356,7 +414,7 @@ int tsdr_dev_free(tsdr_ctx *ctx, void *dev) {
   if (dev) {
     int rc = tsdr::pipe_drain(ctx);  // a submitted buffer may still have to write into this allocation
     if (rc) return rc;
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
     TSDR_HIP(ctx, hipFree(dev));
   }
   return TSDR_OK;
@@ -366,7 +424,7 @@ int tsdr_upload(tsdr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes
   if (!ctx || (bytes && (!dst_dev || !src_host))) return TSDR_EINVAL;
   if (bytes) {
     TSDR_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   }
   return TSDR_OK;
 }
@@ -375,7 +433,7 @@ int tsdr_download(tsdr_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
   if (!ctx || (bytes && (!dst_host || !src_dev))) return TSDR_EINVAL;
   if (bytes) {
     TSDR_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   }
   return TSDR_OK;
 }
@@ -389,7 +447,7 @@ int tsdr_timer_start(tsdr_ctx *ctx) {
 int tsdr_timer_stop(tsdr_ctx *ctx, double *ms) {
   if (!ctx || !ms) return TSDR_EINVAL;
   TSDR_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
-  TSDR_HIP(ctx, hipEventSynchronize(ctx->t1));
+  { int _w = tsdr::wait_event(ctx, ctx->t1, __func__); if (_w) return _w; }
   float f = 0.f;
   TSDR_HIP(ctx, hipEventElapsedTime(&f, ctx->t0, ctx->t1));
   *ms = f;

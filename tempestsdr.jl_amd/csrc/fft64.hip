@@ -142,9 +142,9 @@ int fft64_d(tsdr_ctx *ctx, double2 *data, double2 *scratch, size_t N, int dir) {
     hipLaunchKernelGGL(k_blue64_post, dim3(stream_grid(ctx, N)), dim3(256), 0, ctx->launch_stream, (const double2 *)a, N, sign, g, data);
     rc = checked("fft64: k_blue64_post");
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  // (a stream that never completes keeps its scratch: hipFree would wait for the device without a bound)
+  if (int w = tsdr::wait_stream(ctx, ctx->stream, "fft64")) return rc ? rc : w;
   (void)hipFree(a); (void)hipFree(b); (void)hipFree(t);
-  if (!rc && e != hipSuccess) rc = hip_fail(ctx, e, "fft64");
   return rc;
 }
 

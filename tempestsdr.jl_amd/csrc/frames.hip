@@ -76,32 +76,43 @@ struct PrecisionScope {  // a call that has to run in TSDR_EXACT restores the ca
 constexpr unsigned kGuardAutoWindow = 60;
 static void guard_auto_update(tsdr_ctx *ctx, unsigned long long upto) {
   if (!ctx->guard_ring) return;
+  using clk = std::chrono::steady_clock;
+  // entries the host never read before their ring slot was handed to a later call (only when waits were given up or
+  // "guard_nowait" left the host behind): gone, counted as such
+  if (ctx->guard_seq > (unsigned long long)tsdr_ctx::kGuardRing && ctx->guard_consumed < ctx->guard_seq - tsdr_ctx::kGuardRing) {
+    ctx->guard_uncounted += ctx->guard_seq - tsdr_ctx::kGuardRing - ctx->guard_consumed;
+    ctx->guard_consumed = ctx->guard_seq - tsdr_ctx::kGuardRing;
+  }
   for (; ctx->guard_consumed < upto; ++ctx->guard_consumed) {
     const unsigned long long j = ctx->guard_consumed, want = (j + 1) & 0xFFFFull;
     volatile unsigned long long *e = ctx->guard_ring + (j % tsdr_ctx::kGuardRing);
     unsigned long long w = 0;
     bool seen = false;
-    std::chrono::steady_clock::time_point t0;
+    // The wait is bounded: 50 ms in all (2 ms once an earlier entry has already timed out, until one arrives again), and it
+    // ends early when nothing is in flight any more (the entry's launch was never enqueued: a call that failed half-way).
+    // t_start is never moved; t_look paces the looks at the streams (every 2 ms: a stream query may put a marker packet into
+    // the queue it asks about, so the ordinary wait makes no HIP call at all).
+    clk::time_point t_start, t_look;
+    const auto bound = std::chrono::milliseconds(ctx->guard_late ? 2 : 50);
     for (unsigned it = 1; !seen; ++it) {
       w = __atomic_load_n(e, __ATOMIC_ACQUIRE);
       seen = (w >> 48) == want;
-      if (!seen && ctx->opt_guard_nowait) return;   // (measurement switch: fold what has arrived, never wait -- not reproducible)
-      if (!seen && (it & 0x3FFu) == 0) {
-        // (no HIP call in the ordinary wait: a stream query may put a marker packet into the queue it asks about)
-        if (it == 0x400u) { t0 = std::chrono::steady_clock::now(); continue; }
-        const auto waited = std::chrono::steady_clock::now() - t0;
-        if (waited < std::chrono::milliseconds(2)) continue;
-        // the entry's launch may never have been enqueued (a call that failed half-way): once nothing is in flight any
-        // more, nothing will write it.  And a caller's own stream may be held by something only this thread can release:
-        // the wait is bounded (50 ms), the entry then goes uncounted
-        bool idle = hipStreamQuery(ctx->stream) == hipSuccess;
-        for (auto l : ctx->pool) if (l && idle) idle = hipStreamQuery(l) == hipSuccess;
-        (void)hipGetLastError();
-        if (idle || waited > std::chrono::milliseconds(50)) { w = __atomic_load_n(e, __ATOMIC_ACQUIRE); seen = (w >> 48) == want; break; }
-        t0 += std::chrono::milliseconds(2);   // (next look at the streams in another 2 ms)
-      }
+      if (seen) break;
+      if (ctx->opt_guard_nowait) return;   // (measurement switch: fold what has arrived, never wait -- not reproducible)
+      if ((it & 0x3FFu) != 0) continue;
+      const auto now = clk::now();
+      if (it == 0x400u) { t_start = now; t_look = now + std::chrono::milliseconds(2); continue; }
+      const bool over = now - t_start > bound;
+      if (!over && now < t_look) continue;
+      bool idle = !over && hipStreamQuery(ctx->stream) == hipSuccess;
+      if (!over) for (auto l : ctx->pool) if (l && idle) idle = hipStreamQuery(l) == hipSuccess;
+      (void)hipGetLastError();
+      if (idle || over) { w = __atomic_load_n(e, __ATOMIC_ACQUIRE); seen = (w >> 48) == want; break; }
+      t_look = now + std::chrono::milliseconds(2);
     }
-    if (!seen || !ctx->opt_guard_auto) continue;
+    ctx->guard_late = !seen;
+    if (!seen) { ++ctx->guard_uncounted; continue; }
+    if (!ctx->opt_guard_auto) continue;
     ctx->guard_win_c += (unsigned)((w >> 24) & 0xFFFFFFull);
     ctx->guard_win_f += (unsigned)(w & 0xFFFFFFull);
     if (ctx->guard_win_c < kGuardAutoWindow) continue;
@@ -349,8 +360,9 @@ int pipe_drain(tsdr_ctx *ctx) {
 }
 
 // host-side wait for the lanes (workspace reallocation, destruction, a change of arrangement)
-void pipe_sync_lanes(tsdr_ctx *ctx) {
-  for (auto l : ctx->pool) if (l) (void)hipStreamSynchronize(l);
+int pipe_sync_lanes(tsdr_ctx *ctx) {
+  for (auto l : ctx->pool) if (l) { int rc = wait_stream(ctx, l, "pipeline lane"); if (rc) return rc; }
+  return TSDR_OK;
 }
 
 // the arrangement of this submission: forced ("pipe_mode" >= 0), the geometry rule of rounds 3-4 ("pipe_tune" = 0), or the
@@ -375,7 +387,8 @@ static int pipe_pick(tsdr_ctx *ctx, const tsdr_ctx::PipeKey &key) {
   if (t.state == 1 && t.pos == tsdr_ctx::kTrial) {   // this arrangement's trial is complete
     int rc = pipe_drain(ctx);
     if (rc) return rc;
-    pipe_sync_lanes(ctx);
+    rc = pipe_sync_lanes(ctx);
+    if (rc) return rc;
     // mean interval between the tails of successive buffers over a whole number of lane rotations (12 intervals: with two or
     // three lanes the tails complete in bursts, so a median of single intervals says nothing), after 3 buffers of ramp-up
     float ms = 0.f;
@@ -452,7 +465,8 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   if (!(ctx->pipe_key == key) || ctx->pipe_cand_now != cand) {
     rc = pipe_drain(ctx);
     if (rc) return rc;
-    pipe_sync_lanes(ctx);
+    rc = pipe_sync_lanes(ctx);
+    if (rc) return rc;
     for (bool &u : ctx->ev_tail_used) u = false;
     ctx->pipe_seq = 0;
     ctx->pipe_last_slot = -1;
@@ -651,7 +665,7 @@ int tsdr_frames(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, si
   if (d_frames && nb) TSDR_HIP(ctx, hipMemcpyAsync(frames_out, d_frames, nb * npx * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (d_raster && nb) TSDR_HIP(ctx, hipMemcpyAsync(raster_out, d_raster, nb * P * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (d_idx && nb) TSDR_HIP(ctx, hipMemcpyAsync(sync_idx, d_idx, nb * 8, hipMemcpyDeviceToHost, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   return TSDR_OK;
 }
 

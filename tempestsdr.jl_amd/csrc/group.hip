@@ -21,7 +21,8 @@
 //
 // Per-frame / per-lag arithmetic is the single-context library's, unchanged: a group of one device returns the
 // single-context results bit for bit (tests/test_group_gpu.py); N > 1 differs only by the f32 order of the partial sums.
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded at the first group of distinct devices (rccl_api below)
 
 #include <algorithm>
 #include <chrono>
@@ -54,6 +55,53 @@ struct tsdr_group {
 namespace {
 
 using namespace tsdr;
+
+// librccl is loaded on demand (dlopen), not linked: single-GPU users of libtempest_hip.so do not need it installed, and a
+// process that already holds an RCCL (PyTorch's) gets that same copy.
+struct RcclApi {
+  decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&::ncclAllReduce) AllReduce = nullptr;
+  decltype(&::ncclGroupStart) GroupStart = nullptr;
+  decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&::ncclSend) Send = nullptr;
+  decltype(&::ncclRecv) Recv = nullptr;
+  decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+  std::string why;
+};
+const RcclApi &rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) { const char *e = dlerror(); a.why = std::string("librccl not found: ") + (e ? e : "dlopen failed"); return a; }
+    bool all = true;
+    auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p) { all = false; a.why = std::string("librccl lacks ") + n; } return p; };
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(sym("ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = all;
+    return a;
+  }();
+  return api;
+}
+#define ncclCommInitAll rccl_api().CommInitAll
+#define ncclCommDestroy rccl_api().CommDestroy
+#define ncclAllReduce rccl_api().AllReduce
+#define ncclGroupStart rccl_api().GroupStart
+#define ncclGroupEnd rccl_api().GroupEnd
+#define ncclSend rccl_api().Send
+#define ncclRecv rccl_api().Recv
+#define ncclGetErrorString rccl_api().GetErrorString
 
 int gerr(tsdr_group *g, int status, const std::string &what) {
   if (g) g->err = what;
@@ -103,7 +151,7 @@ __global__ __launch_bounds__(256) void k_db(float *__restrict__ y, size_t n) {
 int sync_all(tsdr_group *g) {
   for (int i = 0; i < g->n; ++i) {
     G_HIP(g, hipSetDevice(g->dev[i]));
-    G_HIP(g, hipStreamSynchronize(g->ctx[i]->stream));
+    if (int w = tsdr::wait_stream(g->ctx[i], g->ctx[i]->stream, "group: member stream")) return member_err(g, i, w, "sync_all");
   }
   return TSDR_OK;
 }
@@ -158,7 +206,7 @@ struct CallScope {
   ~CallScope() {
     if (!ok && g)
       for (int i = 0; i < g->n; ++i)
-        if (g->ctx[i] && hipSetDevice(g->dev[i]) == hipSuccess) (void)hipStreamSynchronize(g->ctx[i]->stream);
+        if (g->ctx[i] && hipSetDevice(g->dev[i]) == hipSuccess) (void)tsdr::wait_stream(g->ctx[i], g->ctx[i]->stream, "group: failed call");
     if (prev >= 0) (void)hipSetDevice(prev);
     (void)hipGetLastError();
   }
@@ -201,12 +249,21 @@ int tsdr_group_create(const int *devices, int n, tsdr_group **out) {
   }
   // single-process ranks: rank i = member i on devices[i]; the collectives below run inside ncclGroupStart / End
   // (members sharing a device: RCCL takes one rank per device, so such a group exchanges by copies and adds on the device)
-  if (ok && !g->virt) ok = ncclCommInitAll(g->comm.data(), n, g->dev.data()) == ncclSuccess;
+  bool comm_failed = false;
+  if (ok && !g->virt) {
+    if (!rccl_api().ok) {
+      fprintf(stderr, "tempest_hip: tsdr_group_create: %s (a group of distinct devices needs RCCL)\n", rccl_api().why.c_str());
+      ok = false;
+    } else {
+      ok = ncclCommInitAll(g->comm.data(), n, g->dev.data()) == ncclSuccess;
+      comm_failed = !ok;   // (what a failed ncclCommInitAll left in comm[] is not ours to destroy)
+    }
+  }
   if (ok) ok = hipSetDevice(g->dev[0]) == hipSuccess;
   for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreate(&g->t[k]) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
-    for (auto &c : g->comm) c = c ? (ncclCommDestroy(c), nullptr) : nullptr;
+    if (!comm_failed) for (auto &c : g->comm) c = c ? (ncclCommDestroy(c), nullptr) : nullptr;
     for (int i = 0; i < n; ++i) {
       if (g->ev[i]) { (void)hipSetDevice(g->dev[i]); (void)hipEventDestroy(g->ev[i]); }
       if (g->ctx[i]) tsdr_destroy(g->ctx[i]);
@@ -224,7 +281,11 @@ void tsdr_group_destroy(tsdr_group *g) {
   CallScope scope(nullptr);
   for (int i = 0; i < g->n; ++i) {
     (void)hipSetDevice(g->dev[i]);
-    (void)tsdr_synchronize(g->ctx[i]);
+    if (tsdr_synchronize(g->ctx[i])) {
+      // a member's stream never completed (bounded wait): destroying communicators and contexts would wait with it
+      fprintf(stderr, "tempest_hip: tsdr_group_destroy: %s -- group abandoned, its device memory is not released\n", tsdr_last_error(g->ctx[i]));
+      return;
+    }
   }
   for (auto c : g->comm) if (c) (void)ncclCommDestroy(c);
   (void)hipSetDevice(g->dev[0]);
@@ -319,7 +380,7 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
     if (rc) return member_err(g, 0, rc, "group_search");
     G_HIP(g, hipEventRecord(g->t[3], c0->stream));
     if (out) G_HIP(g, hipMemcpyAsync(out, dout, cnt * 4, hipMemcpyDeviceToHost, c0->stream));
-    G_HIP(g, hipStreamSynchronize(c0->stream));
+    if (int w = tsdr::wait_stream(c0, c0->stream, "group_search")) return member_err(g, 0, w, "group_search");
     stage_times(g);
     return scope.done();
   }

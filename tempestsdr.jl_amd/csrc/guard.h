@@ -26,6 +26,9 @@ struct GuardArgs {
   unsigned long long *host = nullptr;   // pinned ring entry of THIS call: host_tag << 48 | frames << 24 | flagged (what the
   unsigned long long host_tag = 0;      // adaptive route's decision folds in submission order, frames.hip:guard_auto_update)
   int count_only = 0;                   // 1: the buffer was computed in the exact sequence as a whole; only count
+  // a call of more than kGuardChunk frames is several launches: the earlier ones add their counts to `acc` ({frames, flagged},
+  // per pipeline lane, zero between calls; host == null for them), the last one publishes the call's totals and clears it
+  unsigned *acc = nullptr;
 };
 
 constexpr int kGuardChunk = 256;   // frames per guard_image launch

@@ -110,8 +110,9 @@ int tsdr_ring_create(tsdr_ctx *ctx, size_t nEch, int depth, int fmt, float scale
 
 void tsdr_ring_free(tsdr_ring *r) {
   if (!r) return;
-  if (r->copy) { (void)hipStreamSynchronize(r->copy); (void)hipStreamDestroy(r->copy); }
-  if (r->ctx) (void)hipStreamSynchronize(r->ctx->stream);
+  // (bounded like every host-side wait of the library: a copy or consumer stream that never completes keeps the ring's memory)
+  if (r->ctx && ((r->copy && tsdr::wait_stream(r->ctx, r->copy, "tsdr_ring_free")) || tsdr::wait_stream(r->ctx, r->ctx->stream, "tsdr_ring_free"))) return;
+  if (r->copy) (void)hipStreamDestroy(r->copy);
   for (int i = 0; i < 2; ++i) {
     if (r->dev[i]) (void)hipFree(r->dev[i]);
     if (r->raw[i]) (void)hipFree(r->raw[i]);
@@ -132,7 +133,7 @@ static void ring_wait_slot_idle(tsdr_ring *r, int pos) {
       r->cv.wait(lk, [&] { return !(r->staging[i] && r->dma_slot[i] == pos); });  // until its event is recorded
       pending = r->dma_slot[i] == pos;
     }
-    if (pending) (void)hipEventSynchronize(r->ready[i]);
+    if (pending) (void)tsdr::wait_event(r->ctx, r->ready[i], "ring: DMA out of the slot about to be rewritten");
   }
 }
 

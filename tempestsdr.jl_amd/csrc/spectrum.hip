@@ -681,7 +681,7 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
     H0[k] = make_double2(nearbyint(cos(th)), nearbyint(sin(th)));
   }
   hipError_t e = hipMemcpyAsync(r->H, H0.data(), N * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) { if (int w = tsdr::wait_stream(ctx, ctx->stream, "init_resampler upload")) return w; }   // (a stuck stream keeps the tables)
   if (e != hipSuccess) { (void)hipFree(scratch); tsdr_resampler_free(r); return hip_fail(ctx, e, "init_resampler upload"); }
   // h = ifft(H0) .* blackman  (ifft on ComplexF32 data in the reference, the window and everything after it in f64);
   // H = fft(h) .* (-1)^k -- on the device in f64 (fft64.hip)
@@ -695,10 +695,12 @@ int tsdr_resampler_init(tsdr_ctx *ctx, size_t bufferSize, int upCoeff, tsdr_resa
     if (rc2) return rc2;
     TSDR_LAUNCH(ctx, "lpf_altsign64", k_altsign64, dim3(stream_grid(ctx, N)), dim3(256), 0, r->H, N);
     if (r->Hs) TSDR_LAUNCH(ctx, "lpf_herm_half", k_herm_half, dim3(stream_grid(ctx, N / 2 + 1)), dim3(256), 0, (const double2 *)r->H, N, r->Hs);
-    TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
     return TSDR_OK;
   };
+  const unsigned long long wt = ctx->wait_timeouts;
   int rc = finish();
+  if (ctx->wait_timeouts != wt) return rc;   // (a stream that never completed keeps scratch and tables: hipFree would wait without a bound)
   (void)hipFree(scratch);
   if (rc) { tsdr_resampler_free(r); return rc; }
   if (r->Hs) {  // twiddle tables of k_resamp_mid (resamp_tw): evaluated in long double, rounded once
@@ -784,7 +786,7 @@ int tsdr_resampler_lpf(tsdr_resampler *r, float *H_host) {
   if (!tmp) return TSDR_ENOMEM;
   TSDR_LAUNCH(ctx, "lpf_c32", k_c64_to_c32, dim3(stream_grid(ctx, r->sizeFFT)), dim3(256), 0, (const double2 *)r->H, r->sizeFFT, tmp);
   TSDR_HIP(ctx, hipMemcpyAsync(H_host, tmp, r->sizeFFT * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   return TSDR_OK;
 }
 
@@ -792,7 +794,7 @@ int tsdr_resampler_lpf64(tsdr_resampler *r, double *H_host) {
   if (!r || !H_host) return TSDR_EINVAL;
   tsdr_ctx *ctx = r->ctx;
   TSDR_HIP(ctx, hipMemcpyAsync(H_host, r->H, r->sizeFFT * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   return TSDR_OK;
 }
 
@@ -809,7 +811,7 @@ int tsdr_fft_z2z(tsdr_ctx *ctx, const double *in, double *out, size_t n, int dir
   hipError_t e = hipMemcpyAsync(d, in, n * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) rc = fft64_d(ctx, d, sc, n, dir);
   if (e == hipSuccess && !rc) e = hipMemcpyAsync(out, d, n * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) { if (int w = tsdr::wait_stream(ctx, ctx->stream, "fft_z2z")) return rc ? rc : w; }   // (a stuck stream keeps its scratch)
   (void)hipFree(d); (void)hipFree(sc);
   if (!rc && e != hipSuccess) rc = hip_fail(ctx, e, "fft_z2z");
   return rc;
@@ -817,7 +819,7 @@ int tsdr_fft_z2z(tsdr_ctx *ctx, const double *in, double *out, size_t n, int dir
 
 void tsdr_resampler_free(tsdr_resampler *r) {
   if (!r) return;
-  if (r->ctx) (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->ctx && tsdr::wait_stream(r->ctx, r->ctx->stream, "tsdr_resampler_free")) return;   // (a stuck stream keeps its tables)
   if (r->H) (void)hipFree(r->H);
   if (r->Hs) (void)hipFree(r->Hs);
   if (r->work) (void)hipFree(r->work);

@@ -765,8 +765,13 @@ __global__ __launch_bounds__(512, 2) void k_guard(GuardAllArgs a) {
           if (n) atomicAdd(&a.g.stats[1], (unsigned long long)n);
           // this call's own counts into its pinned ring entry (guard launches of two pipeline lanes may complete in either
           // order: the host folds the entries by sequence number, not by arrival)
+          unsigned tf = (unsigned)a.frames, tn = (unsigned)n;
+          if (a.g.acc) {   // (launches of one call are stream-ordered: plain read-modify-write)
+            tf += a.g.acc[0]; tn += a.g.acc[1];
+            a.g.acc[0] = a.g.host ? 0u : tf; a.g.acc[1] = a.g.host ? 0u : tn;
+          }
           if (a.g.host)
-            __hip_atomic_store(a.g.host, (a.g.host_tag << 48) | ((unsigned long long)(unsigned)a.frames << 24) | (unsigned long long)(unsigned)n,
+            __hip_atomic_store(a.g.host, (a.g.host_tag << 48) | ((unsigned long long)tf << 24) | (unsigned long long)(tn & 0xFFFFFFu),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
@@ -857,17 +862,22 @@ int sync_guard_d(tsdr_sync *s, const float *iq, size_t S, int y_t, int x_t, int 
   for (int f0 = 0; f0 < frames; f0 += kGuardChunk) {   // (the list of flagged frames lives in LDS)
     const int nf = std::min(kGuardChunk, frames - f0);
     // queue words: zero between launches (the kernel restores that itself)
-    const size_t words = 2 + 2 * (size_t)kGuardChunk;
+    const size_t words = 2 + 2 * (size_t)kGuardChunk + 2;   // + the per-call accumulator of multi-launch calls (GuardArgs::acc)
     unsigned *&qwords = ctx->guard_sync[ctx->pipe_lane & 3];   // (guard launches of different pipeline lanes may run side by side)
     if (!qwords) {
       TSDR_HIP(ctx, hipMalloc((void **)&qwords, words * 4));
       TSDR_HIP(ctx, hipMemsetAsync(qwords, 0, words * 4, ctx->launch_stream));
     }
     a.g = g;
+    if (frames > kGuardChunk) {   // the call's ring entry is written once, by its last launch, with the call's totals
+      a.g.acc = qwords + 2 + 2 * (size_t)kGuardChunk;
+      if (f0 + nf < frames) a.g.host = nullptr;
+    }
     a.g.top2 = g.top2 + (size_t)f0 * (size_t)(g.nbx + g.nby);
     a.g.flags = g.flags + f0;
     a.frames = nf;
-    a.iq = iq + (size_t)f0 * S * 2; a.in_stride = S; a.img = img + (size_t)f0 * img_stride; a.img_stride = img_stride;
+    // (an sc16 buffer has one float's worth of bytes per sample)
+    a.iq = iq + (size_t)f0 * S * iq_floats(ctx->iq_fmt); a.in_stride = S; a.img = img + (size_t)f0 * img_stride; a.img_stride = img_stride;
     a.tilesA = (int)(ceil_div((size_t)y, 64) * (size_t)a.dq.tiles_c);
     a.y_t = y; a.x_t = x;
     a.proj_stride = proj_floats(y, x, pl); a.ncp = pl.ncp; a.nrp = pl.nrp;
@@ -1010,7 +1020,7 @@ int tsdr_sync_reset(tsdr_sync *s) {
   const int one[4] = {1, 1, 0, 0};  // findmax of an all-zero beta_y is index (1,1)
   s->cur = 0;
   TSDR_HIP(ctx, hipMemcpyAsync(s->pending, one, 16, hipMemcpyHostToDevice, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   return TSDR_OK;
 }
 
@@ -1018,7 +1028,7 @@ void tsdr_sync_free(tsdr_sync *s) {
   if (!s) return;
   if (s->ctx) {
     (void)pipe_drain(s->ctx);  // submitted buffers read this state's pending s_y: they come first
-    (void)hipStreamSynchronize(s->ctx->stream);
+    if (tsdr::wait_stream(s->ctx, s->ctx->stream, "tsdr_sync_free")) return;   // (a stuck stream keeps the state's memory)
   }
   for (auto &b : s->bset) for (float *p : b) if (p) (void)hipFree(p);
   if (s->pending) (void)hipFree(s->pending);
@@ -1062,7 +1072,7 @@ int tsdr_vsync(tsdr_sync *s, const float *img, int *s_y, int *s_x) {
   if (rc) return rc;
   int hidx[2];
   TSDR_HIP(ctx, hipMemcpyAsync(hidx, didx, 8, hipMemcpyDeviceToHost, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   *s_y = hidx[0]; *s_x = hidx[1];
   return TSDR_OK;
 }
@@ -1076,7 +1086,7 @@ int tsdr_sync_beta(tsdr_sync *s, int which, float *beta_host) {
     if (rc) return rc;
   }
   TSDR_HIP(ctx, hipMemcpyAsync(beta_host, which == 0 ? s->beta_x : s->beta_y, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  TSDR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { int _w = tsdr::wait_stream(ctx, ctx->stream, __func__); if (_w) return _w; }
   return TSDR_OK;
 }
 

@@ -20,7 +20,7 @@ export calculate_autocorrelation, zoom_autocorr
 export getSpectrum, getWelch, getWaterfall
 export SyncXY, vsync
 export hip_frames!, hip_frames_submit!, hip_frames_submit_sc16!, hip_frames_flush, hip_synchronize   # fused GUI.jl:163-178 loop body (optional fast path; pipelined form)
-export hip_extract_configuration, sync_guard_stats, sync_guard_auto   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
+export hip_extract_configuration, sync_guard_stats, sync_guard_auto, wait_stats   # fused GUI.jl:67-81 search; counters of the FAST loop's sync guard
 export hip_set_precision, hip_set_option                              # TSDR_EXACT / TSDR_FAST and the library's options, per task context
 export HipGroup, hip_group                                            # one process, several GPUs (RCCL inside the library): `devices = ...`
 
@@ -316,6 +316,13 @@ function sync_guard_auto()
     return (e[] != 0, Int(a[]), Int(b[]))
 end
 
+"(stream waits given up after \"wait_ms\", guard ring entries that went uncounted): every host-side wait of the library is bounded"
+function wait_stats()
+    a = Ref{Culonglong}(0); b = Ref{Culonglong}(0); c = ctx()
+    check(c, ccall((:tsdr_wait_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Culonglong}, Ptr{Culonglong}), c.h, a, b), "wait_stats")
+    return (Int(a[]), Int(b[]))
+end
+
 # ---- one process, several GPUs (tsdr_group_*: one context + one RCCL communicator per device) ----------------------
 """
     HipGroup(devices = 0:0)
@@ -416,11 +423,11 @@ end
 
 "getWelch (GetSpectrum.jl:36-52) with the segments sharded over the group: one all-reduce of `sizeFFT` Float32"
 function getWelch(fe, sig, g::HipGroup; sizeFFT = 1024)
-    a = _dense(sig); cplx = eltype(a) <: Complex ? 1 : 0
+    a, cplx = _raw(sig)          # (Float32 / ComplexF32 only, like the single-context method: MethodError otherwise)
     y = Vector{Float32}(undef, sizeFFT)
     check(g, ccall((:tsdr_group_welch, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Csize_t, Csize_t, Cint, Ptr{Float32}),
                    g.h, a, cplx, length(a), sizeFFT, 0, y), "getWelch")
-    return ((0:sizeFFT-1) ./ sizeFFT .- 0.5) .* fe, y
+    return (collect(((0:sizeFFT-1) ./ sizeFFT .- 0.5) * fe), y)
 end
 
 # ---- streaming ingest: the staging ring (AtomicAbstractSDRs.jl:64-190 on pinned memory) ----------

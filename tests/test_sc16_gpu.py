@@ -90,6 +90,28 @@ def test_sc16_through_the_sync_guard_and_the_pipeline(ctx, tsdr, synth):
             ctx.set_option("sync_guard_auto", 1)
 
 
+def test_sc16_guard_beyond_one_guard_launch(ctx, tsdr, synth):
+    """More than kGuardChunk = 256 frames in one call: the guard runs as several launches, and the later ones must find their
+    frames' int16 samples at f0 * S * 4 bytes (they were offset as ComplexF32, i.e. read frame 2 * f0 and past the
+    buffer).  The plateau leak flags frames in every chunk; one-by-one re-evaluation ("sync_guard_auto" 0).  The call's guard
+    ring entry carries the CALL's totals (one entry per call, written by its last launch)."""
+    Fs, x_t, y_t, nfr = 2.0e6, 1056, 628, 300
+    S = synth.samples_per_frame(Fs, 60.0)
+    q, scale, cf = _capture(synth, Fs, x_t, y_t, 60.0, S * nfr, card="plateau")
+    for auto in (0, 1):
+        ctx.set_option("sync_guard_auto", auto)
+        ctx.sync_guard_stats(reset=True)
+        try:
+            _, ix, _, _ = _run(ctx, tsdr, cf, q, scale, S, y_t, x_t, False)
+            checked, flagged = ctx.sync_guard_stats()
+            assert checked == 2 * nfr and flagged > 0      # (two runs: cf32 and sc16)
+            if auto == 0:
+                flags_late = flagged
+        finally:
+            ctx.set_option("sync_guard_auto", 1)
+    assert flags_late > 2, "the plateau leak should flag frames beyond the first guard launch"
+
+
 def test_ring_sc16raw_hands_out_the_int16_pairs(ctx, tsdr, synth):
     """ring fmt "sc16raw": the H2D DMA moves 4 bytes per sample and nothing expands them; frames_sc16_d on the buffer the
     ring hands out equals frames_d on the expanded ring's."""
