@@ -49,18 +49,27 @@ NPX = 600 * 800
 
 
 def run_group_child(devs, workload, timeout=150):
-    """tools/group_devices.py on the given devices in a child process; its JSON line, or what went wrong"""
+    """tools/group_devices.py on the given devices in a child process; its JSON line, or what went wrong.  A child that does not
+    end when killed (a process waiting on a wedged GPU) is left behind, not waited for."""
     import subprocess
     cmd = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "group_devices.py"), devs, workload]
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
-    except subprocess.TimeoutExpired as e:
-        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
-        stage = [l for l in err.splitlines() if l.startswith("[group_devices]")]
-        return {"devices": devs, "error": f"no result within {timeout} s (child process ended); last stage reached: " + (stage[-1] if stage else "none")}
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if r.returncode != 0 or not lines:
-        return {"devices": devs, "error": f"exit code {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        return {"devices": devs, "error": f"could not start: {e}"}
+    try:
+        so, se = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()   # (this exact process)
+        try:
+            so, se = proc.communicate(timeout=10)
+        except subprocess.TimeoutExpired:
+            so, se = "", ""
+        stage_lines = [l for l in (se or "").splitlines() if l.startswith("[group_devices]")]
+        return {"devices": devs, "error": f"no result within {timeout} s (child process stopped); last stage reached: " + (stage_lines[-1] if stage_lines else "none")}
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        return {"devices": devs, "error": f"exit code {proc.returncode}: " + (se.strip().splitlines() or ["no output"])[-1][:300]}
     try:
         return json.loads(lines[-1])
     except ValueError as e:
@@ -683,17 +692,19 @@ def leg_other_workload(env, args, name):
 
 
 # name -> (function, time limit in seconds (about 4x what the leg takes on the pool's boxes), needs the parent's buffers)
+# (`group` last: on a box that shows several GPUs it starts the N > 1 RCCL split, which no box has run so far -- whatever it
+# does costs only itself)
 LEGS = {
     "fused": (leg_fused, 60, True),
     "pipeline": (leg_pipeline, 75, True),
     "two_streams": (leg_two_streams, 60, True),
     "search": (leg_search, 45, True),
-    "group": (leg_group, 90, True),
     "host_ingest": (leg_host_ingest, 60, True),
     "spectra": (leg_spectra, 60, True),
     "exact": (leg_exact, 60, True),
     "c5": (lambda env, args, bufs: leg_other_workload(env, args, "C5"), 90, False),
     "c3": (lambda env, args, bufs: leg_other_workload(env, args, "C3"), 120, False),
+    "group": (leg_group, 90, True),
 }
 LINE_KEY = {"fused": "fused", "pipeline": "pipeline", "two_streams": "two_streams", "search": "search", "group": "group",
             "host_ingest": "host_ingest", "spectra": "spectra", "exact": "exact", "c5": "c5", "c3": "c3"}
@@ -797,19 +808,24 @@ def make_env(args, rank, local_rank, world):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     ctx = tsdr.Context(local_rank)  # raises if the HIP library / device is missing: no fallback
+    # The weak-scaling headline has no data-path collective (each rank owns its capture buffers): its barriers and the
+    # max-over-ranks of its wall times are CONTROL traffic, and go over a gloo group -- host sockets -- so that the headline of an
+    # N > 1 line does not depend on the first RCCL collective this code has ever run on several devices.  RCCL carries the
+    # data-path collectives (`strong`, `search`: all-gather / all-reduce of device tensors on the default group).
+    ctl = dist.new_group(backend="gloo") if world > 1 and not share else None
 
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)
             torch.cuda.synchronize()
 
     def reduce_max(vals):
         if world == 1:
             return list(vals)
-        t = torch.tensor(list(vals), dtype=torch.float64, device="cpu" if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor(list(vals), dtype=torch.float64, device="cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=ctl)
         return [float(v) for v in t.tolist()]
 
     return dict(torch=torch, dist=dist, tsdr=tsdr, synth=synth, api=api, par=par, ctx=ctx, dev=dev, rank=rank, world=world,
@@ -892,7 +908,7 @@ def finish_line(line):
         if isinstance(x, dict):
             for k in list(x):
                 v = x[k]
-                if isinstance(v, str) and len(v) > 100 and k not in ("mode", "error") and path + [k] not in (["config", "workload"], ["cpu_baseline", "sample"]):
+                if isinstance(v, str) and len(v) > 100 and k not in ("mode", "error", "incomplete", "skipped") and path + [k] not in (["config", "workload"], ["cpu_baseline", "sample"]):
                     notes[".".join(path + [k])] = v
                     x[k] = "see notes"
                 else:

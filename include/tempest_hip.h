@@ -120,6 +120,15 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *                 only the shift + IIR launches chained; 2 = one internal stream (the sequential order).
  *                 "pipe_tune" 1 (default): with "pipe_mode" -1 the first submissions of a configuration time every candidate
  *                 arrangement (tsdr_frames_pipeline_info) and the rest use the fastest; 0: arrangement 0 with rasters, 1 without.
+ *                 The measurement is kept per configuration (frames per buffer, S, y_t, x_t, raster or not, precision, input
+ *                 format, SyncXY object) for the 8 most recently used ones; a configuration within 10 % of a measured one in S
+ *                 and raster size (GUI.jl:492-506: y_t / x_t corrections one line at a time) takes over its choice without
+ *                 trials; a configuration whose trials were cut into four times by other configurations keeps the sequential
+ *                 order.  DURING the trials (17 x 15 submissions) a submission at a trial boundary runs the lanes empty and waits
+ *                 for them on the host (bounded, "wait_ms"); latency-sensitive callers pin instead:
+ *   "pipe_pin"    k >= 0: arrangement k of the list tsdr_frames_pipeline_info reports, nothing is measured; -1 (default): the
+ *                 measured choice.  "pipe_measure" 1: forget what is known about the current configuration and measure it at
+ *                 the next submissions ("measure now").
  *   "wait_ms"     bound of every host-side wait for a stream, in milliseconds (default 30000; 0 = unbounded): tsdr_wait_stats.
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
  * TSDR_WAIT_MS / TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_TUNE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT

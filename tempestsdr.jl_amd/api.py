@@ -105,8 +105,11 @@ class Context:
         """what tsdr_frames_submit_d measured on this context: dict(trials_left, chosen, ms_per_buffer[8], text)"""
         left, chosen, ms, text = C.c_int(0), C.c_int(-1), (C.c_float * 8)(), C.create_string_buffer(1024)
         self.call("tsdr_frames_pipeline_info", C.byref(left), C.byref(chosen), ms, 8, text, 1024)
+        txt = text.value.decode()
+        import re
+        m = re.search(r"measurements started on this context: (\d+)", txt)
         return {"trials_left": left.value, "chosen": chosen.value, "ms_per_buffer": [round(float(v), 5) for v in ms],
-                "text": text.value.decode()}
+                "text": txt, "measurements_started": int(m.group(1)) if m else None}
 
     def sync_guard_margins(self, max_frames=1 << 16):
         """(frames, 2) relative top-2 margins (x, y) the guard saw in the last FAST frame-loop call"""

@@ -132,9 +132,17 @@ struct tsdr_ctx {
   // frames apart), the tile plan of (S, y_t, x_t, raster or not, precision) for the projection sums, the SyncXY object's block
   // counts for the guard records.  A change of any of them runs the pipeline empty first.
   struct PipeKey {
-    size_t nb = 0, S = 0; int y_t = 0, x_t = 0, raster = -1, prec = -1, align = -1; const void *sync = nullptr;
+    size_t nb = 0, S = 0; int y_t = 0, x_t = 0, raster = -1, prec = -1, align = -1, sc16 = 0; const void *sync = nullptr;
     bool operator==(const PipeKey &o) const {
-      return nb == o.nb && S == o.S && y_t == o.y_t && x_t == o.x_t && raster == o.raster && prec == o.prec && align == o.align && sync == o.sync;
+      return nb == o.nb && S == o.S && y_t == o.y_t && x_t == o.x_t && raster == o.raster && prec == o.prec && align == o.align && sc16 == o.sc16 && sync == o.sync;
+    }
+    // the same loop at a slightly different geometry (GUI.jl:492-506: the interactive y_t / x_t corrections move one line at a
+    // time): same frames per buffer, raster or not, precision, alignment, input format; S and the raster size within 10 %.
+    // What was measured for one holds for the other (the launches have the same shapes and durations within a few percent).
+    bool near(const PipeKey &o) const {
+      if (!(nb == o.nb && raster == o.raster && prec == o.prec && align == o.align && sc16 == o.sc16)) return false;
+      const double s = (double)S / (double)(o.S ? o.S : 1), p = ((double)y_t * x_t) / ((double)o.y_t * o.x_t > 0 ? (double)o.y_t * o.x_t : 1.0);
+      return s > 0.9 && s < 1.1 && p > 0.9 && p < 1.1;
     }
   } pipe_key;
   hipStream_t pool[kPoolN + kPoolH] = {};  // created at the first submission (frames.hip:pipe_init)
@@ -158,8 +166,12 @@ struct tsdr_ctx {
   struct PipeTune {                 // the measured choice for one PipeKey
     PipeKey key; int state = 0;     // 0: nothing measured; 1: trials running; 2: settled
     int cand = 0, pos = 0, chosen = -1, round = 0;   // round 0: warm-up trial of candidate 0; 1, 2: the two measured passes
+    int interrupts = 0;             // times another configuration cut into this one's trials (4: settle on the sequential order)
+    bool inherited = false;         // settled by taking over a neighbouring configuration's choice (PipeKey::near), not by trials
     float ms[kTuneCands] = {};      // mean interval between the tails of successive buffers, per arrangement
   } tune;
+  int opt_pipe_pin = -1;            // "pipe_pin" k >= 0: arrangement k of frames.hip:kCands, nothing measured; -1: not pinned
+  unsigned long long tune_runs = 0; // measurements (full sets of trials) started on this context so far
   std::vector<PipeTune> tune_done;  // settled measurements of earlier configurations (a caller that goes back to one -- GUI.jl's
                                     // y_t / x_t corrections, a raster asked for now and then -- does not measure it again); <= 16
   hipEvent_t tune_ev[kTrial] = {};

@@ -196,6 +196,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_GUARD_NOWAIT")) ctx->opt_guard_nowait = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_DEV_EVENTS")) ctx->opt_pipe_dev_events = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_TUNE")) ctx->opt_pipe_tune = atoi(e) != 0;
+  if (const char *e = getenv("TSDR_PIPE_PIN")) ctx->opt_pipe_pin = atoi(e) < 0 || atoi(e) >= tsdr_ctx::kTuneCands ? -1 : atoi(e);
   if (const char *e = getenv("TSDR_PIPE_EXT_EVENT")) ctx->opt_pipe_ext_event = atoi(e) != 0;
   if (const char *e = getenv("TSDR_PIPE_LANES")) ctx->opt_pipe_lanes = atoi(e) == 3 ? 3 : 2;
   if (const char *e = getenv("TSDR_WAIT_MS")) ctx->opt_wait_ms = atoi(e) < 0 ? 0 : atoi(e);
@@ -288,6 +289,16 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
     else if (name[5] == 'l') ctx->opt_pipe_lanes = value == 3 ? 3 : 2;
     else if (name[5] == 'p') ctx->opt_pipe_priority = value != 0;
     else { ctx->opt_pipe_tune = value != 0; ctx->tune = tsdr_ctx::PipeTune{}; ctx->tune_done.clear(); }   // (setting it also discards what was measured)
+  }
+  else if (!strcmp(name, "pipe_pin") || !strcmp(name, "pipe_measure")) {
+    int rc = tsdr::pipe_drain(ctx);
+    if (rc) return rc;
+    if (name[5] == 'p') {   // the arrangement (index into the candidates tsdr_frames_pipeline_info lists), nothing measured; -1: back to the measured choice
+      if (value >= tsdr_ctx::kTuneCands) return tsdr::set_err(ctx, TSDR_EINVAL, "pipe_pin must be -1 .. %d", tsdr_ctx::kTuneCands - 1);
+      ctx->opt_pipe_pin = value < 0 ? -1 : value;
+    } else if (value) {     // measure (again) at the next submission: what is known about the current configuration is dropped
+      ctx->tune = tsdr_ctx::PipeTune{};
+    }
   }
   else if (!strcmp(name, "pipe_ext_event")) ctx->opt_pipe_ext_event = value != 0;
   else if (!strcmp(name, "wait_ms")) ctx->opt_wait_ms = value < 0 ? 0 : value;

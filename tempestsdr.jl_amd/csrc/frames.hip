@@ -368,21 +368,33 @@ int pipe_sync_lanes(tsdr_ctx *ctx) {
 // the arrangement of this submission: forced ("pipe_mode" >= 0), the geometry rule of rounds 3-4 ("pipe_tune" = 0), or the
 // measured one.  May run the pipeline empty (a trial boundary).  Returns an index into kCands, or a negative status.
 static int pipe_pick(tsdr_ctx *ctx, const tsdr_ctx::PipeKey &key) {
+  if (ctx->opt_pipe_pin >= 0) return ctx->opt_pipe_pin;
   if (ctx->opt_pipe_mode == 0) return ctx->opt_pipe_priority ? 1 : 2;
   if (ctx->opt_pipe_mode == 1) return ctx->opt_pipe_lanes == 3 ? 7 : 4;
   if (ctx->opt_pipe_mode == 2) return 0;
   if (!ctx->opt_pipe_tune) return key.raster ? 1 : 4;
   tsdr_ctx::PipeTune &t = ctx->tune;
-  if (t.state == 0 || !(t.key == key)) {   // another configuration: one measured before, or measure now
-    if (t.state == 2) {                      // (what was settled for the previous one is kept)
-      if (ctx->tune_done.size() >= 16) ctx->tune_done.erase(ctx->tune_done.begin());
+  if (t.state == 0 || !(t.key == key)) {   // another configuration: one measured before, a neighbour of one, or measure now
+    // what is known about the previous one is kept -- settled or half-way through its trials (a caller that alternates between
+    // two configurations resumes each one's trials where it left them instead of starting over on every change); the table
+    // holds the 8 most recently used configurations
+    if (t.state != 0) {
+      if (ctx->tune_done.size() >= 8) ctx->tune_done.erase(ctx->tune_done.begin());
+      if (t.state == 1) {                    // (the trial that was interrupted is run again from its first buffer)
+        t.pos = 0;
+        // a caller that keeps cutting in (two configurations in strict alternation) would never settle and would run the lanes
+        // empty at every change: after four interruptions the configuration keeps the sequential order
+        if (++t.interrupts >= 4) { t.state = 2; t.chosen = 0; }
+      }
       ctx->tune_done.push_back(t);
     }
     t = tsdr_ctx::PipeTune{};
-    t.key = key;
-    t.state = 1;
-    for (size_t i = 0; i < ctx->tune_done.size(); ++i)
-      if (ctx->tune_done[i].key == key) { t = ctx->tune_done[i]; ctx->tune_done.erase(ctx->tune_done.begin() + (long)i); break; }
+    bool found = false;
+    for (size_t i = 0; i < ctx->tune_done.size() && !found; ++i)
+      if (ctx->tune_done[i].key == key) { t = ctx->tune_done[i]; ctx->tune_done.erase(ctx->tune_done.begin() + (long)i); found = true; }
+    for (size_t i = ctx->tune_done.size(); i-- > 0 && !found;)   // (the most recent neighbour first)
+      if (ctx->tune_done[i].state == 2 && ctx->tune_done[i].key.near(key)) { t = ctx->tune_done[i]; t.key = key; t.inherited = true; found = true; }
+    if (!found) { t.key = key; t.state = 1; ++ctx->tune_runs; }
   }
   if (t.state == 1 && t.pos == tsdr_ctx::kTrial) {   // this arrangement's trial is complete
     int rc = pipe_drain(ctx);
@@ -451,7 +463,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
   if (rc) return rc;
   tsdr_ctx::PipeKey key;
   key.nb = nb; key.S = S; key.y_t = y_t; key.x_t = x_t; key.raster = raster_out ? 1 : 0; key.prec = ctx->precision;
-  key.align = do_align ? 1 : 0; key.sync = (const void *)sync;
+  key.align = do_align ? 1 : 0; key.sync = (const void *)sync; key.sc16 = ctx->iq_fmt.sc16;
   const int cand = pipe_pick(ctx, key);
   if (cand < 0) return cand;
   const PipeCand &pc = kCands[cand];
@@ -577,7 +589,7 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
       if (!ctx->opt_pipe_ext_event) TSDR_HIP(ctx, hipEventRecord(ctx->ev_tail[slot], ctx->lane[2]));
     }
   }
-  if (ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune && ctx->tune.state == 1 && ctx->tune.pos < tsdr_ctx::kTrial) {
+  if (ctx->opt_pipe_pin < 0 && ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune && ctx->tune.state == 1 && ctx->tune.pos < tsdr_ctx::kTrial) {
     // two timing events per trial (a timed event is a marker packet that holds up the launches behind it for a few
     // microseconds: one per buffer made the one-stream candidate look 10 % slower than it is)
     if (ctx->tune.pos == 2 || ctx->tune.pos == tsdr_ctx::kTrial - 1) TSDR_HIP(ctx, hipEventRecord(ctx->tune_ev[ctx->tune.pos], tail_stream));
@@ -594,20 +606,22 @@ int tsdr_frames_submit_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t
 int tsdr_frames_pipeline_info(tsdr_ctx *ctx, int *trials_left, int *chosen, float *ms_per_buffer, int cap, char *text, size_t text_cap) {
   if (!ctx || cap < 0 || (cap && !ms_per_buffer)) return TSDR_EINVAL;
   const tsdr_ctx::PipeTune &t = ctx->tune;
-  const bool measured = ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune;
+  const bool measured = ctx->opt_pipe_mode < 0 && ctx->opt_pipe_tune && ctx->opt_pipe_pin < 0;
   constexpr int kAll = 2 * tsdr_ctx::kTuneCands + 1;   // the warm-up trial + two passes
   if (trials_left) *trials_left = !measured ? 0 : t.state == 2 ? 0 : t.state == 1 ? kAll - (t.round == 0 ? 0 : 1 + (t.round - 1) * tsdr_ctx::kTuneCands + t.cand) : kAll;
   if (chosen) *chosen = measured ? (t.state == 2 ? t.chosen : -1) : ctx->pipe_cand_now;
   for (int c = 0; c < cap && c < tsdr_ctx::kTuneCands; ++c) ms_per_buffer[c] = measured && (t.state == 2 || t.round == 2 || (t.round == 1 && c < t.cand)) ? t.ms[c] : 0.f;
   if (text && text_cap) {
     std::string s;
-    if (!measured) s = std::string("forced: ") + (ctx->pipe_cand_now >= 0 ? kCands[ctx->pipe_cand_now].name : "nothing submitted yet");
+    if (ctx->opt_pipe_pin >= 0) s = std::string("pinned (\"pipe_pin\"): ") + kCands[ctx->opt_pipe_pin].name;
+    else if (!measured) s = std::string("forced: ") + (ctx->pipe_cand_now >= 0 ? kCands[ctx->pipe_cand_now].name : "nothing submitted yet");
     else if (t.state != 2) s = "measuring";
     else {
-      s = std::string("measured: ") + kCands[t.chosen].name + " |";
+      s = std::string(t.inherited ? "taken over from a neighbouring configuration's measurement: " : "measured: ") + kCands[t.chosen].name + " |";
       char b[96];
       for (int c = 0; c < tsdr_ctx::kTuneCands; ++c) { snprintf(b, sizeof b, " [%d] %s %.4f ms;", c, kCands[c].name, (double)t.ms[c]); s += b; }
     }
+    s += " (measurements started on this context: " + std::to_string(ctx->tune_runs) + ")";
     snprintf(text, text_cap, "%s", s.c_str());
   }
   return TSDR_OK;

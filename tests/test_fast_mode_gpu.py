@@ -254,6 +254,82 @@ def test_pipeline_measurement_is_kept_per_configuration(tsdr, synth):
         ctx.close()
 
 
+def test_pipeline_choice_is_taken_over_by_neighbouring_geometries_and_can_be_pinned(tsdr, synth):
+    """GUI.jl:492-506: the user corrects y_t one line at a time.  Each new y_t is a new configuration for the pipeline; it must
+    not pay 255 trial submissions again -- a configuration within 10 % of a measured one takes over its choice.  50 values of
+    y_t: ONE measurement.  Two configurations in strict alternation from the start settle (on the sequential order) instead of
+    cutting into each other's trials for ever.  "pipe_pin" k runs arrangement k with nothing measured; "pipe_measure" 1
+    measures the current configuration again.  Results equal one tsdr_frames_d per buffer throughout."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y0, fv = 2.0e6, 1056, 628, 60.0
+    S = synth.samples_per_frame(Fs, fv)
+    npx = 600 * 800
+    buf = synth.synth_leak(Fs, x_t, y0, fv, S)
+
+    def session():
+        c = tsdr.Context(0)
+        c.set_option("pipe_mode", -1)
+        c.set_option("pipe_tune", 1)
+        return c, tsdr.SyncXY(c, 600, 800), c.upload(np.zeros(npx, np.float32)), c.upload(buf.view(np.float32)), c.dev_alloc(npx * 4), c.dev_alloc(8)
+
+    def close(c, sync, *ptrs):
+        sync.close()
+        for p in ptrs:
+            c.dev_free(p)
+        c.close()
+
+    ctx, sync, d_state, d_iq, d_fr, d_ix = session()
+    ref, rsync, r_state, r_iq, r_fr, r_ix = session()
+    try:
+        def submit(n, y_t, check=False):
+            for _ in range(n):
+                assert api.frames_submit_d(ctx, sync, d_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, None, d_ix) == 1
+                if check:
+                    assert api.frames_d(ref, rsync, r_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, r_state, r_fr, None, r_ix) == 1
+            if check:
+                ctx.synchronize()
+                ref.synchronize()
+                assert np.array_equal(ctx.download(d_fr, (npx,), np.uint32), ref.download(r_fr, (npx,), np.uint32))
+                assert np.array_equal(ctx.download(d_ix, (2,), np.int32), ref.download(r_ix, (2,), np.int32))
+        submit(256, y0, check=True)
+        first = ctx.pipeline_info()
+        assert first["trials_left"] == 0 and first["measurements_started"] == 1
+        for k in range(1, 51):                 # y_t walks 50 lines down and up again
+            y_t = y0 + (k if k <= 25 else 50 - k)
+            submit(2, y_t, check=True)
+            info = ctx.pipeline_info()
+            assert info["trials_left"] == 0 and info["chosen"] == first["chosen"], (y_t, info)
+            assert y_t == y0 or "taken over" in info["text"], info["text"]
+        assert ctx.pipeline_info()["measurements_started"] == 1
+        # pinned: arrangement k, no trials even for a configuration far from everything measured
+        ctx.set_option("pipe_pin", 4)
+        submit(3, y0 // 2, check=True)
+        info = ctx.pipeline_info()
+        assert info["chosen"] == 4 and info["trials_left"] == 0 and info["measurements_started"] == 1 and "pinned" in info["text"]
+        ctx.set_option("pipe_pin", -1)
+        # measure now: the current configuration is measured again
+        submit(1, y0)
+        ctx.set_option("pipe_measure", 1)
+        submit(1, y0)
+        assert ctx.pipeline_info()["trials_left"] > 0 and ctx.pipeline_info()["measurements_started"] == 2
+        with pytest.raises(tsdr.TempestHIPError):
+            ctx.set_option("pipe_pin", 8)
+    finally:
+        close(ctx, sync, d_state, d_iq, d_fr, d_ix)
+        close(ref, rsync, r_state, r_iq, r_fr, r_ix)
+    # two configurations in strict alternation from the first submission on
+    ctx, sync, d_state, d_iq, d_fr, d_ix = session()
+    try:
+        for i in range(40):
+            for y_t in (y0, y0 // 2):
+                assert api.frames_submit_d(ctx, sync, d_iq, buf.size, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, None, d_ix) == 1
+        info = ctx.pipeline_info()
+        assert info["trials_left"] == 0 and info["chosen"] == 0, info     # settled: the sequential order
+        ctx.synchronize()
+    finally:
+        close(ctx, sync, d_state, d_iq, d_fr, d_ix)
+
+
 def test_pipeline_pending_stage_is_drained_by_other_entry_points(ctx, tsdr, synth):
     """Submitted buffers run on the pipeline's internal streams.  Entry points that use the same SyncXY / IIR state
     outside the pipeline (tsdr_vsync_d here, tsdr_frames_d) and tsdr_sync_free must order themselves behind them first: the
