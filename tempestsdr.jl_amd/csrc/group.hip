@@ -26,8 +26,13 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -38,8 +43,31 @@ namespace tsdr {
 int autocorr_args(tsdr_ctx *ctx, size_t len, double Fs, double minDelay, double maxDelay, size_t *n, size_t *k0, size_t *cnt);
 }
 
+// One host thread per member (round 6).  Every per-device stage "only enqueues" -- but an H2D copy from the caller's PAGEABLE
+// array (a Julia Array) is staged through the runtime's bounce buffers by the calling thread and returns when the data has
+// left the host array, and a D2H copy into one returns when it has arrived: issued by ONE thread, member i + 1's upload
+// started after member i's had finished, and 8 PCIe links carried one link's rate.  Each member's stage now runs on that
+// member's own thread (its device current there for good); the caller's thread runs member 0 and waits for the others.
+struct GroupMember {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has = false, quit = false;
+  int rc = 0;
+};
+
 struct tsdr_group {
   int n = 0;
+  std::vector<std::unique_ptr<GroupMember>> mem;   // [1 .. n): started at the first call that has work for them
+  int opt_threads = 1;             // "member_threads" 0: every stage from the caller's thread (rounds 1-5; the A/B)
+  // "pin_host" 1: the caller's arrays are page-locked (hipHostRegister, portable) at first use and STAY registered until the
+  // group is destroyed or another array overlaps them -- DMA straight from the array at the link's rate instead of through
+  // bounce buffers.  For callers that reuse their buffers (recv!(buffer, csdr) into the same Array, GUI.jl:150-166) and keep
+  // them alive as long as the group; off by default (registering 80 MB costs more than one call saves).
+  int opt_pin_host = 0;
+  struct Pin { const char *p; size_t bytes; };
+  std::vector<Pin> pins;
   std::vector<int> dev;
   std::vector<tsdr_ctx *> ctx;
   std::vector<ncclComm_t> comm;
@@ -147,6 +175,84 @@ __global__ __launch_bounds__(256) void k_acc(float *__restrict__ acc, const floa
 __global__ __launch_bounds__(256) void k_db(float *__restrict__ y, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = 10.0f * log10f(y[i]);
 }
+
+void member_loop(tsdr_group *g, int i) {
+  GroupMember &w = *g->mem[i];
+  (void)hipSetDevice(g->dev[i]);
+  std::unique_lock<std::mutex> lk(w.m);
+  for (;;) {
+    w.cv.wait(lk, [&] { return w.has || w.quit; });
+    if (w.quit) return;
+    std::function<int()> job = std::move(w.job);
+    lk.unlock();
+    const int rc = job();
+    lk.lock();
+    w.rc = rc;
+    w.has = false;
+    w.cv.notify_all();
+  }
+}
+
+// fn(i) for every member i < world: member 0 on the calling thread, the others on their own threads, side by side; returns
+// when all have returned.  fn touches only member i's context (and reads the call's arguments); errors are reported from
+// the calling thread afterwards.
+template <class F>
+int run_members(tsdr_group *g, int world, const char *what, F fn) {
+  std::vector<int> rcs((size_t)world, TSDR_OK);
+  const bool threads = g->opt_threads && world > 1;
+  if (threads) {
+    if (g->mem.empty()) g->mem.resize((size_t)g->n);
+    for (int i = 1; i < world; ++i) {
+      if (!g->mem[i]) { g->mem[i] = std::make_unique<GroupMember>(); g->mem[i]->th = std::thread(member_loop, g, i); }
+      GroupMember &w = *g->mem[i];
+      { std::lock_guard<std::mutex> lk(w.m); w.job = [&fn, i] { return fn(i); }; w.has = true; }
+      w.cv.notify_all();
+    }
+  }
+  for (int i = 0; i < (threads ? 1 : world); ++i) {
+    if (hipSetDevice(g->dev[i]) != hipSuccess) { rcs[i] = hip_fail(g->ctx[i], hipGetLastError(), "hipSetDevice"); continue; }
+    rcs[i] = fn(i);
+    if (rcs[i] && !threads) break;
+  }
+  if (threads)
+    for (int i = 1; i < world; ++i) {
+      GroupMember &w = *g->mem[i];
+      std::unique_lock<std::mutex> lk(w.m);
+      w.cv.wait(lk, [&] { return !w.has; });
+      rcs[i] = w.rc;
+    }
+  for (int i = 0; i < world; ++i)
+    if (rcs[i]) return member_err(g, i, rcs[i], what);
+  return TSDR_OK;
+}
+
+void stop_members(tsdr_group *g) {
+  for (auto &w : g->mem) {
+    if (!w) continue;
+    { std::lock_guard<std::mutex> lk(w->m); w->quit = true; }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+  }
+  g->mem.clear();
+}
+
+// "pin_host": [p, p + bytes) page-locked for every device of the node, once (see tsdr_group::opt_pin_host)
+void pin_host(tsdr_group *g, const void *ptr, size_t bytes) {
+  if (!g->opt_pin_host || !ptr || bytes < (1u << 20)) return;
+  const char *p = (const char *)ptr;
+  for (const auto &e : g->pins) if (p >= e.p && p + bytes <= e.p + e.bytes) return;
+  for (size_t k = g->pins.size(); k-- > 0;)    // an array that overlaps an older registration replaces it
+    if (p < g->pins[k].p + g->pins[k].bytes && g->pins[k].p < p + bytes) { (void)hipHostUnregister((void *)g->pins[k].p); g->pins.erase(g->pins.begin() + (long)k); }
+  if (g->pins.size() >= 16) { (void)hipHostUnregister((void *)g->pins[0].p); g->pins.erase(g->pins.begin()); }
+  if (hipHostRegister((void *)p, bytes, hipHostRegisterPortable) == hipSuccess) g->pins.push_back({p, bytes});
+  (void)hipGetLastError();   // (an array that cannot be registered is copied through the bounce buffers as before)
+}
+
+#define M_HIP(c, call)                                               \
+  do {                                                               \
+    hipError_t _e = (call);                                          \
+    if (_e != hipSuccess) return hip_fail((c), _e, #call);           \
+  } while (0)
 
 int sync_all(tsdr_group *g) {
   for (int i = 0; i < g->n; ++i) {
@@ -287,6 +393,9 @@ void tsdr_group_destroy(tsdr_group *g) {
       return;
     }
   }
+  stop_members(g);
+  for (auto &e : g->pins) (void)hipHostUnregister((void *)e.p);
+  g->pins.clear();
   for (auto c : g->comm) if (c) (void)ncclCommDestroy(c);
   (void)hipSetDevice(g->dev[0]);
   for (auto e : g->t) if (e) (void)hipEventDestroy(e);
@@ -315,7 +424,16 @@ int tsdr_group_set_precision(tsdr_group *g, int mode) {
 }
 
 int tsdr_group_set_option(tsdr_group *g, const char *name, int value) {
-  if (!g) return TSDR_EINVAL;
+  if (!g || !name) return TSDR_EINVAL;
+  // the group's own switches: "member_threads" (1: one host thread per member drives its stage, default; 0: the caller's
+  // thread drives them all in turn) and "pin_host" (1: the caller's arrays are page-locked at first use and stay so until the
+  // group is destroyed; the caller keeps them alive that long)
+  if (!strcmp(name, "member_threads")) { g->opt_threads = value != 0; return TSDR_OK; }
+  if (!strcmp(name, "pin_host")) {
+    g->opt_pin_host = value != 0;
+    if (!value) { for (auto &e : g->pins) (void)hipHostUnregister((void *)e.p); g->pins.clear(); (void)hipGetLastError(); }
+    return TSDR_OK;
+  }
   CallScope scope(nullptr);
   for (int i = 0; i < g->n; ++i) {
     G_HIP(g, hipSetDevice(g->dev[i]));
@@ -384,29 +502,30 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
     stage_times(g);
     return scope.done();
   }
-  // stage 1, per member: H2D of its range of m plus the halo (wrapping at n), partial sums over that range
+  // stage 1, per member (each on its own host thread): H2D of its range of m plus the halo (wrapping at n), partial sums
+  // over that range
   const int world = sharded ? N : 1;
   std::vector<float *> part(world, nullptr);
-  for (int i = 0; i < world; ++i) {
+  pin_host(g, x, n * esz);
+  rc = run_members(g, world, "group_search", [&](int i) -> int {
     tsdr_ctx *c = g->ctx[i];
-    G_HIP(g, hipSetDevice(g->dev[i]));
     size_t m0, mc;
     shard_range(n, world, i, &m0, &mc);
     part[i] = (float *)c->scratch(WS_OUT, n_lags * 4);
-    if (!part[i]) return member_err(g, i, TSDR_ENOMEM, "group_search");
-    if (mc == 0) { G_HIP(g, hipMemsetAsync(part[i], 0, n_lags * 4, c->stream)); continue; }
+    if (!part[i]) return TSDR_ENOMEM;
+    if (mc == 0) { M_HIP(c, hipMemsetAsync(part[i], 0, n_lags * 4, c->stream)); return TSDR_OK; }
     const size_t vlen = mc + n_lags - 1;
     char *dx = (char *)c->scratch(WS_IN, vlen * esz);
-    if (!dx) return member_err(g, i, TSDR_ENOMEM, "group_search");
+    if (!dx) return TSDR_ENOMEM;
     for (size_t done = 0; done < vlen;) {   // x[(m0 + j) mod n], j < vlen: at most a few contiguous pieces
       const size_t src = (m0 + done) % n, run = std::min(vlen - done, n - src);
-      G_HIP(g, hipMemcpyAsync(dx + done * esz, (const char *)x + src * esz, run * esz, hipMemcpyHostToDevice, c->stream));
+      M_HIP(c, hipMemcpyAsync(dx + done * esz, (const char *)x + src * esz, run * esz, hipMemcpyHostToDevice, c->stream));
       done += run;
     }
     // the slice as a sequence of its own: sum_{m < mc} xs[m] xs[m + k], no wrap inside (m + k <= vlen - 1)
-    rc = tsdr_autocorr_partial_d(c, (const float *)dx, is_iq, vlen, 0, mc, n_lags, part[i]);
-    if (rc) return member_err(g, i, rc, "autocorr_partial");
-  }
+    return tsdr_autocorr_partial_d(c, (const float *)dx, is_iq, vlen, 0, mc, n_lags, part[i]);
+  });
+  if (rc) return rc;
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[1], c0->stream));
   // stage 2: ONE all-reduce of the accumulators (linear domain) over xGMI
@@ -447,28 +566,32 @@ int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int
   std::vector<size_t> f0(N), fc(N);
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[0], c0->stream));
-  // stage 1, per member: H2D of its frames' samples, IQ -> 600x800 image + two argmax keys per frame (+ raster -> host)
-  for (int i = 0; i < N; ++i) {
+  // stage 1, per member (each on its own host thread): H2D of its frames' samples, IQ -> 600x800 image + two argmax keys per
+  // frame (+ raster -> the caller's host array, from that member over its own link)
+  pin_host(g, iq, nb * S * 8);
+  if (raster_out) pin_host(g, raster_out, nb * P * 4);
+  rc = run_members(g, N, "group_frames", [&](int i) -> int {
     tsdr_ctx *c = g->ctx[i];
     shard_range(nb, N, i, &f0[i], &fc[i]);
-    G_HIP(g, hipSetDevice(g->dev[i]));
     // (the root's buffers hold every frame of the buffer: its own range lies where the gather puts the others')
     const size_t hold = i == 0 ? nb : fc[i];
     img[i] = (float *)c->scratch(WS_IMG, (hold ? hold : 1) * npx * 4);
     keys[i] = (unsigned long long *)c->scratch(WS_KEYS, (hold ? hold : 1) * 2 * 8);
-    if (!img[i] || !keys[i]) return member_err(g, i, TSDR_ENOMEM, "group_frames");
-    if (fc[i] == 0) continue;
+    if (!img[i] || !keys[i]) return TSDR_ENOMEM;
+    if (fc[i] == 0) return TSDR_OK;
     float *d_iq = (float *)c->scratch(WS_IN, fc[i] * S * 8);
     float *d_ra = raster_out ? (float *)c->scratch(WS_FFT_A, fc[i] * P * 4) : nullptr;
-    if (!d_iq || (raster_out && !d_ra)) return member_err(g, i, TSDR_ENOMEM, "group_frames");
-    G_HIP(g, hipMemcpyAsync(d_iq, iq + 2 * f0[i] * S, fc[i] * S * 8, hipMemcpyHostToDevice, c->stream));
+    if (!d_iq || (raster_out && !d_ra)) return TSDR_ENOMEM;
+    M_HIP(c, hipMemcpyAsync(d_iq, iq + 2 * f0[i] * S, fc[i] * S * 8, hipMemcpyHostToDevice, c->stream));
     int nf = 0;
     float *my_img = img[i] + (i == 0 ? f0[0] * npx : 0);
     unsigned long long *my_keys = keys[i] + (i == 0 ? f0[0] * 2 : 0);
-    rc = tsdr_frames_scan_d(c, g->sync[i], d_iq, fc[i] * S, S, y_t, x_t, do_align, my_img, d_ra, do_align ? my_keys : nullptr, &nf);
-    if (rc) return member_err(g, i, rc, "frames_scan");
-    if (d_ra) G_HIP(g, hipMemcpyAsync(raster_out + f0[i] * P, d_ra, fc[i] * P * 4, hipMemcpyDeviceToHost, c->stream));
-  }
+    int rcm = tsdr_frames_scan_d(c, g->sync[i], d_iq, fc[i] * S, S, y_t, x_t, do_align, my_img, d_ra, do_align ? my_keys : nullptr, &nf);
+    if (rcm) return rcm;
+    if (d_ra) M_HIP(c, hipMemcpyAsync(raster_out + f0[i] * P, d_ra, fc[i] * P * 4, hipMemcpyDeviceToHost, c->stream));
+    return TSDR_OK;
+  });
+  if (rc) return rc;
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[1], c0->stream));
   // stage 2: gather to the rendering device (GUI.jl:177 hands the frames to ONE renderer): every other member sends its
@@ -496,7 +619,12 @@ int tsdr_group_frames(tsdr_group *g, const float *iq, size_t nEch, size_t S, int
   }
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[2], c0->stream));
-  // stage 3, root: lagged s_y (FrameSynchronisation.jl:66) + circshift + IIR (GUI.jl:172,175) over all frames in order
+  // stage 3, root: lagged s_y (FrameSynchronisation.jl:66) + circshift + IIR (GUI.jl:172,175) over all frames in order.
+  // (frames_out leaves from the root: frame k of the output is alpha * frame k - 1 + (1 - alpha) * shifted image k, an f32
+  // recurrence whose rounding depends on the order -- a member could form its range's outputs only by a re-associated scan,
+  // and the group's results are the single-context ones bit for bit.  Rasters, which have no such coupling, do leave from
+  // each member over its own link, above.)
+  if (frames_out) pin_host(g, frames_out, nb * npx * 4);
   float *d_state = (float *)c0->scratch(WS_AUX, npx * 4);
   float *d_frames = frames_out ? (float *)c0->scratch(WS_OUT, nb * npx * 4) : nullptr;
   int *d_idx = (sync_idx && do_align) ? (int *)c0->scratch(WS_MISC, nb * 8 + 16) : nullptr;
@@ -529,19 +657,21 @@ int tsdr_group_welch(tsdr_group *g, const float *sig, int is_complex, size_t len
   std::vector<float *> part(N, nullptr);
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[0], c0->stream));
-  for (int i = 0; i < N; ++i) {
-    tsdr_ctx *c = g->ctx[i];
-    size_t s0, sc;
-    shard_range(nbSeg, N, i, &s0, &sc);
-    G_HIP(g, hipSetDevice(g->dev[i]));
-    part[i] = (float *)c->scratch(WS_OUT, sizeFFT * 4);
-    if (!part[i]) return member_err(g, i, TSDR_ENOMEM, "group_welch");
-    if (sc == 0) { G_HIP(g, hipMemsetAsync(part[i], 0, sizeFFT * 4, c->stream)); continue; }
-    char *dx = (char *)c->scratch(WS_IN, sc * sizeFFT * esz);
-    if (!dx) return member_err(g, i, TSDR_ENOMEM, "group_welch");
-    G_HIP(g, hipMemcpyAsync(dx, (const char *)sig + s0 * sizeFFT * esz, sc * sizeFFT * esz, hipMemcpyHostToDevice, c->stream));
-    int rc = tsdr_welch_d(c, (const float *)dx, is_complex, sc * sizeFFT, sizeFFT, /*lin=*/1, part[i]);   // fftshifted linear sums
-    if (rc) return member_err(g, i, rc, "welch");
+  pin_host(g, sig, nbSeg * sizeFFT * esz);
+  {
+    int rcs = run_members(g, N, "group_welch", [&](int i) -> int {
+      tsdr_ctx *c = g->ctx[i];
+      size_t s0, sc;
+      shard_range(nbSeg, N, i, &s0, &sc);
+      part[i] = (float *)c->scratch(WS_OUT, sizeFFT * 4);
+      if (!part[i]) return TSDR_ENOMEM;
+      if (sc == 0) { M_HIP(c, hipMemsetAsync(part[i], 0, sizeFFT * 4, c->stream)); return TSDR_OK; }
+      char *dx = (char *)c->scratch(WS_IN, sc * sizeFFT * esz);
+      if (!dx) return TSDR_ENOMEM;
+      M_HIP(c, hipMemcpyAsync(dx, (const char *)sig + s0 * sizeFFT * esz, sc * sizeFFT * esz, hipMemcpyHostToDevice, c->stream));
+      return tsdr_welch_d(c, (const float *)dx, is_complex, sc * sizeFFT, sizeFFT, /*lin=*/1, part[i]);   // fftshifted linear sums
+    });
+    if (rcs) return rcs;
   }
   G_HIP(g, hipSetDevice(g->dev[0]));
   G_HIP(g, hipEventRecord(g->t[1], c0->stream));

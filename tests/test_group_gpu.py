@@ -149,3 +149,39 @@ def test_members_sharing_one_device_run_the_split_logic(ctx, tsdr, capture, n):
     finally:
         ctx.set_precision("fast")
         g.close()
+
+
+@pytest.mark.parametrize("threads,pin", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_member_threads_and_pinned_arrays_change_nothing_but_the_transfers(ctx, tsdr, capture, threads, pin):
+    """Round 6: each member's stage (its H2D slice, its launches, its raster D2H) runs on that member's own host thread, so
+    that copies from / into the caller's pageable arrays overlap across members ("member_threads" 0: the caller's thread
+    drives them all in turn, rounds 1-5); "pin_host" 1 page-locks the caller's arrays at first use.  Four members on the one
+    device: results are the single-context ones bit for bit in every combination, call after call on the same arrays (the
+    registration is kept) and on other arrays (an overlapping one replaces it)."""
+    Fs, x_t, y_t, S, iq = capture
+    g = tsdr.Group([0] * 4)
+    try:
+        g.set_option("member_threads", threads)
+        g.set_option("pin_host", pin)
+        g.set_option("sync_guard_auto", 0)
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        s1 = np.zeros((600, 800), np.float32, order="F")
+        s2 = np.zeros((600, 800), np.float32, order="F")
+        big = np.concatenate([iq, iq, iq])         # > 1 MB per array: what "pin_host" registers
+        for part in (big[: 9 * S], big[: 9 * S], big[2 * S: 14 * S + 5], iq[: 3 * S]):
+            _frames_equal(ctx.frames(sync, part, S, y_t, x_t, np.float32(0.1), s1, want_raster=True),
+                          g.frames(part, S, y_t, x_t, np.float32(0.1), s2, want_raster=True))
+            assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32))
+        sync.close()
+        G1, p1, _ = ctx.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90)
+        for _ in range(2):
+            G2, p2, _ = g.autocorr_search(iq, Fs, 0.0, 0.04, 50, 90, route="sharded")
+            assert np.max(np.abs(G1 - G2)) < 2e-4 and p1 == p2
+        _, y1 = ctx.getWelch(Fs, big, sizeFFT=1024)
+        _, y2 = g.getWelch(Fs, big, sizeFFT=1024)
+        assert np.max(np.abs(y1 - y2)) < 2e-4
+        g.set_option("pin_host", 0)                # unregisters
+        _, y3 = g.getWelch(Fs, big, sizeFFT=1024)
+        assert np.array_equal(y2, y3)
+    finally:
+        g.close()

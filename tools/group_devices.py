@@ -1,7 +1,8 @@
 """One process, SEVERAL devices through tsdr_group_* (RCCL inside the library): results against the single-context ones and
 timings, as ONE JSON line.  bench.py runs this as a child process (own HIP / RCCL state, a timeout) when the box shows more
 than one GPU; by hand:   python tools/group_devices.py 0,1,2,3 [workload]
-A device listed more than once (0,0) exchanges by copies and adds instead of RCCL -- the split logic on a 1-GPU box."""
+A device listed more than once (0,0) exchanges by copies and adds instead of RCCL -- the split logic on a 1-GPU box.
+A third argument sets the group's own switches: threads=0|1,pin=0|1 (tsdr_group_set_option "member_threads" / "pin_host")."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,6 +27,12 @@ def stage(what):   # (bench.py reports the last one reached when it has to end t
 stage("creating the contexts and communicators")
 ctx = T.Context(devices[0])
 g = T.Group(devices)
+gopts = dict(kv.split("=") for kv in sys.argv[3].split(",")) if len(sys.argv) > 3 else {}
+if "threads" in gopts:
+    g.set_option("member_threads", int(gopts["threads"]))
+if "pin" in gopts:
+    g.set_option("pin_host", int(gopts["pin"]))
+out["member_threads"], out["pin_host"] = int(gopts.get("threads", 1)), int(gopts.get("pin", 0))
 try:
     stage("frames: parity")
     # ---- frames: bit for bit the single-context result, both precisions, two successive buffers (lagged s_y, IIR state)
