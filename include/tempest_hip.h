@@ -426,12 +426,11 @@ int tsdr_group_set_precision(tsdr_group *g, int mode);                  /* tsdr_
  *                    member's own host thread, member 0's by the caller's, side by side: copies from / into the caller's
  *                    PAGEABLE arrays (Julia Arrays) are staged by the issuing thread and return only when the data has left /
  *                    reached the array, so one thread driving all members serialises their transfers.  0: the caller's thread
- *                    drives every member in turn (rounds 1-5; the A/B).
- *   "pin_host"       1: the caller's arrays (>= 1 MiB) are page-locked for all devices (hipHostRegister, portable) at first
- *                    use and STAY registered until the group is destroyed, "pin_host" 0, or another array overlaps them --
- *                    DMA straight from / into the array at the link's rate.  For callers that reuse their buffers
- *                    (recv!(buffer, csdr) into the same Array, GUI.jl:150-166) and keep them alive as long as the group.
- *                    Default 0: registering a capture buffer costs more than one call saves. */
+ *                    drives every member in turn (rounds 1-5; the A/B).  With 1, members that SHARE a device (a device listed
+ *                    more than once) are driven by the caller's thread: they share one link.  2: member threads always.
+ *   "pin_host"       1: the caller's arrays (>= 1 MiB) are page-locked for all devices (hipHostRegister, portable) for the
+ *                    duration of the call -- DMA straight from / into the array instead of through bounce buffers.  Default 0:
+ *                    registering and releasing a capture buffer costs more than the staged copy it replaces. */
 int tsdr_group_set_option(tsdr_group *g, const char *name, int value);
 /* extract_configuration's inner step, GUI.jl:73-81 -- arguments as tsdr_autocorr_search_d, x and out on the HOST (out may be
  * NULL).  The circular autocorrelation (Autocorrelations.jl:27-29) is a sum over m: member g receives its range of m plus a

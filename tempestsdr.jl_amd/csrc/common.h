@@ -171,6 +171,7 @@ struct tsdr_ctx {
     float ms[kTuneCands] = {};      // mean interval between the tails of successive buffers, per arrangement
   } tune;
   int opt_pipe_pin = -1;            // "pipe_pin" k >= 0: arrangement k of frames.hip:kCands, nothing measured; -1: not pinned
+  bool tune_force = false;          // "pipe_measure" 1: the next configuration is measured whatever is known about it or its neighbours
   unsigned long long tune_runs = 0; // measurements (full sets of trials) started on this context so far
   std::vector<PipeTune> tune_done;  // settled measurements of earlier configurations (a caller that goes back to one -- GUI.jl's
                                     // y_t / x_t corrections, a raster asked for now and then -- does not measure it again); <= 16

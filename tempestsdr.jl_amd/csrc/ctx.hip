@@ -298,6 +298,7 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
       ctx->opt_pipe_pin = value < 0 ? -1 : value;
     } else if (value) {     // measure (again) at the next submission: what is known about the current configuration is dropped
       ctx->tune = tsdr_ctx::PipeTune{};
+      ctx->tune_force = true;
     }
   }
   else if (!strcmp(name, "pipe_ext_event")) ctx->opt_pipe_ext_event = value != 0;

@@ -390,6 +390,12 @@ static int pipe_pick(tsdr_ctx *ctx, const tsdr_ctx::PipeKey &key) {
     }
     t = tsdr_ctx::PipeTune{};
     bool found = false;
+    if (ctx->tune_force) {   // "measure now": what the table holds for this configuration goes, neighbours are not consulted
+      for (size_t i = ctx->tune_done.size(); i-- > 0;) if (ctx->tune_done[i].key == key) ctx->tune_done.erase(ctx->tune_done.begin() + (long)i);
+      ctx->tune_force = false;
+      t.key = key; t.state = 1; ++ctx->tune_runs;
+      found = true;
+    }
     for (size_t i = 0; i < ctx->tune_done.size() && !found; ++i)
       if (ctx->tune_done[i].key == key) { t = ctx->tune_done[i]; ctx->tune_done.erase(ctx->tune_done.begin() + (long)i); found = true; }
     for (size_t i = ctx->tune_done.size(); i-- > 0 && !found;)   // (the most recent neighbour first)

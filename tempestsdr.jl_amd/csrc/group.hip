@@ -60,11 +60,14 @@ struct GroupMember {
 struct tsdr_group {
   int n = 0;
   std::vector<std::unique_ptr<GroupMember>> mem;   // [1 .. n): started at the first call that has work for them
-  int opt_threads = 1;             // "member_threads" 0: every stage from the caller's thread (rounds 1-5; the A/B)
-  // "pin_host" 1: the caller's arrays are page-locked (hipHostRegister, portable) at first use and STAY registered until the
-  // group is destroyed or another array overlaps them -- DMA straight from the array at the link's rate instead of through
-  // bounce buffers.  For callers that reuse their buffers (recv!(buffer, csdr) into the same Array, GUI.jl:150-166) and keep
-  // them alive as long as the group; off by default (registering 80 MB costs more than one call saves).
+  int opt_threads = 1;             // "member_threads" 1: member threads when the members sit on distinct devices (members sharing a
+                                   // device share its link: their staged copies only contend -- sharded search 4.1 against 2.3 ms
+                                   // with four members on one device); 2: always (tests); 0: never (rounds 1-5; the A/B)
+  // "pin_host" 1: the caller's arrays are page-locked (hipHostRegister, portable) for the duration of the call -- DMA straight
+  // from / into the array at the link's rate instead of through bounce buffers.  Off by default: registering and releasing
+  // 80 MB costs more than the staged copy it replaces (measured, NOTEBOOK round 6).  (Registrations that OUTLIVE the call were
+  // built and withdrawn: a later copy -- the caller's own, or the single-context entry points' -- whose range only partly
+  // overlaps a registered one fails with hipErrorInvalidValue.)
   int opt_pin_host = 0;
   struct Pin { const char *p; size_t bytes; };
   std::vector<Pin> pins;
@@ -199,7 +202,7 @@ void member_loop(tsdr_group *g, int i) {
 template <class F>
 int run_members(tsdr_group *g, int world, const char *what, F fn) {
   std::vector<int> rcs((size_t)world, TSDR_OK);
-  const bool threads = g->opt_threads && world > 1;
+  const bool threads = world > 1 && (g->opt_threads == 2 || (g->opt_threads == 1 && !g->virt));
   if (threads) {
     if (g->mem.empty()) g->mem.resize((size_t)g->n);
     for (int i = 1; i < world; ++i) {
@@ -236,16 +239,16 @@ void stop_members(tsdr_group *g) {
   g->mem.clear();
 }
 
-// "pin_host": [p, p + bytes) page-locked for every device of the node, once (see tsdr_group::opt_pin_host)
+// "pin_host": [p, p + bytes) page-locked for every device of the node until the call returns (CallScope)
 void pin_host(tsdr_group *g, const void *ptr, size_t bytes) {
   if (!g->opt_pin_host || !ptr || bytes < (1u << 20)) return;
-  const char *p = (const char *)ptr;
-  for (const auto &e : g->pins) if (p >= e.p && p + bytes <= e.p + e.bytes) return;
-  for (size_t k = g->pins.size(); k-- > 0;)    // an array that overlaps an older registration replaces it
-    if (p < g->pins[k].p + g->pins[k].bytes && g->pins[k].p < p + bytes) { (void)hipHostUnregister((void *)g->pins[k].p); g->pins.erase(g->pins.begin() + (long)k); }
-  if (g->pins.size() >= 16) { (void)hipHostUnregister((void *)g->pins[0].p); g->pins.erase(g->pins.begin()); }
-  if (hipHostRegister((void *)p, bytes, hipHostRegisterPortable) == hipSuccess) g->pins.push_back({p, bytes});
+  if (hipHostRegister((void *)ptr, bytes, hipHostRegisterPortable) == hipSuccess) g->pins.push_back({(const char *)ptr, bytes});
   (void)hipGetLastError();   // (an array that cannot be registered is copied through the bounce buffers as before)
+}
+void unpin_all(tsdr_group *g) {
+  for (auto &e : g->pins) (void)hipHostUnregister((void *)e.p);
+  g->pins.clear();
+  (void)hipGetLastError();
 }
 
 #define M_HIP(c, call)                                               \
@@ -313,6 +316,7 @@ struct CallScope {
     if (!ok && g)
       for (int i = 0; i < g->n; ++i)
         if (g->ctx[i] && hipSetDevice(g->dev[i]) == hipSuccess) (void)tsdr::wait_stream(g->ctx[i], g->ctx[i]->stream, "group: failed call");
+    if (g) unpin_all(g);   // (every copy of the call is complete here: sync_all on success, the waits above otherwise)
     if (prev >= 0) (void)hipSetDevice(prev);
     (void)hipGetLastError();
   }
@@ -394,8 +398,6 @@ void tsdr_group_destroy(tsdr_group *g) {
     }
   }
   stop_members(g);
-  for (auto &e : g->pins) (void)hipHostUnregister((void *)e.p);
-  g->pins.clear();
   for (auto c : g->comm) if (c) (void)ncclCommDestroy(c);
   (void)hipSetDevice(g->dev[0]);
   for (auto e : g->t) if (e) (void)hipEventDestroy(e);
@@ -428,10 +430,9 @@ int tsdr_group_set_option(tsdr_group *g, const char *name, int value) {
   // the group's own switches: "member_threads" (1: one host thread per member drives its stage, default; 0: the caller's
   // thread drives them all in turn) and "pin_host" (1: the caller's arrays are page-locked at first use and stay so until the
   // group is destroyed; the caller keeps them alive that long)
-  if (!strcmp(name, "member_threads")) { g->opt_threads = value != 0; return TSDR_OK; }
+  if (!strcmp(name, "member_threads")) { g->opt_threads = value < 0 ? 0 : value > 2 ? 2 : value; return TSDR_OK; }
   if (!strcmp(name, "pin_host")) {
     g->opt_pin_host = value != 0;
-    if (!value) { for (auto &e : g->pins) (void)hipHostUnregister((void *)e.p); g->pins.clear(); (void)hipGetLastError(); }
     return TSDR_OK;
   }
   CallScope scope(nullptr);
@@ -491,6 +492,7 @@ int tsdr_group_search(tsdr_group *g, const float *x, int is_iq, size_t len, doub
     float *dx = (float *)c0->scratch(WS_IN, n * esz);
     float *dout = (float *)c0->scratch(WS_OUT, cnt * 4);
     if (!dx || !dout) return member_err(g, 0, TSDR_ENOMEM, "group_search");
+    pin_host(g, x, n * esz);
     G_HIP(g, hipMemcpyAsync(dx, x, n * esz, hipMemcpyHostToDevice, c0->stream));
     G_HIP(g, hipEventRecord(g->t[1], c0->stream));
     G_HIP(g, hipEventRecord(g->t[2], c0->stream));

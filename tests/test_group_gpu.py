@@ -151,13 +151,14 @@ def test_members_sharing_one_device_run_the_split_logic(ctx, tsdr, capture, n):
         g.close()
 
 
-@pytest.mark.parametrize("threads,pin", [(0, 0), (1, 0), (1, 1), (0, 1)])
+@pytest.mark.parametrize("threads,pin", [(0, 0), (2, 0), (2, 1), (0, 1)])
 def test_member_threads_and_pinned_arrays_change_nothing_but_the_transfers(ctx, tsdr, capture, threads, pin):
     """Round 6: each member's stage (its H2D slice, its launches, its raster D2H) runs on that member's own host thread, so
     that copies from / into the caller's pageable arrays overlap across members ("member_threads" 0: the caller's thread
-    drives them all in turn, rounds 1-5); "pin_host" 1 page-locks the caller's arrays at first use.  Four members on the one
-    device: results are the single-context ones bit for bit in every combination, call after call on the same arrays (the
-    registration is kept) and on other arrays (an overlapping one replaces it)."""
+    drives them all in turn, rounds 1-5; 2: threads even for members sharing a device, as here); "pin_host" 1 page-locks the caller's arrays for the duration of each call.  Four members on
+    the one device: results are the single-context ones bit for bit in every combination, call after call on the same arrays
+    and on overlapping ones (nothing stays registered between calls: the single-context copies in between would fail on a
+    range that only partly overlaps a registered one)."""
     Fs, x_t, y_t, S, iq = capture
     g = tsdr.Group([0] * 4)
     try:
@@ -180,7 +181,7 @@ def test_member_threads_and_pinned_arrays_change_nothing_but_the_transfers(ctx, 
         _, y1 = ctx.getWelch(Fs, big, sizeFFT=1024)
         _, y2 = g.getWelch(Fs, big, sizeFFT=1024)
         assert np.max(np.abs(y1 - y2)) < 2e-4
-        g.set_option("pin_host", 0)                # unregisters
+        g.set_option("pin_host", 0)
         _, y3 = g.getWelch(Fs, big, sizeFFT=1024)
         assert np.array_equal(y2, y3)
     finally:

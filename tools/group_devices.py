@@ -2,7 +2,7 @@
 timings, as ONE JSON line.  bench.py runs this as a child process (own HIP / RCCL state, a timeout) when the box shows more
 than one GPU; by hand:   python tools/group_devices.py 0,1,2,3 [workload]
 A device listed more than once (0,0) exchanges by copies and adds instead of RCCL -- the split logic on a 1-GPU box.
-A third argument sets the group's own switches: threads=0|1,pin=0|1 (tsdr_group_set_option "member_threads" / "pin_host")."""
+A third argument sets the group's own switches: threads=0|1|2,pin=0|1 (tsdr_group_set_option "member_threads" / "pin_host")."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
