@@ -98,7 +98,104 @@ static void run(const char *name, int y_t) {
   hipFree(out);
 }
 
+// ---- round 6: the raster launch's WHOLE traffic pattern with free arithmetic ("skeleton") -----------------------------------
+// k_raster_fast (resample.hip) at C2, stripped of everything but its memory operations and a VALU filler:
+//   tile = 127 lines x 127 pixel columns, 512 threads = 2 (vertical) x 4 (horizontal) wavefronts, lanes = lines, a wavefront
+//   walks 32 pixel columns: one 256-byte column segment per pixel at (p * y_t + line) * 4 -- arbitrary 4-byte alignment;
+//   staging: per line the 17 IQ samples (8 bytes each) the tile's pixels lie between, read at (line * x_t + p0) * S / P,
+//   |IQ| to LDS, one barrier; per pixel one LDS read;
+//   image: every column that is the left tap of an output column (31 %) stores ~34 floats (the wave's output rows) into the
+//   column-major 600 x 800 image -- a 136-byte run at arbitrary alignment;
+//   W fma per pixel of filler (the real walk: 9 + ~5 amortised event / staging instructions).
+// Same grid order as the kernel (8 XCD slots x line tiles x units).  IMG / IQR switch the image stores and the IQ reads.
+template <int W, bool IMG, bool IQR>
+__global__ __launch_bounds__(512, 8) void k_skeleton(const float2 *__restrict__ iq, float *__restrict__ out, float *__restrict__ img, int y_t,
+                                                    int x_t, int S, int tiles_l, int tiles_p, int frames, float seed) {
+  __shared__ float smp[127 * 19];
+  const unsigned xcd = blockIdx.x, ul = blockIdx.z;
+  const int tl = (int)blockIdx.y;
+  const unsigned U = (unsigned)(frames * tiles_p);
+  const unsigned u = ((((ul >> 1) << 3) + xcd) << 1) + (ul & 1u);
+  if (u >= U) return;
+  const int f = (int)(u / (unsigned)tiles_p), tp = (int)(u % (unsigned)tiles_p);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = wave >> 2, wh = wave & 3;
+  const int l0 = tl * 126, p0 = tp * 127;
+  const double sf = (double)S / ((double)y_t * x_t);
+  float acc = seed + lane;
+  if (IQR) {
+    // 4 lanes per line, up to 5 samples each
+    for (int r = threadIdx.x >> 2; r < 127; r += 128) {
+      const int l = min(l0 + r, y_t - 1);
+      const unsigned k0 = (unsigned)(((double)l * x_t + p0) * sf);
+      for (int t = 0; t < 5; ++t) {
+        const int j = (threadIdx.x & 3) * 5 + t;
+        if (j < 19) {
+          const float2 z = iq[(size_t)f * S + min(k0 + (unsigned)j, (unsigned)S - 1u)];
+          smp[r * 19 + j] = __fsqrt_rn(z.x * z.x + z.y * z.y);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int line = wv * 63 + lane;
+  const int l = min(l0 + line, y_t - 1);
+  float *base = out + (size_t)f * y_t * x_t;
+  float *ib = img + (size_t)f * 480000;
+  const int rrow = (int)((l + 0.5) * (600.0 / y_t));          // this lane's output row
+  const bool own = (int)((l - 0.5) * (600.0 / y_t)) != rrow && rrow < 600;   // ~ every 1.875th line owns one
+  float pos = (float)lane * 0.37f;
+  for (int i = 0; i < 32; ++i) {
+    const int p = p0 + wh * 32 + i;
+    if (p >= x_t) break;
+    if (IQR) { pos += 0.115f; acc += smp[line * 19 + min((int)pos & 15, 17)]; }
+#pragma unroll
+    for (int w = 0; w < W; ++w) acc = __fmaf_rn(acc, 1.0001f, 0.5f);
+    float *dst = base + (size_t)p * y_t + l;
+    asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(acc) : "memory");
+    if (IMG) {
+      const int c = (int)((p + 0.5) * (800.0 / x_t));
+      if ((int)((p - 0.5) * (800.0 / x_t)) != c && own && c < 800) {     // (wave-uniform column test, per-lane row ownership)
+        float *d2 = ib + (size_t)c * 600 + rrow;
+        asm volatile("global_store_dword %0, %1, off" ::"v"(d2), "v"(acc) : "memory");
+      }
+    }
+  }
+}
+
+template <int W, bool IMG, bool IQR>
+static void run_skeleton(const char *name) {
+  const int y_t = 1125, x_t = 2576, frames = 30, S = 333333;
+  const int tiles_l = (y_t - 2) / 126 + 1, tiles_p = (x_t - 2) / 127 + 1;
+  const size_t bytes = (size_t)frames * y_t * x_t * 4;
+  float *out, *img; float2 *iq;
+  if (hipMalloc(&out, bytes + 4096) != hipSuccess || hipMalloc(&img, (size_t)frames * 480000 * 4) != hipSuccess ||
+      hipMalloc(&iq, (size_t)frames * S * 8) != hipSuccess) { printf("alloc failed\n"); exit(1); }
+  (void)hipMemset(iq, 0, (size_t)frames * S * 8);
+  const unsigned units = frames * tiles_p, upx = (units + 15) / 16 * 2;
+  const dim3 grid(8, tiles_l, upx);
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) k_skeleton<W, IMG, IQR><<<grid, 512>>>(iq, out, img, y_t, x_t, S, tiles_l, tiles_p, frames, 1.0f);
+  (void)hipEventRecord(a);
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i) k_skeleton<W, IMG, IQR><<<grid, 512>>>(iq, out, img, y_t, x_t, S, tiles_l, tiles_p, frames, 1.0f);
+  (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+  float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= reps;
+  const double alg = (double)bytes + (IMG ? frames * 480000.0 * 4 : 0.0) + (IQR ? frames * (double)S * 8 : 0.0);
+  printf("%-58s %7.1f us  %6.2f TB/s algorithmic (%.1f MB)\n", name, ms * 1e3, alg / (ms * 1e-3) / 1e12, alg / 1e6);
+  (void)hipFree(out); (void)hipFree(img); (void)hipFree(iq);
+}
+
 int main() {
+  printf("---- skeleton of the raster launch (C2: 30 frames, 2576 x 1125, tiles of 127 x 127, 512 threads, kernel's grid order)\n");
+  run_skeleton<0, false, false>("raster stores only");
+  run_skeleton<12, false, false>("raster stores + 12 fma/pixel");
+  run_skeleton<12, false, true>("raster stores + IQ staging + LDS read + 12 fma/pixel");
+  run_skeleton<12, true, false>("raster + image stores + 12 fma/pixel");
+  run_skeleton<0, true, true>("raster + image stores + IQ staging, no filler");
+  run_skeleton<12, true, true>("raster + image stores + IQ staging + 12 fma/pixel");
+  run_skeleton<24, true, true>("raster + image stores + IQ staging + 24 fma/pixel");
+  printf("---- store shapes (round 2-5)\n");
   for (int y : {1125, 1152}) {
     run<1, 0>("dword    (1 line/lane), no VALU", y);
     run<2, 0>("dwordx2  (2 lines/lane), no VALU", y);
