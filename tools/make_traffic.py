@@ -80,9 +80,38 @@ def spectra_main():
     print(leg, json.dumps(doc["spectra"][leg]))
 
 
+def stats_main():
+    """make_traffic.py --stats <kernel_stats.csv> <tag> [workload]: the rocprofv3 --kernel-trace --stats averages of the frame-loop
+    kernels into profiles/traffic.json (per kernel: "rocprofv3": {avg_launch_ms, calls, tag}), so that bench.py can print the
+    profiler's average beside its own HIP-event one (roofline.profiled)."""
+    path_csv, tag = sys.argv[2], sys.argv[3]
+    wl = sys.argv[4] if len(sys.argv) > 4 else "C2"
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        doc = json.load(open(path))
+    except Exception:
+        doc = {}
+    kb = {"raster_down_iq": 485359920, "raster_down_iq_exact": 485359920, "down_fused_iq_sums": 137599920}   # C2 algorithmic bytes per launch
+    for r in csv.DictReader(open(path_csv)):
+        for sub, name in NAMES.items():
+            if sub in r["Name"]:
+                e = doc.setdefault(wl, {}).setdefault(name, {})
+                ms = float(r["AverageNs"]) * 1e-6
+                e["rocprofv3"] = {"avg_launch_ms": round(ms, 5), "calls": int(r["Calls"]), "tag": tag,
+                                  "source": f"profiles/{tag}_kernel_stats_bench.csv"}
+                if wl == "C2" and name in kb:
+                    e["rocprofv3"]["achieved_GBs"] = round(kb[name] / (ms * 1e-3) / 1e9, 1)
+                    e["rocprofv3"]["frac"] = round(kb[name] / (ms * 1e-3) / 1e9 / 8000.0, 4)
+                break
+    json.dump(doc, open(path, "w"), indent=1)
+    print(json.dumps({k: v.get("rocprofv3") for k, v in doc.get(wl, {}).items() if isinstance(v, dict) and "rocprofv3" in v}, indent=1))
+
+
 def main():
     if sys.argv[1] == "--spectra":
         return spectra_main()
+    if sys.argv[1] == "--stats":
+        return stats_main()
     fdir, wdir, tag = sys.argv[1:4]
     wl = sys.argv[4] if len(sys.argv) > 4 else "C2"
     f, w = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
@@ -96,20 +125,18 @@ def main():
                     f"the passes tagged {tag}.  Counter unit KB, median over a kernel's launches.  gfx950 correction per "
                     "MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts coalesced reads at one half, so fetch bytes = "
                     "FETCH_SIZE*1024*2; WRITE_SIZE taken as is.  Infinity-Cache hits are included in FETCH_SIZE.")
-    spectra_keep = doc.get("spectra")
-    doc[wl] = {}
-    if spectra_keep:
-        doc["spectra"] = spectra_keep
+    doc.setdefault(wl, {})   # (entries this pass did not measure keep their own tag)
     # (doc["_calibration"], written from tools/calib_fetch.sh's table, is kept as it is: the x2 correction was verified at 4, 8
     # and 16 bytes per lane in round 4)
     for k in sorted(set(f) | set(w)):
         fk, wk = f.get(k, 0.0), w.get(k, 0.0)
-        doc[wl][k] = {"fetch_size_kb": round(fk), "write_size_kb": round(wk), "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024)}
+        e = doc[wl].setdefault(k, {})
+        e.update({"fetch_size_kb": round(fk), "write_size_kb": round(wk), "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024), "tag": tag})
     fs, ns = search_totals(fdir, "FETCH_SIZE")
     ws, _ = search_totals(wdir, "WRITE_SIZE")
     if ns:
         doc[wl]["search"] = {"fetch_size_kb": round(fs), "write_size_kb": round(ws), "hbm_bytes_per_search": int(fs * 1024 * 2 + ws * 1024),
-                             "searches": ns, "note": "all FFT passes + argmax of one configuration search (fused loaders / epilogue: no other kernels)"}
+                             "searches": ns, "tag": tag, "note": "all FFT passes + argmax of one configuration search (fused loaders / epilogue: no other kernels)"}
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(doc[wl], indent=1))
 
