@@ -1021,6 +1021,17 @@ def main():
         os._exit(5)
     signal.signal(signal.SIGTERM, on_term)
 
+    try:
+        return run_parent(args, rank, local_rank, world, t_end, state)
+    except BaseException as e:   # whatever went wrong -- a library call that gave up on a stuck stream among it -- the line is printed
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        if rank == 0:
+            emit(partial(f"{type(e).__name__}: {e}"))
+        return 1
+
+
+def run_parent(args, rank, local_rank, world, t_end, state):
     stage("import torch, library, context")
     env = make_env(args, rank, local_rank, world)
     torch, dist, tsdr, synth, par, ctx, dev, share = (env[k] for k in ("torch", "dist", "tsdr", "synth", "par", "ctx", "dev", "share"))
@@ -1106,6 +1117,8 @@ def main():
         except Exception as e:
             line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
 
+    if os.environ.get("TSDR_BENCH_TEST_HANG") == "raise":    # (tests: a call of this process that fails)
+        raise RuntimeError("test: the parent fails here")
     if os.environ.get("TSDR_BENCH_TEST_HANG") == "parent":   # (tests: a call of this process that never returns)
         stage("test: the parent hangs here")
         time.sleep(1e6)

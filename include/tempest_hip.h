@@ -129,6 +129,9 @@ int tsdr_get_precision(tsdr_ctx *ctx);
  *   "pipe_pin"    k >= 0: arrangement k of the list tsdr_frames_pipeline_info reports, nothing is measured; -1 (default): the
  *                 measured choice.  "pipe_measure" 1: forget what is known about the current configuration and measure it at
  *                 the next submissions ("measure now").
+ *   "raster_v4"   32 / 16: the FAST raster launch with four raster lines per lane (k_raster_fast4: 1024-byte wave-stores, image rows
+ *                 compacted into contiguous runs) where the geometry allows (C2); same rasters, images and indices.  Round 6's
+ *                 A/B of the store pattern: 12-20 % slower than the one-line-per-lane walk; default 0.
  *   "wait_ms"     bound of every host-side wait for a stream, in milliseconds (default 30000; 0 = unbounded): tsdr_wait_stats.
  * The environment variables TSDR_AC_MIXED / TSDR_FFT_NO_MIX2 / TSDR_SYNC_GUARD_PPB / TSDR_SYNC_GUARD_AUTO / TSDR_FAST_WALK_ONLY /
  * TSDR_WAIT_MS / TSDR_BETA_WAVES / TSDR_PIPE_MODE / TSDR_PIPE_TUNE / TSDR_PIPE_LANES / TSDR_PIPE_PRIORITY / TSDR_RASTER_SPLIT / TSDR_DOWN_XCD / TSDR_DOWN_SPP_MAX_PCT

@@ -75,6 +75,8 @@ struct tsdr_ctx {
                                   // (round 4: 50 -> 200 once wide rows stage with 16 loads in flight: C3 0.40 -> 0.24 ms per buffer)
   int opt_down_xcd = 1;      // raster-free FAST kernel: XCD-aware tile order
   int opt_raster_rec4 = -1;  // FAST raster walk: staged |IQ| as plain f32 samples (4 bytes) instead of {a, slope hi, slope lo} records (16): 0 = never (the A/B), else wherever the f32 walk forms the images
+  int opt_raster_v4 = 0;     // FAST frame loop with rasters at C2-like geometry: four lines per lane (k_raster_fast4: dwordx4 raster stores, compacted image
+                             // rows) -- 32: four wavefronts of 32 pixel columns per tile, other > 0: eight of 16.  Round 6's A/B: loses by 12-20 %, off
   int opt_raster_split = 0;  // FAST frame loop with rasters: 1 = sheared raster-only kernel + raster-free image kernel, 2 = the same unsheared (A/B)
   int opt_ac_fuse_mid = 1;  // autocorrelation: last forward pass + power spectrum + first inverse pass as one launch
   // sync guard of the FAST frame loop (guard.h): relative top-2 margin below which a frame is re-evaluated exactly

@@ -190,6 +190,7 @@ tsdr_ctx *tsdr_create(int device) {
   if (const char *e = getenv("TSDR_PIPE_PRIORITY")) ctx->opt_pipe_priority = atoi(e);
   if (const char *e = getenv("TSDR_RASTER_SPLIT")) ctx->opt_raster_split = atoi(e);
   if (const char *e = getenv("TSDR_RASTER_REC4")) ctx->opt_raster_rec4 = atoi(e);
+  if (const char *e = getenv("TSDR_RASTER_V4")) ctx->opt_raster_v4 = atoi(e);
   if (const char *e = getenv("TSDR_DOWN_XCD")) ctx->opt_down_xcd = atoi(e) != 0;
   if (const char *e = getenv("TSDR_DOWN_SPP_MAX_PCT")) ctx->opt_down_spp_max_pct = atoi(e);
   if (const char *e = getenv("TSDR_PIPE_MODE")) ctx->opt_pipe_mode = atoi(e) < 0 ? -1 : atoi(e) > 2 ? 2 : atoi(e);
@@ -281,6 +282,11 @@ int tsdr_set_option(tsdr_ctx *ctx, const char *name, int value) {
   else if (!strcmp(name, "down_spp_max_pct")) ctx->opt_down_spp_max_pct = value < 0 ? 0 : value;
   else if (!strcmp(name, "raster_split")) ctx->opt_raster_split = value < 0 || value > 2 ? 0 : value;
   else if (!strcmp(name, "raster_rec4")) ctx->opt_raster_rec4 = value < 0 ? -1 : value != 0;
+  else if (!strcmp(name, "raster_v4")) {
+    int rc = tsdr::pipe_drain(ctx);   // (the projection-sum layout of submitted buffers belongs to the old setting)
+    if (rc) return rc;
+    ctx->opt_raster_v4 = value < 0 ? 0 : value;   // 0 (default): k_raster_fast; 32: k_raster_fast4, four wavefronts of 32 pixel columns per tile; other > 0: eight of 16
+  }
   else if (!strcmp(name, "beta_waves")) ctx->opt_beta_waves = value == 8 ? 8 : 4;
   else if (!strcmp(name, "pipe_mode") || !strcmp(name, "pipe_lanes") || !strcmp(name, "pipe_priority") || !strcmp(name, "pipe_tune")) {
     int rc = tsdr::pipe_drain(ctx);   // (the next submission sees another arrangement and runs the lanes empty itself)

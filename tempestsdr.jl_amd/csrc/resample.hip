@@ -753,6 +753,327 @@ __global__ __launch_bounds__(256 * VW, 8) void k_raster_fast(const float *__rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_raster_fast4 (round 6; option "raster_v4", OFF: built, correct, measured, loses): the FAST raster + image + sums launch with
+// FOUR consecutive raster lines per lane.  Measured on C2 (30 frames): 126-137 us against 112-121 us for k_raster_fast on the
+// same boxes (eight wavefronts of 16 pixel columns: 145 us; five wavefronts per SIMD: 145 us; XCD grouping 1 / 2 / 4 / 8: no
+// difference; conflict-free LDS planes: no difference).  By deletion: everything but the raster stores 79 us (k_raster_fast:
+// 77), the image stores 13.6 us of that, the raster stores +57 us (k_raster_fast: +42): what the store-only skeleton promised
+// (tools/ubench/store_pattern.hip: 81 against 130 us with "free" arithmetic) does not carry over to a kernel whose stores are
+// paced by its own arithmetic.  Kept as the A/B, tested for identical rasters / images / indices.
+//
+// Why: the launch is bound by the NUMBER of 128-byte write requests, not by their bytes (tools/ubench/store_pattern.hip:
+// every store shape fits ~45 G line requests per second, partial or full).  With one line per lane a wave-store is 256 bytes
+// on an arbitrary 4-byte boundary = 3 requests, and a column event's image rows leave as ~136-byte runs = 2 more; with four
+// lines per lane the wave-store is ONE dwordx4 per lane = 1024 contiguous bytes = 9 requests instead of 12, and a wavefront's
+// 136 image rows of a column are compacted through LDS into contiguous 256-byte runs (6 requests instead of 8-9).
+//
+// Same arithmetic as k_raster_fast<REC4, F32W> (position advance, |IQ| / D staged as f32, pixel = (D - r) a' + r b'; image =
+// f64 blends of f32 pixels, one rounding): rasters and images are bit-identical to that kernel's.  What differs is the
+// association of the projection partial sums (one row partial per 128-pixel strip as before; one column partial per 255-line
+// tile instead of per 127-line tile), which FAST mode leaves open (the sync guard decides close calls exactly).
+//
+// Tile = 256 staged lines (255 owned) x 128 pixels (127 owned); 256 threads = 4 wavefronts side by side, 32 pixel columns
+// each; lane j owns tile lines 4j .. 4j+3.  The vertical neighbour of lines 4j .. 4j+2 is in the lane itself, of line 4j+3
+// it is lane j+1's first line (ds_bpermute of its horizontal blend).
+// ------------------------------------------------------------------------------------------------------------
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float_t;   // (a pointer the compiler KNOWS is LDS: ds_* instructions, not flat_*)
+
+__device__ inline void store4_saddr(float *base_uniform, unsigned lane_off_bytes, v4f_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(lane_off_bytes), "v"(v), "s"(base_uniform) : "memory");
+}
+
+// a pointer that IS wave-uniform, said so (keeps it in scalar registers for store_saddr's "s" operand)
+__device__ __forceinline__ float *uniform_ptr(float *p) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return reinterpret_cast<float *>(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
+struct Down4 {   // per-lane / per-wave state of the in-walk downgrade, four lines per lane
+  unsigned long long colmask;  // bit j: segment pixel j is the left tap of an output column
+  int ccol; double cdxd;       // lane j: that column and its weight
+  int rrow[4]; double rdyd[4]; // this lane's lines: output row (-1: none) and weight
+  int below;                   // ds_bpermute address of the lane below
+  float *dn; int h_out;
+  bool proj;
+  float racc[4];               // row sums of this lane's rows over the wave's columns, in column order
+  float csum;                  // lane j: sum over the wave's rows of the column whose left tap is pixel j
+  int lane;
+  int R0, nrows;               // the wave's output rows: [R0, R0 + nrows), contiguous
+  lds_float_t *rowbuf;         // this wave's LDS scratch: one column's rows in row order
+};
+
+__device__ __forceinline__ void down_event4(Down4 &di, int j, const float (&p0)[4], const float (&p1)[4]) {
+  const int c = __builtin_amdgcn_readlane(di.ccol, j);
+  const long long bits = __double_as_longlong(di.cdxd);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffLL), j), hi = __builtin_amdgcn_readlane((int)(bits >> 32), j);
+  const double dx = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  double top[5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) top[i] = fma(dx, (double)p1[i] - (double)p0[i], (double)p0[i]);
+  {
+    const long long tb = __double_as_longlong(top[0]);
+    const int blo = __builtin_amdgcn_ds_bpermute(di.below, (int)(tb & 0xffffffffLL));
+    const int bhi = __builtin_amdgcn_ds_bpermute(di.below, (int)(tb >> 32));
+    top[4] = __longlong_as_double(((long long)bhi << 32) | (unsigned)blo);
+  }
+  float m = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = (float)fma(di.rdyd[i], top[i + 1] - top[i], top[i]);
+    if (di.rrow[i] >= 0) di.rowbuf[di.rrow[i] - di.R0] = v;
+    if (di.proj) {
+      const float mv = di.rrow[i] >= 0 ? v : 0.0f;
+      di.racc[i] = __fadd_rn(di.racc[i], mv);
+      m = __fadd_rn(m, mv);
+    }
+  }
+  // the column's rows, compacted: lane t stores row R0 + t (+ 64, + 128, ...) -- contiguous runs whatever the lines' ownership
+  // pattern is.  (LDS operations of one wavefront complete in order: the reads below see the writes above; the fence keeps the
+  // compiler from moving them across each other.)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float *dcol = uniform_ptr(di.dn + (size_t)c * di.h_out + di.R0);
+  for (int t = di.lane; t < di.nrows; t += 64) {
+    const float v = di.rowbuf[t];
+    store_saddr(dcol, (unsigned)t * 4u, v);
+  }
+  if (di.proj) {
+    const float tot = wave_sum63(m);
+    const float t63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
+    di.csum = di.lane == j ? t63 : di.csum;
+  }
+}
+
+// The walk of one wavefront: npix pixel columns (+ one evaluated, not stored, when `extra`), four lines per lane.
+// CLAMP: first pixels of a frame (x0 < 0); TAILT: the tile reaches past the last raster line (per-line store predicates).
+template <bool CLAMP, bool TAILT>
+__device__ __forceinline__ void walk4(const FastAx &fa, const float *const (&row)[4], int (&kk)[4], float (&rf)[4], int npix, bool extra,
+                                      float *ob, unsigned loff_bytes, size_t ostride, int nvalid, Down4 &di) {
+  {
+    const unsigned long long b = reinterpret_cast<unsigned long long>(ob);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    ob = reinterpret_cast<float *>(((unsigned long long)hi << 32) | (unsigned long long)lo);
+  }
+  const float rstepf = (float)fa.rstep, Df = (float)fa.D;
+  float prev[4] = {0.f, 0.f, 0.f, 0.f};
+  const int n = npix + (extra ? 1 : 0);
+  unsigned long long mm = di.colmask << 1;   // bit i: column (left tap i - 1) is completed by pixel i
+  float2 s1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s1[i] = rec4_read(row[i], CLAMP ? max(kk[i], 0) : kk[i]);
+#pragma unroll 1
+  for (int pi = 0; pi < n; ++pi) {   // (not unrolled: four independent lines per step are the instruction-level parallelism; 17 unrolled steps spill)
+    float cur[4];
+    float2 nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ref = CLAMP ? (kk[i] < 0 ? 0.f : rf[i]) : rf[i];
+      const float r2 = rf[i] + rstepf;
+      const bool cy = r2 >= Df;
+      kk[i] += (int)fa.qstep + (cy ? 1 : 0);
+      rf[i] = cy ? r2 - Df : r2;
+      // the next pixel's pair, one step ahead (after the last pixel: a read one or two floats past the row's samples, inside
+      // the workgroup's LDS, never used)
+      nx[i] = rec4_read(row[i], CLAMP ? max(kk[i], 0) : kk[i]);
+      cur[i] = rec4_pixel(ref, Df, s1[i]);
+    }
+    if (pi < npix) {
+      if (!TAILT) {
+        v4f_t v = {cur[0], cur[1], cur[2], cur[3]};
+        store4_saddr(ob, loff_bytes, v);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nvalid) store_saddr(uniform_ptr(ob), loff_bytes + 4u * (unsigned)i, cur[i]);
+      }
+      ob += ostride;
+    }
+    if ((mm >> pi) & 1ull) down_event4(di, pi - 1, prev, cur);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { prev[i] = cur[i]; s1[i] = nx[i]; }
+  }
+}
+
+// PW: pixel columns per wavefront (32: four wavefronts per 128-pixel tile; 16: eight -- twice as many, half as long: the launch
+// is ~3 rounds of workgroups at PW = 32, and its last, nearly empty round costs a quarter of it)
+template <int IQF, int PW>
+__global__ __launch_bounds__(64 * (128 / PW), 4) void k_raster_fast4(   // (HIP: second argument = wavefronts per SIMD -> at most 128 VGPRs)
+   const float *__restrict__ in, size_t in_stride, TileParams q, FastAx fa, FastInc fi,
+                                                        float *__restrict__ out, size_t out_stride, float *__restrict__ down, size_t down_stride) {
+  extern __shared__ double lds_d[];
+  constexpr int NL = 256, NWV = 128 / PW, NT = 64 * NWV;
+  const int Wp = q.W | 1;
+  float *smp1 = reinterpret_cast<float *>(lds_d);                       // [NL][Wp] |IQ| / D
+  char *after = reinterpret_cast<char *>(lds_d) + (((size_t)NL * Wp * 4 + 15) & ~(size_t)15);
+  double *rdyd = reinterpret_cast<double *>(after);                     // per line: row weight
+  double *cdxd = rdyd + NL;                                             // per pixel: column weight
+  int *rrow = reinterpret_cast<int *>(cdxd + q.TP + 1);
+  int *ccol = rrow + NL;
+  float *rowbuf = reinterpret_cast<float *>(ccol + q.TP + 1);           // [NWV][NL]
+
+  const unsigned xcd = blockIdx.x, ul = blockIdx.z;
+  const int tl = (int)blockIdx.y;
+  const unsigned U = (unsigned)(q.frames * q.tiles_p);
+  const unsigned gl = (unsigned)q.xcd_group_log;
+  const unsigned u = ((((ul >> gl) << 3) + xcd) << gl) + (ul & ((1u << gl) - 1u));
+  if (u >= U) return;
+  int f = (int)(((float)u + 0.5f) * q.inv_tiles_p);
+  int tp = (int)u - f * q.tiles_p;
+  if (tp < 0) { tp += q.tiles_p; --f; } else if (tp >= q.tiles_p) { tp -= q.tiles_p; ++f; }
+  const int l0 = tl * q.own_l, p0 = tp * q.own_p;
+  const float *src = in + (size_t)f * in_stride * iq_floats_as<IQF>(q.iqf);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+  int kb = fi.k00; unsigned rb = fi.r00;
+  adv32(kb, rb, (unsigned)tl, fi.qTL, fi.rTL, fa.D, fi.invD);
+  adv32(kb, rb, (unsigned)tp, fi.qTP, fi.rTP, fa.D, fi.invD);
+  auto line_pos = [&](int line_in_tile, int &k, unsigned &r) {
+    const int l = min(l0 + line_in_tile, q.y_t - 1);
+    k = kb; r = rb;
+    adv32(k, r, (unsigned)(l - l0), fi.qL, fi.rL, fa.D, fi.invD);
+  };
+
+  {  // stage: 2^lpl_log lanes per line, `cs` consecutive samples each; four lines' loads in flight per lane, the output
+     // row / column tables (f64 arithmetic that needs no memory) worked out under the first batch
+    const int lpl = 1 << q.lpl_log;
+    const int sub = tid >> q.lpl_log, j0 = tid & (lpl - 1), nsub = NT >> q.lpl_log;
+    const int cs = q.cs, jb = j0 * cs;
+    float re[4][4], im[4][4];
+    auto issue = [&](int r, float (&rre)[4], float (&rim)[4]) {
+      int k; unsigned rr;
+      line_pos(min(r, NL - 1), k, rr);
+      const unsigned kf = (unsigned)max(k, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        rre[t] = 0.f; rim[t] = 0.f;
+        if (t < cs) {
+          const unsigned ks = min(kf + (unsigned)min(jb + t, q.W - 1), q.S - 1u);
+          const float2 z = ld_iq_as<IQF>(src, ks, q.iqf);
+          rre[t] = z.x; rim[t] = z.y;
+        }
+      }
+    };
+    auto consume = [&](int r, const float (&rre)[4], const float (&rim)[4]) {
+      if (r >= NL) return;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = jb + t;
+        // a' = a / D (rec4_pixel).  Tile line r lies in LDS row (r & 3) * 64 + (r >> 2): the four lines of a lane in four planes,
+        // so that the 64 lanes of a wave-read are Wp (odd) floats apart -- conflict-free -- instead of 4 Wp
+        if (t < cs && j < q.W) smp1[((r & 3) * 64 + (r >> 2)) * Wp + j] = __fmul_rn(abs_iq<false>(rre[t], rim[t]), fi.invD);
+      }
+    };
+#pragma unroll
+    for (int b = 0; b < 4; ++b) issue(sub + b * nsub, re[b], im[b]);
+    {
+      // the first NL threads: output row of their line; the last TP + 1 (the first, with 256 threads): output column of every pixel
+      if (tid < NL) {
+        const int l = l0 + tid;
+        const bool mine = tid < q.own_l || tl == q.tiles_l - 1;
+        double d = 0.0;
+        const int r = (mine && l < q.y_t) ? inv_tap(q.ay, q.inv_sfy, l, q.h_out, d) : -1;
+        rrow[tid] = r; rdyd[tid] = d;
+      }
+      const int ct = NT > NL ? tid - NL : tid;
+      if (ct >= 0 && ct <= q.TP) {
+        const int pp = p0 + ct;
+        const bool minec = ct < q.TP && (ct < q.own_p || tp == q.tiles_p - 1);
+        double d2 = 0.0;
+        const int c = (minec && pp < q.x_t) ? inv_tap(q.axx, q.inv_sfx, pp, q.w_out, d2) : -1;
+        ccol[ct] = c; cdxd[ct] = d2;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) consume(sub + b * nsub, re[b], im[b]);
+    for (int r0 = sub + 4 * nsub; r0 < NL; r0 += 4 * nsub) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) issue(r0 + b * nsub, re[b], im[b]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) consume(r0 + b * nsub, re[b], im[b]);
+    }
+  }
+  __syncthreads();
+
+  Down4 di{};
+  int my_col = -1;
+  {
+    const int pbeg = p0 + wave * PW;
+    const int n_own = min(PW, q.x_t - pbeg);
+    if (n_own > 0) {
+      const bool extra = wave < NWV - 1 && pbeg + PW < q.x_t;
+      int kk[4]; float rf[4]; const float *row[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k; unsigned r;
+        line_pos(4 * lane + i, k, r);
+        const int kf = max(k, 0);
+        adv32(k, r, (unsigned)(wave * PW), fa.qstep, fa.rstep, fa.D, fi.invD);
+        kk[i] = k - kf; rf[i] = (float)r;
+        row[i] = smp1 + (i * 64 + lane) * Wp;
+        di.rrow[i] = rrow[4 * lane + i];
+        di.rdyd[i] = rdyd[4 * lane + i];
+        di.racc[i] = 0.f;
+      }
+      const int cj = lane <= PW ? wave * PW + lane : q.TP;   // entry TP is never a column
+      di.ccol = ccol[cj];
+      di.cdxd = cdxd[cj];
+      di.colmask = __ballot(lane < PW && di.ccol >= 0);
+      my_col = lane < PW ? di.ccol : -1;
+      di.below = ((lane + 1) & 63) << 2;
+      di.dn = down + (size_t)f * down_stride;
+      di.h_out = q.h_out;
+      di.proj = q.proj != nullptr;
+      di.lane = lane;
+      di.csum = 0.f;
+      di.rowbuf = (lds_float_t *)(rowbuf + wave * NL);
+      {  // the wave's rows: contiguous [R0, R0 + nrows) (every row between two owned ones has its top line in the tile)
+        int mn = 0x7fffffff, mx = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (di.rrow[i] >= 0) { mn = min(mn, di.rrow[i]); mx = max(mx, di.rrow[i]); }
+        for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_xor(mn, off, 64)); mx = max(mx, __shfl_xor(mx, off, 64)); }
+        di.R0 = mx >= 0 ? mn : 0;
+        di.nrows = mx >= 0 ? mx - mn + 1 : 0;
+      }
+      const long long num0 = (long long)(2ull * ((unsigned long long)l0 * q.x_t + p0) + 1ull) * (long long)fa.S - (long long)fa.P;
+      float *ob = out + (size_t)f * out_stride + (size_t)pbeg * q.y_t;
+      const unsigned loff = (unsigned)(l0 + 4 * lane) * 4u;
+      const int nvalid = max(0, min(4, q.y_t - (l0 + 4 * lane)));   // lines of this lane inside the raster
+      const bool tailt = l0 + NL > q.y_t;
+      if (num0 < 0) {
+        if (tailt) walk4<true, true>(fa, row, kk, rf, n_own, extra, ob, loff, (size_t)q.y_t, nvalid, di);
+        else walk4<true, false>(fa, row, kk, rf, n_own, extra, ob, loff, (size_t)q.y_t, nvalid, di);
+      } else if (tailt) walk4<false, true>(fa, row, kk, rf, n_own, extra, ob, loff, (size_t)q.y_t, nvalid, di);
+      else walk4<false, false>(fa, row, kk, rf, n_own, extra, ob, loff, (size_t)q.y_t, nvalid, di);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { di.rrow[i] = -1; di.racc[i] = 0.f; }
+    }
+  }
+  if (q.proj) {
+    // row partials: the four wavefronts side by side added left to right -> rowpart[strip][row]; column partials: one
+    // wavefront row per tile, so a column's sum over the tile's rows is already complete -> colpart[line tile][column]
+    __syncthreads();   // (the staged samples are dead: their LDS carries the wavefronts' row sums)
+    float *rp = reinterpret_cast<float *>(lds_d);   // [NWV][NL]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rp[wave * NL + 4 * lane + i] = di.racc[i];
+    __syncthreads();
+    float *pr = q.proj + (size_t)f * q.proj_stride;
+    if (tl == 0 && tp == 0 && tid < 2) q.keys[(size_t)f * 2 + tid] = 0ull;
+    const int r = tid < NL ? rrow[tid] : -1;
+    if (r >= 0) {
+      float a = rp[tid];
+#pragma unroll
+      for (int w = 1; w < NWV; ++w) a = __fadd_rn(a, rp[w * NL + tid]);
+      pr[(size_t)q.tiles_l * q.w_out + (size_t)tp * q.h_out + r] = a;
+    }
+    if (my_col >= 0) pr[(size_t)tl * q.w_out + my_col] = di.csum;
+  }
+}
+
 // direct variant (no LDS, EXACT arithmetic) for ratios the tiled kernel cannot stage; lanes along lines.
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_raster_direct(const float *__restrict__ in, size_t in_stride, unsigned S,
@@ -926,9 +1247,13 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     const bool dn = want_down && q.TP >= 32 && y_t > h_out && x_t > w_out;
     // wavefronts stacked vertically per workgroup (see k_raster_fast).  Measured on C2: 1 -> 0.121 ms, 2 -> 0.118 ms,
     // 4 (1024 threads, 77 KiB LDS) -> 0.131 ms; again with f32 samples (REC4, 12 KiB): 130 / 124 / 138 us for the launch
-    int VW = y_t >= 2 * 64 ? 2 : 1;
-    const int lstep = dn ? 63 : 64, NL = lstep * (VW - 1) + 64;
-    q.own_l = lstep * VW;
+    // round 6: four lines per lane (k_raster_fast4) wherever the f32-sample walk with the in-walk image writes rasters from
+    // 128-pixel tiles -- C2's route: a quarter fewer write requests for the same bytes (option "raster_v4", default on)
+    const bool v4 = ctx->opt_raster_v4 > 0 && rec4_ok && dn && q.TP == 128 && out != nullptr && 2 * P < (size_t(1) << 24) && y_t >= 512 &&
+                    x_t <= 127 * 128 && ctx->opt_raster_split == 0;
+    int VW = v4 ? 1 : y_t >= 2 * 64 ? 2 : 1;
+    const int lstep = dn ? 63 : 64, NL = v4 ? 256 : lstep * (VW - 1) + 64;
+    q.own_l = v4 ? 255 : lstep * VW;
     q.own_p = dn ? q.TP - 1 : q.TP;
     q.tiles_l = dn ? (y_t - 2) / q.own_l + 1 : (int)ceil_div((size_t)y_t, (size_t)q.own_l);
     q.tiles_p = dn ? (x_t - 2) / q.own_p + 1 : (int)ceil_div((size_t)x_t, (size_t)q.TP);
@@ -954,6 +1279,8 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     q.lpl_log = best;
     q.cs = (int)ceil_div((size_t)q.W, (size_t)1 << best);
     size_t lds = rec4 ? (((size_t)NL * (size_t)(q.W | 1) * 4 + 15) & ~(size_t)15) + 16 : (size_t)NL * (size_t)(q.W | 1) * 16 + 16;
+    const int v4pw = ctx->opt_raster_v4 == 32 ? 32 : 16;
+    if (v4) lds += (size_t)(128 / v4pw) * NL * 4;   // the wavefronts' image-row scratch (down_event4)
     // the images' projection partial sums come out of the same walk when the caller has room for them
     // (with narrower tiles -- down-sampling ratios such as C3's -- the per-workgroup part of the sums is spread over
     // four times as many workgroups and costs more than the separate pass over the images: 0.382 vs 0.354 ms)
@@ -979,6 +1306,21 @@ int raster_frames_d(tsdr_ctx *ctx, const float *in, int cplx, size_t in_stride, 
     if (upx > 65535 || (size_t)q.tiles_l > 65535 || units >= (size_t(1) << 20))
       return set_err(ctx, TSDR_EINVAL, "raster: too many tiles for one launch (split the buffer)");
     const dim3 grid(8, (unsigned)q.tiles_l, (unsigned)upx);
+    if (v4) {
+      if (v4pw == 32) {
+        if (q.iqf.sc16) {
+          TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast4<IQF_SC16, 32>), grid, dim3(256), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);
+        } else {
+          TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast4<IQF_CF32, 32>), grid, dim3(256), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);
+        }
+      } else if (q.iqf.sc16) {
+        TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast4<IQF_SC16, 16>), grid, dim3(512), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);
+      } else {
+        TSDR_LAUNCH(ctx, "raster_down_iq", (k_raster_fast4<IQF_CF32, 16>), grid, dim3(512), lds, in, in_stride, q, fa, fi, out, out_stride, down, down_stride);
+      }
+      if (did_down) *did_down = true;
+      return TSDR_OK;
+    }
 #define FASTK2(C, W32, D, PW, VWK, NAME)                                                                              \
   do {                                                                                                                \
     if (out) {                                                                                                        \

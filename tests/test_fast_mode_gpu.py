@@ -676,3 +676,50 @@ def test_frames_pipeline_without_alignment_and_mixed_with_one_call(ctx, tsdr, sy
                 assert np.array_equal(want[1], got[1]), (kinds, do_align)
     finally:
         ctx.set_option("pipe_mode", -1)
+
+
+@pytest.mark.parametrize("pw", [32, 16])
+@pytest.mark.parametrize("fmt", ["cf32", "sc16"])
+def test_raster_v4_option_gives_the_same_rasters_images_and_indices(tsdr, synth, pw, fmt):
+    """Option "raster_v4" (round 6's A/B of the raster launch's store pattern: four raster lines per lane, 1024-byte wave-stores,
+    image rows compacted through LDS; off by default because it measures slower): same arithmetic per pixel, so rasters, frames
+    and frame-sync indices are those of the default kernel bit for bit -- C2 geometry (five 255-line tiles, the last one cut by
+    the raster's end; 21 strips, the last one 36 pixels wide; the frame's first pixels before the first sample), two buffers."""
+    from tempestsdr_jl_amd import api
+    w = synth.WORKLOADS["C2"]
+    Fs, x_t, y_t, fv = w["Fs"], w["x_t"], w["y_t"], w["fv"]
+    S = synth.samples_per_frame(Fs, fv)
+    nfr, npx, P = 4, 600 * 800, x_t * y_t
+    z = synth.synth_leak(Fs, x_t, y_t, fv, 2 * nfr * S)
+    if fmt == "sc16":
+        scale = np.float32(float(np.max(np.abs(z.view(np.float32)))) / 2047.0)
+        q = np.round(z.view(np.float32) / scale).astype(np.int16)
+    res = {}
+    for v4 in (0, pw):
+        ctx = tsdr.Context(0)
+        ctx.set_option("raster_v4", v4)
+        sync = tsdr.SyncXY(ctx, 600, 800)
+        d_state = ctx.upload(np.zeros(npx, np.float32))
+        d_in = ctx.upload(q) if fmt == "sc16" else ctx.upload(z.view(np.float32))
+        d_fr, d_ra, d_ix = ctx.dev_alloc(nfr * npx * 4), ctx.dev_alloc(nfr * P * 4), ctx.dev_alloc(nfr * 8)
+        out = []
+        try:
+            for b in range(2):
+                o_in = d_in + b * nfr * S * (4 if fmt == "sc16" else 8)
+                if fmt == "sc16":
+                    api.frames_sc16_d(ctx, sync, o_in, scale, nfr * S, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, d_ra, d_ix)
+                else:
+                    api.frames_d(ctx, sync, o_in, nfr * S, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, d_ra, d_ix)
+                ctx.synchronize()
+                out.append((ctx.download(d_fr, (nfr * npx,), np.uint32), ctx.download(d_ra, (nfr * P,), np.uint32),
+                            ctx.download(d_ix, (nfr * 2,), np.int32)))
+            res[v4] = out
+        finally:
+            sync.close()
+            for p in (d_state, d_in, d_fr, d_ra, d_ix):
+                ctx.dev_free(p)
+            ctx.close()
+    for a, b in zip(res[0], res[pw]):
+        assert np.array_equal(a[1], b[1]), "rasters differ"
+        assert np.array_equal(a[2], b[2]), "sync indices differ"
+        assert np.array_equal(a[0], b[0]), "frames differ"

@@ -93,23 +93,50 @@ def test_sc16_through_the_sync_guard_and_the_pipeline(ctx, tsdr, synth):
 def test_sc16_guard_beyond_one_guard_launch(ctx, tsdr, synth):
     """More than kGuardChunk = 256 frames in one call: the guard runs as several launches, and the later ones must find their
     frames' int16 samples at f0 * S * 4 bytes (they were offset as ComplexF32, i.e. read frame 2 * f0 and past the
-    buffer).  The plateau leak flags frames in every chunk; one-by-one re-evaluation ("sync_guard_auto" 0).  The call's guard
-    ring entry carries the CALL's totals (one entry per call, written by its last launch)."""
+    buffer).  The plateau leak flags frames in every launch's range; one-by-one re-evaluation ("sync_guard_auto" 0: the adaptive
+    route depends on the calls before, which differ between the two formats' runs here)."""
     Fs, x_t, y_t, nfr = 2.0e6, 1056, 628, 300
     S = synth.samples_per_frame(Fs, 60.0)
     q, scale, cf = _capture(synth, Fs, x_t, y_t, 60.0, S * nfr, card="plateau")
-    for auto in (0, 1):
-        ctx.set_option("sync_guard_auto", auto)
-        ctx.sync_guard_stats(reset=True)
-        try:
-            _, ix, _, _ = _run(ctx, tsdr, cf, q, scale, S, y_t, x_t, False)
-            checked, flagged = ctx.sync_guard_stats()
-            assert checked == 2 * nfr and flagged > 0      # (two runs: cf32 and sc16)
-            if auto == 0:
-                flags_late = flagged
-        finally:
-            ctx.set_option("sync_guard_auto", 1)
-    assert flags_late > 2, "the plateau leak should flag frames beyond the first guard launch"
+    ctx.set_option("sync_guard_auto", 0)
+    ctx.sync_guard_stats(reset=True)
+    try:
+        _run(ctx, tsdr, cf, q, scale, S, y_t, x_t, False)
+        checked, flagged = ctx.sync_guard_stats()
+        assert checked == 2 * nfr and flagged > 2      # (two runs: cf32 and sc16)
+    finally:
+        ctx.set_option("sync_guard_auto", 1)
+
+
+def test_guard_ring_entry_carries_the_calls_totals(tsdr, synth):
+    """One pinned ring entry per CALL, written by its last guard launch with the call's totals (a call of 300 frames is two
+    launches; round 5 let each launch overwrite the entry with its own counts, so the adaptive route saw 44 frames of 300).
+    300 plateau frames per call, > 15 % flagged: the entry of call 1 is folded at call 4 (the lag is 3 calls) and, being a
+    full window (>= 60 frames) by itself, switches the route at once -- call 4 is the first whole buffer run exactly."""
+    from tempestsdr_jl_amd import api
+    Fs, x_t, y_t, nfr = 2.0e6, 1056, 628, 300
+    S = synth.samples_per_frame(Fs, 60.0)
+    q, scale, cf = _capture(synth, Fs, x_t, y_t, 60.0, S * nfr, card="plateau")
+    npx = 600 * 800
+    ctx = tsdr.Context(0)
+    sync = tsdr.SyncXY(ctx, 600, 800)
+    d_state, d_in = ctx.upload(np.zeros(npx, np.float32)), ctx.upload(q)
+    d_fr, d_ix = ctx.dev_alloc(nfr * npx * 4), ctx.dev_alloc(nfr * 8)
+    try:
+        seen = []
+        for k in range(5):
+            api.frames_sc16_d(ctx, sync, d_in, scale, nfr * S, S, y_t, x_t, np.float32(0.1), True, d_state, d_fr, None, d_ix)
+            ctx.synchronize()
+            seen.append(ctx.sync_guard_auto())
+        checked, flagged = ctx.sync_guard_stats()
+        assert flagged > 0.15 * checked, (checked, flagged)
+        assert [s[1] for s in seen] == [0, 0, 0, 1, 2], seen      # whole buffers exact so far, after calls 1 .. 5
+        assert ctx.wait_stats() == (0, 0)
+    finally:
+        sync.close()
+        for p in (d_state, d_in, d_fr, d_ix):
+            ctx.dev_free(p)
+        ctx.close()
 
 
 def test_ring_sc16raw_hands_out_the_int16_pairs(ctx, tsdr, synth):

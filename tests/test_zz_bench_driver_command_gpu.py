@@ -64,3 +64,11 @@ def test_a_parent_that_hangs_still_prints_what_it_measured():
     d = _one_line(r)
     assert r.returncode == 3 and "watchdog" in d["incomplete"] and "last stage reached" in d["incomplete"]
     assert d["value"] > 0 and d["roofline"]["frac"] > 0        # the headline had been measured: it is in the line
+
+
+def test_a_parent_that_fails_still_prints_what_it_measured():
+    env = dict(CLEAN, TSDR_BENCH_TEST_HANG="raise")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--repeats", "3",
+                        "--no-cpu", "--legs", "none"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+    d = _one_line(r)
+    assert r.returncode == 1 and "RuntimeError" in d["incomplete"] and d["value"] > 0 and d["roofline"]["frac"] > 0

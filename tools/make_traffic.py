@@ -8,7 +8,7 @@ only the raster-materialising launches (OUT = true template argument) are used."
 import csv, glob, json, os, statistics, sys
 
 NAMES = {  # kernel-name substring -> bench.py's launch name
-    "k_raster_fast<true, true, true, 32, true": "raster_down_iq",
+    "k_raster_fast<true, true, true, 32, true": "raster_down_iq", "k_raster_fast4<": "raster_down_iq",
     "k_raster_fast<true, true, true, 32, false": "down_walk_iq",
     "k_raster_tile<true, true>": "raster_down_iq_exact",
     "k_shift_iir": "shift_iir", "k_proj": "sync_proj", "k_beta": "sync_beta", "k_tail": "sync_beta+shift_iir",

@@ -154,8 +154,8 @@ __global__ __launch_bounds__(512, 8) void k_skeleton(const float2 *__restrict__ 
     float *dst = base + (size_t)p * y_t + l;
     asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(acc) : "memory");
     if (IMG) {
-      const int c = (int)((p + 0.5) * (800.0 / x_t));
-      if ((int)((p - 0.5) * (800.0 / x_t)) != c && own && c < 800) {     // (wave-uniform column test, per-lane row ownership)
+      const int c = (p * 800) / x_t;
+      if (c != ((p - 1) * 800) / x_t && own && c < 800) {     // (wave-uniform column test in integers, per-lane row ownership)
         float *d2 = ib + (size_t)c * 600 + rrow;
         asm volatile("global_store_dword %0, %1, off" ::"v"(d2), "v"(acc) : "memory");
       }
@@ -297,13 +297,102 @@ __global__ __launch_bounds__(256, 8) void k_skeleton2(float *__restrict__ out, f
       asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(d) : "memory");
     }
     if (IMG) {
-      const int c = (int)((p + 0.5) * (800.0 / x_t));
-      if ((int)((p - 0.5) * (800.0 / x_t)) != c && c < 800) {
+      const int c = (p * 800) / x_t;
+      if (c != ((p - 1) * 800) / x_t && c < 800) {
         if (row0 + lane < 600) { float *d2 = ib + (size_t)c * 600 + row0 + lane; asm volatile("global_store_dword %0, %1, off" ::"v"(d2), "v"(acc) : "memory"); }
         if (lane < 4 && row0 + 64 + lane < 600) { float *d3 = ib + (size_t)c * 600 + row0 + 64 + lane; asm volatile("global_store_dword %0, %1, off" ::"v"(d3), "v"(acc2) : "memory"); }
       }
     }
   }
+}
+
+// FOUR consecutive lines per lane: dwordx4 raster stores (1024 contiguous bytes per wave-store: 9 line requests instead of the 12 of
+// four dword wave-stores), tile = 255 lines x 127 columns, 256 threads; an event's 136 image rows leave as three contiguous runs.
+template <int W, bool IMG, bool IQR = false>
+__global__ __launch_bounds__(256, 4) void k_skeleton4(float *__restrict__ out, float *__restrict__ img, int y_t, int x_t, int tiles_l, int tiles_p,
+                                                     int frames, float seed, const float2 *__restrict__ iq = nullptr, int S = 0) {
+  __shared__ float smp[IQR ? 256 * 19 : 1];
+  const unsigned xcd = blockIdx.x, ul = blockIdx.z;
+  const int tl = (int)blockIdx.y;
+  const unsigned U = (unsigned)(frames * tiles_p);
+  const unsigned u = ((((ul >> 1) << 3) + xcd) << 1) + (ul & 1u);
+  if (u >= U) return;
+  const int f = (int)(u / (unsigned)tiles_p), tp = (int)(u % (unsigned)tiles_p);
+  const int wh = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l0 = tl * 255, p0 = tp * 127;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  float a0 = seed + lane, a1 = seed - lane, a2 = seed * 2 + lane, a3 = seed * 3 - lane;
+  if (IQR) {
+    const double sf = (double)S / ((double)y_t * x_t);
+    for (int r = threadIdx.x >> 2; r < 256; r += 64) {      // 4 lanes per line, up to 5 samples each
+      const int ll = min(l0 + r, y_t - 1);
+      const unsigned k0 = (unsigned)(((double)ll * x_t + p0) * sf);
+      for (int t = 0; t < 5; ++t) {
+        const int j = (threadIdx.x & 3) * 5 + t;
+        if (j < 19) {
+          const float2 z = iq[(size_t)f * S + min(k0 + (unsigned)j, (unsigned)S - 1u)];
+          smp[r * 19 + j] = __fsqrt_rn(z.x * z.x + z.y * z.y);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float pos = (float)lane * 0.37f;
+  const int l = l0 + 4 * lane;
+  float *base = out + (size_t)f * y_t * x_t;
+  float *ib = img + (size_t)f * 480000;
+  const int row0 = (l0 * 600) / y_t;
+  for (int i = 0; i < 32; ++i) {
+    const int p = p0 + wh * 32 + i;
+    if (p >= x_t) break;
+#pragma unroll
+    for (int w = 0; w < W; ++w) { a0 = __fmaf_rn(a0, 1.0001f, 0.5f); a1 = __fmaf_rn(a1, 1.0001f, 0.25f); a2 = __fmaf_rn(a2, 1.0001f, 0.125f); a3 = __fmaf_rn(a3, 1.0001f, 0.0625f); }
+    if (IQR) {
+      pos += 0.115f;
+      const int kk = min((int)pos & 15, 17), rr = 4 * lane * 19;
+      a0 += smp[rr + kk]; a1 += smp[rr + 19 + kk]; a2 += smp[rr + 38 + kk]; a3 += smp[rr + 57 + kk];
+    }
+    if (l + 3 < y_t) {
+      float *dst = base + (size_t)p * y_t + l;
+      v4f d = {a0, a1, a2, a3};
+      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(d) : "memory");
+    } else {
+      for (int k = 0; k < 4; ++k) if (l + k < y_t) base[(size_t)p * y_t + l + k] = a0;
+    }
+    if (IMG) {
+      const int c = (p * 800) / x_t;
+      if (c != ((p - 1) * 800) / x_t && c < 800) {
+        float *d2 = ib + (size_t)c * 600 + row0 + lane;
+        if (row0 + lane < 600) asm volatile("global_store_dword %0, %1, off" ::"v"(d2), "v"(a0) : "memory");
+        if (row0 + 64 + lane < 600) asm volatile("global_store_dword %0, %1, off" ::"v"(d2 + 64), "v"(a1) : "memory");
+        if (lane < 8 && row0 + 128 + lane < 600) asm volatile("global_store_dword %0, %1, off" ::"v"(d2 + 128), "v"(a2) : "memory");
+      }
+    }
+  }
+}
+
+template <int W, bool IMG, bool IQR = false>
+static void run_skeleton4(const char *name) {
+  const int y_t = 1125, x_t = 2576, frames = 30, S = 333333;
+  float2 *iq = nullptr;
+  if (hipMalloc(&iq, (size_t)frames * S * 8) != hipSuccess) exit(1);
+  (void)hipMemset(iq, 0, (size_t)frames * S * 8);
+  const int tiles_l = (y_t - 2) / 255 + 1, tiles_p = (x_t - 2) / 127 + 1;
+  const size_t bytes = (size_t)frames * y_t * x_t * 4;
+  float *out, *img;
+  if (hipMalloc(&out, bytes + 4096) != hipSuccess || hipMalloc(&img, (size_t)frames * 480000 * 4 + 4096) != hipSuccess) { printf("alloc failed\n"); exit(1); }
+  const unsigned units = frames * tiles_p, upx = (units + 15) / 16 * 2;
+  const dim3 grid(8, tiles_l, upx);
+  hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) k_skeleton4<W, IMG, IQR><<<grid, 256>>>(out, img, y_t, x_t, tiles_l, tiles_p, frames, 1.0f, iq, S);
+  (void)hipEventRecord(a);
+  const int reps = 20;
+  for (int i = 0; i < reps; ++i) k_skeleton4<W, IMG, IQR><<<grid, 256>>>(out, img, y_t, x_t, tiles_l, tiles_p, frames, 1.0f, iq, S);
+  (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+  float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= reps;
+  const double alg = (double)bytes + (IMG ? frames * 480000.0 * 4 : 0.0) + (IQR ? frames * (double)S * 8 : 0.0);
+  printf("%-58s %7.1f us  %6.2f TB/s algorithmic (%.1f MB)  [%s]\n", name, ms * 1e3, alg / (ms * 1e-3) / 1e12, alg / 1e6, hipGetErrorString(hipGetLastError()));
+  (void)hipFree(out); (void)hipFree(img); (void)hipFree(iq);
 }
 
 template <int W, bool IMG>
@@ -364,8 +453,17 @@ int main() {
   run_skeleton2<6, false>("2 lines/lane: raster stores + 12 fma/pixel");
   run_skeleton2<6, true>("2 lines/lane: raster + image stores + 12 fma/pixel");
   run_skeleton<12, true, false>("(1 line/lane again) raster + image stores + 12 fma/pixel");
+  run_skeleton4<0, false>("4 lines/lane: raster stores only");
+  run_skeleton4<3, false>("4 lines/lane: raster stores + 12 fma/pixel");
+  run_skeleton4<3, true>("4 lines/lane: raster + image stores + 12 fma/pixel");
   run_skeleton2<6, true>("2 lines/lane: raster + image stores + 12 fma/pixel");
   run_skeleton<12, true, false>("(1 line/lane again) raster + image stores + 12 fma/pixel");
+  run_skeleton4<3, true>("4 lines/lane: raster + image stores + 12 fma/pixel");
+  run_skeleton4<3, true, true>("4 lines/lane: raster + image + IQ staging + 12 fma/pixel");
+  run_skeleton<12, true, true>("(1 line/lane) raster + image + IQ staging + 12 fma/pixel");
+  run_skeleton4<3, true, true>("4 lines/lane: raster + image + IQ staging + 12 fma/pixel");
+  run_skeleton<12, true, true>("(1 line/lane) raster + image + IQ staging + 12 fma/pixel");
+  run_skeleton4<6, true, true>("4 lines/lane: raster + image + IQ staging + 24 fma/pixel");
   printf("---- whole-column strips through an LDS image of the output (576 threads, 32 columns x all lines, 8-column sub-tiles)\n");
   run_strip<0, false, 0>("strip: raster stores only");
   run_strip<12, false, 0>("strip: raster stores + 12 fma/pixel");
