@@ -331,8 +331,9 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
  * -- 15 buffers through each of 8 candidates, twice, results identical in all of them -- are timed with HIP events and the rest
  * use the fastest, the sequential order included, so the pipeline is never slower than one call per buffer by more than the
  * measurement's noise (options "pipe_mode" / "pipe_tune"; tsdr_frames_pipeline_info).  What was settled for a configuration is
- * kept (the last 16): going back to one -- a y_t / x_t correction undone, a raster asked for now and then -- measures nothing
- * again.  Up to three image / key / projection slots rotate.
+ * kept (the 8 most recently used): going back to one -- a y_t / x_t correction undone, a raster asked for now and then --
+ * measures nothing again, a configuration within 10 % of a measured one takes over its choice, and "pipe_pin" /
+ * "pipe_measure" override (tsdr_set_option).  Up to three image / key / projection slots rotate.
  * Ordering: a submission waits for whatever the context's stream holds at the time of the call (uploads, a producer's
  * kernels); tsdr_frames_flush -- which only enqueues -- orders the context's stream behind every submitted buffer, so
  * outputs are complete in stream order after the flush and on the host after tsdr_synchronize (which flushes).  Any
@@ -340,7 +341,8 @@ int tsdr_frames_d(tsdr_ctx *ctx, tsdr_sync *sync, const float *iq, size_t nEch, 
  * tsdr_vsync_d, tsdr_sync_reset / _free, tsdr_set_stream, tsdr_dev_free, tsdr_destroy) flushes first, so results never
  * depend on the mix of calls.  Results are identical to calling tsdr_frames_d once per buffer (sync indices; pixels
  * bit for bit, the adaptive guard route included).  A submission whose configuration (frames per buffer, S, y_t, x_t, raster or not, precision, SyncXY) differs
- * from the previous one's waits on the HOST for the buffers in flight (its workspace slots move), as does a trial boundary.
+ * from the previous one's waits on the HOST for the buffers in flight (its workspace slots move), as does every trial boundary of
+ * the measurement (17 boundaries in the first 255 submissions of a measured configuration); these waits are bounded ("wait_ms").
  * Lifetime: until a flush point has been reached AND the context's stream has completed, the caller must not touch or
  * free iq, the SyncXY state, imageOut_state, frames_out / raster_out / sync_idx of submitted work, and each in-flight
  * buffer (up to three) needs its own frames_out / raster_out / sync_idx. */
