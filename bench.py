@@ -527,8 +527,12 @@ def leg_pipeline(env, args, bufs):
             envp["ctx"] = ctxp
             envp["barrier"] = (lambda c=ctxp: (c.synchronize(), env["barrier"]()))
             pl = FramesLeg(envp, args.workload, args.precision, raster=raster, pipeline=True, share=base, card=args.card)
-            r = pl.run(args.steps, args.warmup, max(3, args.repeats // 3), profile=False)
-            out[name] = {k: r[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "msps",
+            # (at least 50 buffers per timed region: every region starts with an empty pipeline and ends with a drain, and at the
+            # driver's K = 20 ramp and drain are a tenth of it; `steps` below says what was used)
+            psteps = max(50, args.steps)
+            r = pl.run(psteps, args.warmup, max(3, args.repeats // 3), profile=False)
+            r["steps"] = psteps
+            out[name] = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "ms_per_step_min", "ms_per_step_max", "msps",
                                            "step_frac_of_hbm_peak", "sync_guard") if k in r}
             out[name]["arrangement"] = pl.pipeline_info   # what the library measured and chose
             pl.free()
