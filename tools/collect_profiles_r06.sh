@@ -38,3 +38,13 @@ cp $R/profiles/traffic.json $O/${TAG}_traffic_full.json
 cd $R
 run_bench
 ls $O | grep $TAG
+# tsdr_group_*: four members on this one device, member threads forced -- do the members' uploads overlap? (memory-copy trace)
+cd /tmp
+for th in 0 2; do
+  rm -rf $O/${TAG}_copytrace
+  rocprofv3 --memory-copy-trace --output-format csv -d $O/${TAG}_copytrace -o run -- python3 $R/tools/group_devices.py 0,0,0,0 C2 threads=$th > $O/${TAG}_group4_threads$th.json 2> /dev/null
+  f=$(find $O/${TAG}_copytrace -name '*memory_copy_trace.csv' | head -1)
+  echo "member_threads=$th: $(python3 $R/tools/copy_overlap.py $f)" >> $O/${TAG}_group4_copy_overlap.txt
+  rm -rf $O/${TAG}_copytrace
+done
+cat $O/${TAG}_group4_copy_overlap.txt

@@ -10,6 +10,6 @@ for i in $(seq 1 $n); do
   timeout -s KILL $lim python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/out_$i.json 2> $out/err_$i.txt
   rc=$?
   e=$(date +%s.%N)
-  echo "run $i rc=$rc wall=$(echo "$e - $s" | bc) last_stage=$(grep '^\[bench\]' $out/err_$i.txt | tail -1)" | tee -a $out/summary.txt
+  echo "run $i rc=$rc wall=$(python3 -c "print(round($e - $s, 1))") last_stage=$(grep '^\[bench\]' $out/err_$i.txt | tail -1)" | tee -a $out/summary.txt
 done
 kill $poll
