@@ -39,7 +39,7 @@ def test_the_driver_command_prints_one_complete_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert d["index_parity"]["sync_idx_equal_exact"] == "90/90"
     assert d["legs"]["failed_or_skipped"] == [], d["legs"]
-    for leg in ("fused", "pipeline", "two_streams", "search", "group", "host_ingest", "spectra", "exact", "c5", "c3"):
+    for leg in ("fused", "pipeline", "two_streams", "search", "group", "host_ingest", "spectra", "exact", "sc16_resident", "c5", "c3"):
         assert isinstance(d[leg], dict) and "error" not in d[leg], (leg, d[leg])
     assert "[bench]" in r.stderr and "leg c3" in r.stderr      # stage lines: a tail of stderr names the last leg reached
 
