@@ -69,7 +69,15 @@ int wait_event(tsdr_ctx *ctx, hipEvent_t e, const char *what) {
 
 int wait_stream(tsdr_ctx *ctx, hipStream_t s, const char *what) {
   if (ctx->opt_wait_ms <= 0) { TSDR_HIP(ctx, hipStreamSynchronize(s)); return TSDR_OK; }
-  if (!ctx->wait_ev) TSDR_HIP(ctx, hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
+  if (!ctx->wait_ev) {
+    // (an event belongs to the device that is current when it is created: the context's, whatever the caller's is)
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device) TSDR_HIP(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming);
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipEventCreateWithFlags");
+  }
   TSDR_HIP(ctx, hipEventRecord(ctx->wait_ev, s));
   return wait_event(ctx, ctx->wait_ev, what);
 }
