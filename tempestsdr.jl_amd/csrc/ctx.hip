@@ -49,21 +49,21 @@ int wait_event(tsdr_ctx *ctx, hipEvent_t e, const char *what) {
   if (ctx->opt_wait_ms <= 0) { TSDR_HIP(ctx, hipEventSynchronize(e)); return TSDR_OK; }
   using clk = std::chrono::steady_clock;
   clk::time_point t0;
+  bool slow = false;   // past the first 300 us: one look per 50 us sleep (a waiting GUI thread must not burn a core)
   for (unsigned it = 1;; ++it) {
     const hipError_t q = hipEventQuery(e);
     if (q == hipSuccess) return TSDR_OK;
     if (q != hipErrorNotReady) return hip_fail(ctx, q, what);
     (void)hipGetLastError();   // (hipErrorNotReady is a status, not a failure for the next launch check to find)
-    if ((it & 0x3Fu) == 0) {
-      const auto now = clk::now();
-      if (it == 0x40u) { t0 = now; continue; }
-      const auto waited = now - t0;
-      if (waited > std::chrono::milliseconds(ctx->opt_wait_ms)) {
-        ++ctx->wait_timeouts;
-        return set_err(ctx, TSDR_EHIP, "%s: the stream did not complete within %d ms (bounded host wait; option wait_ms)", what, ctx->opt_wait_ms);
-      }
-      if (waited > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if (!slow && (it & 0x3Fu) != 0) continue;
+    const auto now = clk::now();
+    if (it == 0x40u) { t0 = now; continue; }
+    const auto waited = now - t0;
+    if (waited > std::chrono::milliseconds(ctx->opt_wait_ms)) {
+      ++ctx->wait_timeouts;
+      return set_err(ctx, TSDR_EHIP, "%s: the stream did not complete within %d ms (bounded host wait; option wait_ms)", what, ctx->opt_wait_ms);
     }
+    if (waited > std::chrono::microseconds(300)) { slow = true; std::this_thread::sleep_for(std::chrono::microseconds(50)); }
   }
 }
 
