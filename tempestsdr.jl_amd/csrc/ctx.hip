@@ -42,14 +42,15 @@ int lds_opt_in(tsdr_ctx *ctx, const void *fn, size_t bytes) {
 }
 
 // ---- bounded host-side waits -----------------------------------------------------------------------------------------
-// One marker event behind whatever the stream holds, then polls of that event: a tight spin first (results of a 15 us launch
-// must not pay a sleep), then 50 us sleeps.  hipStreamSynchronize has no time limit: a lane held behind something that
+// One marker event behind whatever the stream holds, then polls of that event: a tight spin for the first 25 ms (results of a
+// 15 us launch, or the end of a bench region, must not pay a sleep), then 50 us sleeps.  hipStreamSynchronize has no time limit: a lane held behind something that
 // never completes would hold the caller's thread with it.
 int wait_event(tsdr_ctx *ctx, hipEvent_t e, const char *what) {
   if (ctx->opt_wait_ms <= 0) { TSDR_HIP(ctx, hipEventSynchronize(e)); return TSDR_OK; }
   using clk = std::chrono::steady_clock;
   clk::time_point t0;
-  bool slow = false;   // past the first 300 us: one look per 50 us sleep (a waiting GUI thread must not burn a core)
+  bool slow = false;   // past the first 25 ms: one look per 50 us sleep (a thread that waits long must not burn a core; a short wait --
+                       // the end of a timed region among them -- is seen within a microsecond, like hipStreamSynchronize's own spin)
   for (unsigned it = 1;; ++it) {
     const hipError_t q = hipEventQuery(e);
     if (q == hipSuccess) return TSDR_OK;
@@ -63,7 +64,7 @@ int wait_event(tsdr_ctx *ctx, hipEvent_t e, const char *what) {
       ++ctx->wait_timeouts;
       return set_err(ctx, TSDR_EHIP, "%s: the stream did not complete within %d ms (bounded host wait; option wait_ms)", what, ctx->opt_wait_ms);
     }
-    if (waited > std::chrono::microseconds(300)) { slow = true; std::this_thread::sleep_for(std::chrono::microseconds(50)); }
+    if (waited > std::chrono::milliseconds(25)) { slow = true; std::this_thread::sleep_for(std::chrono::microseconds(50)); }
   }
 }
 
