@@ -248,7 +248,7 @@ class FramesLeg:
             dom_ms = prof[dom_name]["total_ms"] / prof[dom_name]["launches"]
             gbs = kb.get(dom_name, 0) / (dom_ms * 1e-3) / 1e9
             out["dominant"] = {"kernel": dom_name, "avg_launch_ms": round(dom_ms, 5), "algorithmic_bytes_per_launch": kb.get(dom_name, 0),
-                               "traffic": measured_traffic(self.workload, dom_name),
+                               "traffic": measured_traffic(self.workload, dom_name) if self.iq_fmt == "cf32" else None,   # (PMC passes: ComplexF32 input)
                                "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
             out["kernels_ms_per_step"] = {k: round(v["total_ms"] / steps, 5) for k, v in sorted(prof.items())}
         return out
