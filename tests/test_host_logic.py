@@ -359,3 +359,28 @@ def test_bench_group_child_failure_is_reported_not_raised():
     assert r["devices"] == "0,1" and "error" in r and "exit code" in r["error"]
     r = bench.run_group_child("0,1", "C2", timeout=0.2)
     assert "error" in r and "no result within" in r["error"]
+
+
+def test_bench_child_leg_that_fails_becomes_an_error_entry_not_an_exception():
+    """bench.py runs every leg beside the headline in a child process (round 6).  Without a GPU the child cannot even create its
+    context: the parent's run_child must turn that into an {"error": ...} entry that names the exit code and the last stage the
+    child reached -- never raise, never hang -- and the line's packing (finish_line) must keep error / skip texts in place."""
+    import argparse
+    import importlib.util
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the child would succeed")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = argparse.Namespace(steps=2, warmup=1, repeats=2, workload="C2", precision="fast", card="box", search_steps=1, no_raster=False)
+    r = bench.run_child("search", args, None, timeout=120)
+    assert isinstance(r, dict) and "error" in r and "exit code" in r["error"] and "last stage" in r["error"], r
+    line = {"value": 1.0, "ms_per_step": 2.0, "roofline": {"kernel": "k", "frac": 0.5}, "search": r,
+            "c3": {"skipped": "the run's time budget (280 s) was used up before this leg " + "x" * 120},
+            "config": {"workload": "w" * 150}, "legs": {"failed_or_skipped": ["search", "c3"], "wall_s": 1.0}}
+    out = bench.finish_line(line)
+    assert out["search"]["error"] == r["error"] and out["c3"]["skipped"].startswith("the run's time budget")
+    assert out["summary"]["legs_failed_or_skipped"] == ["search", "c3"] and out["config"]["workload"] == "w" * 150
+    assert set(bench.LEGS) == set(bench.LINE_KEY) and "group" == list(bench.LEGS)[-1]     # (the never-run N > 1 path last)
