@@ -44,6 +44,7 @@ for th in 0 2; do
   rm -rf $O/${TAG}_copytrace
   rocprofv3 --memory-copy-trace --output-format csv -d $O/${TAG}_copytrace -o run -- python3 $R/tools/group_devices.py 0,0,0,0 C2 threads=$th > $O/${TAG}_group4_threads$th.json 2> /dev/null
   f=$(find $O/${TAG}_copytrace -name '*memory_copy_trace.csv' | head -1)
+  cp $f $O/${TAG}_group4_threads${th}_memory_copy_trace.csv
   echo "member_threads=$th: $(python3 $R/tools/copy_overlap.py $f)" >> $O/${TAG}_group4_copy_overlap.txt
   rm -rf $O/${TAG}_copytrace
 done
