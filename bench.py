@@ -494,7 +494,14 @@ def emit(obj):
         if _EMITTED[0]:
             return False
         _EMITTED[0] = True
-        os.write(_REAL_STDOUT, (json.dumps(obj) + "\n").encode())
+        data = (json.dumps(obj) + "\n").encode()
+        while data:   # (a pipe may take the ~20 KB line in pieces)
+            try:
+                n = os.write(_REAL_STDOUT, data)
+            except BlockingIOError:
+                time.sleep(0.01)
+                continue
+            data = data[n:]
         return True
 
 
